@@ -1,0 +1,5 @@
+"""CPU oracle package -- TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from .binding import OracleChain, OrcCfg, OrcTaps, build, firdes_kaiser, lib  # noqa: F401

@@ -1,0 +1,178 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle_pmr.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle_pmr.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("orc_dsp.c", "orc_chain.c", "orc_dsp.h", "orc_chain.h")]
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class OrcCfg(C.Structure):
+    _fields_ = [
+        ("fs_in", C.c_double), ("num_channels", C.c_uint), ("channel_width_hz", C.c_double),
+        ("dcblock_alpha", C.c_float), ("resamp_As", C.c_float), ("pfb_m", C.c_uint), ("pfb_As", C.c_float),
+        ("fm_kf", C.c_float), ("audio_gain", C.c_float), ("lowpass", C.c_int), ("deemph_fir", C.c_int),
+        ("max_block", C.c_uint), ("only_channel", C.c_int),
+        ("hp_taps", C.POINTER(C.c_float)), ("hp_len", C.c_uint),
+        ("lp_taps", C.POINTER(C.c_float)), ("lp_len", C.c_uint),
+        ("deemph_taps", C.POINTER(C.c_float)), ("deemph_len", C.c_uint),
+    ]
+
+
+class OrcTaps(C.Structure):
+    _fields_ = [
+        ("resampled", C.c_void_p), ("resampled_cap", C.c_uint), ("n_resampled", C.c_uint),
+        ("fm", C.c_void_p), ("ctcss_lp", C.c_void_p), ("audio", C.c_void_p), ("stride", C.c_uint),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_chain_default_cfg.argtypes = [C.POINTER(OrcCfg)]
+        L.orc_chain_create.argtypes = [C.POINTER(OrcCfg)]
+        L.orc_chain_create.restype = C.c_void_p
+        L.orc_chain_reset.argtypes = [C.c_void_p]
+        L.orc_chain_destroy.argtypes = [C.c_void_p]
+        L.orc_chain_max_frames.argtypes = [C.c_void_p]
+        L.orc_chain_max_frames.restype = C.c_uint
+        L.orc_chain_max_resampled.argtypes = [C.c_void_p]
+        L.orc_chain_max_resampled.restype = C.c_uint
+        L.orc_chain_process_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint,
+                                              C.POINTER(C.c_uint), C.c_void_p, C.c_void_p, C.POINTER(OrcTaps)]
+        L.orc_chain_process_block.restype = C.c_int
+        L.orc_firdes_kaiser.argtypes = [C.c_uint, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.orc_kaiser_beta_As.argtypes = [C.c_float]
+        L.orc_kaiser_beta_As.restype = C.c_float
+        L.orc_estimate_req_filter_len.argtypes = [C.c_float, C.c_float]
+        L.orc_estimate_req_filter_len.restype = C.c_uint
+        L.orc_nco_constrain.argtypes = [C.c_float]
+        L.orc_nco_constrain.restype = C.c_uint32
+        L.orc_pcm_from_float.argtypes = [C.c_float]
+        L.orc_pcm_from_float.restype = C.c_int16
+        L.orc_msresamp_crcf_create.argtypes = [C.c_float, C.c_float]
+        L.orc_msresamp_crcf_create.restype = C.c_void_p
+        L.orc_msresamp_crcf_destroy.argtypes = [C.c_void_p]
+        L.orc_msresamp_crcf_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.POINTER(C.c_uint)]
+        L.orc_firpfbch_crcf_create_kaiser.argtypes = [C.c_uint, C.c_uint, C.c_float]
+        L.orc_firpfbch_crcf_create_kaiser.restype = C.c_void_p
+        L.orc_firpfbch_crcf_destroy.argtypes = [C.c_void_p]
+        L.orc_firpfbch_crcf_analyzer_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_iirfilt_crcf_create_dc_blocker.argtypes = [C.c_float]
+        L.orc_iirfilt_crcf_create_dc_blocker.restype = C.c_void_p
+        L.orc_iirfilt_crcf_destroy.argtypes = [C.c_void_p]
+        L.orc_iirfilt_crcf_execute_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        L.orc_fft_create.argtypes = [C.c_uint]
+        L.orc_fft_create.restype = C.c_void_p
+        L.orc_fft_destroy.argtypes = [C.c_void_p]
+        L.orc_fft_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def firdes_kaiser(n, fc, As, mu=0.0):
+    h = np.zeros(n, dtype=np.float32)
+    lib().orc_firdes_kaiser(n, fc, As, mu, h.ctypes.data)
+    return h
+
+
+class OracleChain:
+    """Mirror of the reference loop body; see oracle/orc_chain.h."""
+
+    def __init__(self, fs_in=1024000.0, num_channels=16, max_block=100000, audio_gain=4.0, lowpass=False,
+                 deemph_fir=False, only_channel=-1, channel_width_hz=12500.0, pfb_m=13, pfb_As=80.0,
+                 resamp_As=60.0, dcblock_alpha=0.0005, fm_kf=0.5):
+        L = lib()
+        cfg = OrcCfg()
+        L.orc_chain_default_cfg(C.byref(cfg))
+        cfg.fs_in = fs_in
+        cfg.num_channels = num_channels
+        cfg.channel_width_hz = channel_width_hz
+        cfg.max_block = max_block
+        cfg.audio_gain = audio_gain
+        cfg.lowpass = int(lowpass)
+        cfg.deemph_fir = int(deemph_fir)
+        cfg.only_channel = only_channel
+        cfg.pfb_m = pfb_m
+        cfg.pfb_As = pfb_As
+        cfg.resamp_As = resamp_As
+        cfg.dcblock_alpha = dcblock_alpha
+        cfg.fm_kf = fm_kf
+        self.cfg = cfg
+        self.M = num_channels
+        self.h = L.orc_chain_create(C.byref(cfg))
+        if not self.h:
+            raise RuntimeError("orc_chain_create failed")
+        self.max_frames = L.orc_chain_max_frames(self.h)
+        self.max_resampled = L.orc_chain_max_resampled(self.h)
+
+    def reset(self):
+        lib().orc_chain_reset(self.h)
+
+    def close(self):
+        if self.h:
+            lib().orc_chain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_block(self, iq, want=("pcm",)):
+        """iq: complex64 array.  Returns dict with n_frames and the requested outputs, trimmed to n_frames."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        M, S = self.M, self.max_frames
+        want = set(want)
+        pcm = np.zeros((M, S), dtype=np.int16)
+        chan = np.zeros((M, S), dtype=np.complex64) if "chan" in want else None
+        rssi = np.zeros(M, dtype=np.float32) if "rssi" in want else None
+        taps = OrcTaps()
+        bufs = {}
+        if "resampled" in want:
+            bufs["resampled"] = np.zeros(self.max_resampled, dtype=np.complex64)
+            taps.resampled = bufs["resampled"].ctypes.data
+            taps.resampled_cap = self.max_resampled
+        for name in ("fm", "ctcss_lp", "audio"):
+            if name in want:
+                bufs[name] = np.zeros((M, S), dtype=np.float32)
+                setattr(taps, name, bufs[name].ctypes.data)
+        taps.stride = S
+        ns = C.c_uint(0)
+        rc = lib().orc_chain_process_block(
+            self.h, iq.ctypes.data, len(iq), pcm.ctypes.data, S, C.byref(ns),
+            chan.ctypes.data if chan is not None else None,
+            rssi.ctypes.data if rssi is not None else None, C.byref(taps))
+        if rc != 0:
+            raise RuntimeError("orc_chain_process_block rc=%d" % rc)
+        n = ns.value
+        out = {"n_frames": n, "pcm": pcm[:, :n].copy()}
+        if chan is not None:
+            out["chan"] = chan[:, :n].copy()
+        if rssi is not None:
+            out["rssi"] = rssi
+        if "resampled" in bufs:
+            out["resampled"] = bufs["resampled"][:taps.n_resampled].copy()
+        for name in ("fm", "ctcss_lp", "audio"):
+            if name in bufs:
+                out[name] = bufs[name][:, :n].copy()
+        return out

@@ -1,0 +1,206 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see oracle/README.md, orc_chain.h). */
+#include "orc_chain.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../sdr_pmr446_amd/data/pmr446_taps.h"
+
+void orc_chain_default_cfg(orc_chain_cfg *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->fs_in = 1024000.0;          /* include/sdr_pmr446.h:13 */
+    c->num_channels = 16;          /* src/sdr_pmr446.c:23 */
+    c->channel_width_hz = 12500.0; /* :22 */
+    c->dcblock_alpha = 0.0005f;    /* :422 */
+    c->resamp_As = 60.0f;          /* :426 */
+    c->pfb_m = 13; c->pfb_As = 80.0f; /* :437 */
+    c->fm_kf = 0.5f;               /* :440 */
+    c->audio_gain = 4.0f;          /* :33 */
+    c->lowpass = 0;                /* :154 */
+    c->deemph_fir = 0;             /* :457 */
+    c->max_block = 100000;         /* :30 */
+    c->only_channel = -1;
+}
+
+/* PCM hand-off: reference src/dsd_in.c:172-175 `buf_out_s[i] = out_buf[i] * INT16_MAX` (C float->int16
+ * truncation toward zero).  Saturation is this build's addition (SURVEY s7 "PCM convention").       */
+int16_t orc_pcm_from_float(float x)
+{
+    float s = x * 32767.0f;
+    if (!(s == s)) return 0;
+    if (s >= 32767.0f) return 32767;
+    if (s <= -32768.0f) return -32768;
+    return (int16_t)s;
+}
+
+/* reference src/sdr_pmr446.c:330-336 */
+static float average_power(const cf32 *data, size_t len)
+{
+    float a = 0.0f;
+    for (size_t i = 0; i < len; i++) a += cabsf(data[i]);
+    return 20 * log10f(a / len);
+}
+
+orc_chain *orc_chain_create(const orc_chain_cfg *cfg)
+{
+    orc_chain *q = (orc_chain *)calloc(1, sizeof(*q));
+    q->cfg = *cfg;
+    unsigned M = q->M = cfg->num_channels;
+    if (!q->cfg.hp_taps)     { q->cfg.hp_taps = pmr446_hp_audio_taps; q->cfg.hp_len = PMR446_HP_AUDIO_TAPS_LEN; }
+    if (!q->cfg.lp_taps)     { q->cfg.lp_taps = pmr446_lp_audio_taps; q->cfg.lp_len = PMR446_LP_AUDIO_TAPS_LEN; }
+    if (!q->cfg.deemph_taps) { q->cfg.deemph_taps = pmr446_deemph_taps; q->cfg.deemph_len = PMR446_DEEMPH_TAPS_LEN; }
+
+    /* src/sdr_pmr446.c:27,425-426: resample to M * channel width */
+    float resamplerate = (float)((double)M * cfg->channel_width_hz);
+    float rate = resamplerate / (float)cfg->fs_in;
+
+    /* :730-736 buffer sizing (integer division before ceilf, as in the reference) */
+    q->res_size = (unsigned)ceilf(1 + 2 * (float)cfg->max_block * rate);
+    q->chan_size = (unsigned)ceilf((float)(q->res_size / M));
+    if (q->chan_size < 1) q->chan_size = 1;
+
+    q->dcblock = orc_iirfilt_crcf_create_dc_blocker(cfg->dcblock_alpha);            /* :422 */
+    q->resampler = orc_msresamp_crcf_create(rate, cfg->resamp_As);                  /* :425 */
+    if (!q->resampler) { orc_chain_destroy(q); return NULL; }
+    float offset = -0.5f * (float)(M - 1) / (float)M * 2 * M_PI;                    /* :432-433 */
+    orc_nco_reset(&q->nco);
+    orc_nco_set_frequency(&q->nco, offset);                                         /* :434 */
+    q->channelizer = orc_firpfbch_crcf_create_kaiser(M, cfg->pfb_m, cfg->pfb_As);   /* :436 */
+    if (!q->channelizer) { orc_chain_destroy(q); return NULL; }
+    q->resamp_ring = orc_cbuffercf_create(q->res_size + M);                         /* :467 (+M: carried remainder) */
+
+    q->ch = (orc_chan_state *)calloc(M, sizeof(orc_chan_state));
+    for (unsigned i = 0; i < M; i++) {
+        orc_chan_state *c = &q->ch[i];
+        orc_freqdem_init(&c->fm_demod, cfg->fm_kf);                                               /* :440 */
+        c->ctcss_filt = orc_firfilt_rrrf_create(q->cfg.hp_taps, q->cfg.hp_len);                   /* :443 */
+        c->ctcss_lp_delay = orc_wdelayf_create((q->cfg.hp_len - 1) / 2);                          /* :447 */
+        c->audio_filt = orc_firfilt_rrrf_create(q->cfg.lp_taps, q->cfg.lp_len);                   /* :453 */
+        if (cfg->deemph_fir) {
+            c->deemph_fir = orc_firfilt_rrrf_create(q->cfg.deemph_taps, q->cfg.deemph_len);       /* :458 */
+        } else {
+            float b[2] = {0.507301437230636, 0.507301437230636};                                  /* :462 */
+            float a[2] = {1.0, 0.014602874461272194};                                             /* :463 */
+            c->deemph_iir = orc_iirfilt_rrrf_create(b, 2, a, 2);
+        }
+    }
+    q->buffp = (cf32 *)calloc(cfg->max_block ? cfg->max_block : 1, sizeof(cf32));
+    q->resamp_buf = (cf32 *)calloc(q->res_size, sizeof(cf32));
+    q->tmp_chan_out = (cf32 *)calloc(M, sizeof(cf32));
+    q->chan_bufs = (cf32 *)calloc((size_t)M * q->chan_size, sizeof(cf32));
+    q->tmp1 = (float *)calloc(q->chan_size, sizeof(float));
+    q->tmp2 = (float *)calloc(q->chan_size, sizeof(float));
+    return q;
+}
+
+int orc_chain_reset(orc_chain *q)
+{
+    orc_iirfilt_crcf_reset(q->dcblock);
+    orc_msresamp_crcf_reset(q->resampler);
+    orc_nco_reset(&q->nco);
+    orc_firpfbch_crcf_reset(q->channelizer);
+    orc_cbuffercf_reset(q->resamp_ring);
+    for (unsigned i = 0; i < q->M; i++) {
+        orc_chan_state *c = &q->ch[i];
+        orc_freqdem_reset(&c->fm_demod);
+        orc_firfilt_rrrf_reset(c->ctcss_filt);
+        orc_wdelayf_reset(c->ctcss_lp_delay);
+        orc_firfilt_rrrf_reset(c->audio_filt);
+        if (c->deemph_iir) orc_iirfilt_rrrf_reset(c->deemph_iir);
+        if (c->deemph_fir) orc_firfilt_rrrf_reset(c->deemph_fir);
+    }
+    return 0;
+}
+
+int orc_chain_destroy(orc_chain *q)
+{
+    if (!q) return 0;
+    orc_iirfilt_crcf_destroy(q->dcblock);
+    orc_msresamp_crcf_destroy(q->resampler);
+    orc_firpfbch_crcf_destroy(q->channelizer);
+    orc_cbuffercf_destroy(q->resamp_ring);
+    if (q->ch) for (unsigned i = 0; i < q->M; i++) {
+        orc_chan_state *c = &q->ch[i];
+        orc_firfilt_rrrf_destroy(c->ctcss_filt);
+        orc_wdelayf_destroy(c->ctcss_lp_delay);
+        orc_firfilt_rrrf_destroy(c->audio_filt);
+        orc_iirfilt_rrrf_destroy(c->deemph_iir);
+        orc_firfilt_rrrf_destroy(c->deemph_fir);
+    }
+    free(q->ch); free(q->buffp); free(q->resamp_buf); free(q->tmp_chan_out);
+    free(q->chan_bufs); free(q->tmp1); free(q->tmp2); free(q);
+    return 0;
+}
+
+unsigned orc_chain_max_frames(const orc_chain *q) { return q->chan_size; }
+unsigned orc_chain_max_resampled(const orc_chain *q) { return q->res_size; }
+
+int orc_chain_process_block(orc_chain *q, const cf32 *iq, unsigned n_in,
+                            int16_t *pcm, unsigned pcm_stride, unsigned *n_frames,
+                            cf32 *chan_out, float *rssi_db, orc_taps *taps)
+{
+    const unsigned M = q->M;
+    if (n_in > q->cfg.max_block) return 1;
+    unsigned ny = 0;
+
+    memcpy(q->buffp, iq, (size_t)n_in * sizeof(cf32));
+    orc_iirfilt_crcf_execute_block(q->dcblock, q->buffp, n_in, q->buffp);              /* :795 */
+    orc_msresamp_crcf_execute(q->resampler, q->buffp, n_in, q->resamp_buf, &ny);       /* :796 */
+    if (taps && taps->resampled) {
+        unsigned n = ny < taps->resampled_cap ? ny : taps->resampled_cap;
+        memcpy(taps->resampled, q->resamp_buf, (size_t)n * sizeof(cf32));
+        taps->n_resampled = ny;
+    }
+    if (orc_cbuffercf_write(q->resamp_ring, q->resamp_buf, ny)) return 2;              /* :797 */
+
+    unsigned ns = 0, num_read;
+    cf32 *rpc;
+    while (orc_cbuffercf_size(q->resamp_ring) >= M) {                                  /* :804 */
+        orc_cbuffercf_read(q->resamp_ring, M, &rpc, &num_read);                        /* :805 */
+        for (unsigned i = 0; i < M; i++) {                                             /* :808-812 */
+            rpc[i] = orc_nco_mix_down(&q->nco, rpc[i]);
+            orc_nco_step(&q->nco);
+        }
+        orc_firpfbch_crcf_analyzer_execute(q->channelizer, rpc, q->tmp_chan_out);      /* :814 */
+        orc_cbuffercf_release(q->resamp_ring, num_read);                               /* :815 */
+        if (ns >= q->chan_size) return 3;                                              /* :825 */
+        for (unsigned i = 0; i < M; i++)                                               /* :819-821 */
+            q->chan_bufs[(size_t)i * q->chan_size + ns] = q->tmp_chan_out[i];
+        ns++;
+    }
+    if (n_frames) *n_frames = ns;
+    if ((pcm || chan_out) && ns > pcm_stride) return 4;
+
+    for (unsigned i = 0; i < M; i++) {
+        const cf32 *row = q->chan_bufs + (size_t)i * q->chan_size;
+        if (chan_out) memcpy(chan_out + (size_t)i * pcm_stride, row, (size_t)ns * sizeof(cf32));
+        if (rssi_db) rssi_db[i] = average_power(row, ns);                              /* :680 */
+    }
+
+    for (unsigned i = 0; i < M; i++) {                                                 /* :876 */
+        if (q->cfg.only_channel >= 0 && (unsigned)q->cfg.only_channel != i) continue;  /* :877 */
+        orc_chan_state *c = &q->ch[i];
+        const cf32 *row = q->chan_bufs + (size_t)i * q->chan_size;
+        float *t1 = q->tmp1, *t2 = q->tmp2;
+
+        orc_freqdem_demodulate_block(&c->fm_demod, row, ns, t1);                       /* :881 */
+        if (taps && taps->fm) memcpy(taps->fm + (size_t)i * taps->stride, t1, ns * sizeof(float));
+        orc_firfilt_rrrf_execute_block(c->ctcss_filt, t1, ns, t2);                     /* :882 */
+        for (unsigned k = 0; k < ns; k++) {                                            /* :884-891 */
+            orc_wdelayf_push(c->ctcss_lp_delay, t1[k]);
+            float tmp = orc_wdelayf_read(c->ctcss_lp_delay);
+            t1[k] = tmp - t2[k];
+            t2[k] *= q->cfg.audio_gain;
+        }
+        if (taps && taps->ctcss_lp) memcpy(taps->ctcss_lp + (size_t)i * taps->stride, t1, ns * sizeof(float));
+        if (c->deemph_fir) orc_firfilt_rrrf_execute_block(c->deemph_fir, t2, ns, t2);  /* :896 */
+        else               orc_iirfilt_rrrf_execute_block(c->deemph_iir, t2, ns, t2);  /* :898 */
+        if (q->cfg.lowpass) orc_firfilt_rrrf_execute_block(c->audio_filt, t2, ns, t2); /* :901 */
+        if (taps && taps->audio) memcpy(taps->audio + (size_t)i * taps->stride, t2, ns * sizeof(float));
+        if (pcm) for (unsigned k = 0; k < ns; k++)                                     /* :904 / dsd_in.c:174 */
+            pcm[(size_t)i * pcm_stride + k] = orc_pcm_from_float(t2[k]);
+    }
+    return 0;
+}
