@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- complex-IQ Msamples/s through the full chain (BASELINE.json metric) on N MI355X.
+
+One "step" = one pmr_chain_process_block_device() call: one block of synthetic cf32 IQ, already resident in
+HBM, through dc-block -> resample -> NCO -> M-channel polyphase channelizer -> NBFM discriminator for all M
+channels -> CTCSS high-pass -> gain -> de-emphasis -> int16 PCM (left in HBM).  The path shards by independent
+IQ stream: rank r owns stream r on GPU r, no data-path collective (torch.distributed is used only for the
+start/stop barrier and the max-over-ranks of the elapsed time).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (fs_in, M, default log2 block)  -- BASELINE.json configs
+    "cfg2": (2.4e6, 16, 26),      # configs[1]: 16-ch PMR446 chain @ 2.4 MS/s on one MI355X (the metric's config)
+    "cfg3": (61.44e6, 256, 26),   # configs[2]
+    "cfg5": (1.0e9, 1024, 26),    # configs[4]
+}
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def cpu_baseline(fs, M, block_host, seconds_target=12.0):
+    """Time the CPU oracle (kind 'port': the reference itself needs liquid-dsp and cannot be built here) on a
+    bounded sample of the same workload, single thread like the reference's DSP thread (src/sdr_pmr446.c:788)."""
+    import numpy as np
+    import oracle
+    n_probe = min(len(block_host), 1 << 20)
+    ch = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n_probe)
+    t0 = time.perf_counter()
+    ch.process_block(block_host[:n_probe], want=("pcm",))
+    rate = n_probe / (time.perf_counter() - t0)
+    ch.close()
+    n = int(min(len(block_host), max(n_probe, rate * seconds_target)))
+    n_blocks = max(1, n // n_probe)
+    ch = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n_probe)
+    t0 = time.perf_counter()
+    for b in range(n_blocks):
+        ch.process_block(block_host[b * n_probe:(b + 1) * n_probe], want=("pcm",))
+    dt = time.perf_counter() - t0
+    ch.close()
+    total = n_blocks * n_probe
+    return {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d blocks x %d samples of the same synthetic IQ, all %d channels demodulated, %.1f s" %
+                      (n_blocks, n_probe, M, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--log2-block", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    from sdr_pmr446_amd import chain as pmr
+    from sdr_pmr446_amd.synth_torch import synth_iq_torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    fs, M, lb = WORKLOADS[args.workload]
+    lb = args.log2_block if args.log2_block is not None else lb
+    block = 1 << lb
+
+    ch = pmr.PmrChain(fs_in=fs, num_channels=M, max_block=block, device=local_rank)
+    S = ch.max_frames
+    iq = synth_iq_torch(block, fs, M, dev, stream_id=rank)          # resident in HBM before timing
+    pcm = torch.zeros((M, S), dtype=torch.int16, device=dev)        # PCM stays in HBM
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        return ch.process_block_device(iq.data_ptr(), block, d_pcm=pcm.data_ptr(), stride=S)
+
+    for _ in range(args.warmup):
+        step()
+    ch.synchronize()
+    ch.profile_reset()
+    ch.profile_enable(not args.no_kernel_events)
+
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(args.steps):
+        frames += step()
+    ch.synchronize()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    ch.profile_enable(False)
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    prof = ch.profile()
+    if rank == 0:
+        r = M * 12500.0 / fs
+        b_alg = 8.0 + 2.0 * r                                        # bytes per input sample
+        value = world * args.steps * block / dt / 1e6
+        roof = None
+        if prof:
+            name, (ms, n) = max(prof.items(), key=lambda kv: kv[1][0])
+            avg_s = ms / n * 1e-3
+            launches_per_step = n / args.steps
+            achieved = b_alg * block / launches_per_step / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": ms / n,
+                    "launches_per_step": launches_per_step,
+                    "algorithmic_bytes_per_sample": b_alg,
+                    "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items())}}
+        out = {
+            "metric": "complex-IQ Msamples/s through full channelize+demod chain", "value": value,
+            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d-ch PMR446 chain @ %.4g MS/s, one independent IQ stream per GPU" %
+                                   (args.workload, M, fs / 1e6),
+                       "block_samples": block, "frames_per_step": frames // max(1, args.steps),
+                       "channels_demodulated": M, "hbm_frac_of_peak_whole_chain": value * 1e6 * b_alg / 1e9 / world / HBM_PEAK_GBPS},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = min(block, 1 << 24)
+            out["cpu_baseline"] = cpu_baseline(fs, M, iq[:n_cpu].cpu().numpy())
+        print(json.dumps(out), flush=True)
+    ch.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+/* pmr_chain.h -- C-ABI of the MI355X-native per-block IQ DSP chain (libpmr446_hip.so).
+ *
+ * One call = one iteration of the reference's block loop body, src/sdr_pmr446.c:795-906:
+ *   dc-block (:795) -> msresamp (:796) -> ring carry (:797,:804-805,:815) -> NCO shift (:808-812)
+ *   -> firpfbch analyzer (:814) -> transpose (:819-821) -> freqdem (:881) -> CTCSS high-pass (:882)
+ *   -> gain (:890) -> de-emphasis (:895-899) -> optional low-pass (:900-902) -> audio hand-off (:903-906)
+ * executed by hand-written gfx950 HIP kernels, for ALL M channels (the reference demodulates the one
+ * squelch-selected channel, :876-877).  The reference has no process-one-block function (the body is inline
+ * in main()); this header defines it, keeping liquid-dsp's conventions at the call sites it replaces:
+ * opaque handle, xxx_create() returns NULL on failure, int return codes with 0 == OK (LIQUID_OK), the
+ * caller owns every sample buffer, one thread per handle, handles are independent (one IQ stream = one
+ * GPU = one handle; that is the multi-GPU model, no collectives).
+ *
+ * Plain C: no C++ or torch types.  Binding sketch for the reference's main(): see INTEGRATION.md.
+ */
+#ifndef PMR_CHAIN_H
+#define PMR_CHAIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+typedef struct { float re, im; } pmr_cf32;          /* layout-identical to C99 float _Complex */
+#else
+typedef float _Complex pmr_cf32;                    /* == SOAPY_SDR_CF32 sample, src/shared.c:62 */
+#endif
+
+typedef struct pmr_chain_s *pmr_chain;
+
+/* Runtime replacements for the #defines / literals of src/sdr_pmr446.c:18-46 and init_liquid() :420-480. */
+typedef struct {
+    double   fs_in;              /* include/sdr_pmr446.h:13  SDR_SAMPLERATE      1024000            */
+    unsigned num_channels;       /* src/sdr_pmr446.c:23      NUM_CHANNELS        16 (power of two)  */
+    double   channel_width_hz;   /* :22                      CHANNEL_WIDTH_HZ    12500              */
+    float    dcblock_alpha;      /* :422  iirfilt_crcf_create_dc_blocker         0.0005f            */
+    float    resamp_As;          /* :426  msresamp_crcf_create                   60.0f              */
+    unsigned pfb_m;              /* :437  firpfbch_crcf_create_kaiser            13                 */
+    float    pfb_As;             /* :437                                         80.0f              */
+    float    fm_kf;              /* :440  freqdem_create                         0.5f               */
+    float    audio_gain;         /* :33,:890  SDR_DEFAULT_AUDIO_GAIN             4.0f               */
+    int      lowpass;            /* :154,:900  args.lowpass                      0                  */
+    int      deemph_fir;         /* :457  APP_FIR_DEEMPH                         0 = IIR            */
+    unsigned max_block;          /* :30   SDR_INPUT_CHUNK                        100000             */
+    int      device;             /* HIP device ordinal; -1 = current device                         */
+    /* Fixed-coefficient tables the app hands to firfilt_rrrf_create (:443,:453,:458).
+     * NULL selects the PMR446 tables of src/sdr_pmr446.c:56-136.                                   */
+    const float *hp_taps;     unsigned hp_len;      /* 377 */
+    const float *lp_taps;     unsigned lp_len;      /* 103 */
+    const float *deemph_taps; unsigned deemph_len;  /* 101 */
+} pmr_chain_cfg;
+
+/* error codes (0 == OK, like LIQUID_OK) */
+enum {
+    PMR_OK = 0,
+    PMR_EINVAL = 1,      /* bad argument / configuration                  */
+    PMR_ERANGE = 2,      /* n_in > max_block, or stride < frames produced */
+    PMR_EHIP = 3,        /* a HIP runtime call or kernel launch failed    */
+    PMR_ENOMEM = 4
+};
+
+void      pmr_chain_default_cfg(pmr_chain_cfg *cfg);       /* the reference's operating point            */
+pmr_chain pmr_chain_create(const pmr_chain_cfg *cfg);      /* NULL on failure (incl. no HIP device)      */
+int       pmr_chain_reset(pmr_chain q);                    /* all carried state to zero (stream restart) */
+int       pmr_chain_destroy(pmr_chain q);
+unsigned  pmr_chain_max_frames(pmr_chain q);               /* SDR_CHANNEL_BUF_SIZE rule, :730-736        */
+unsigned  pmr_chain_num_channels(pmr_chain q);
+const char *pmr_chain_last_error(pmr_chain q);
+
+/* Process one block held in HOST memory (== buffp after readStream, :789).
+ *   iq        [n_in] cf32 interleaved, n_in <= max_block (0 allowed)
+ *   pcm       [M][pcm_stride] int16, channel-major like ch_buff_mat_t (:51); nullable
+ *   n_frames  frames produced this call (== ns, :800-823); nullable
+ *   chan_out  [M][pcm_stride] cf32 channelizer tap-off (== chan_bufs, :743) for squelch/RSSI plumbing; nullable
+ *   rssi_db   [M] 20*log10(mean|x|) per channel (== average_power, :330-336); nullable
+ * PCM rule: (int16_t)(x * 32767) truncated toward zero (src/dsd_in.c:174), saturated.
+ * Synchronous: returns after the results are in the caller's buffers.                                */
+int pmr_chain_process_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in,
+                            int16_t *pcm, unsigned pcm_stride, unsigned *n_frames,
+                            pmr_cf32 *chan_out, float *rssi_db);
+
+/* Same, plus the float32 audio the reference hands to its sink (:904), [M][pcm_stride]; nullable.    */
+int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in,
+                                int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames,
+                                pmr_cf32 *chan_out, float *rssi_db);
+
+/* Device-resident variant: every pointer is a HIP device pointer on the chain's device; work is queued on
+ * the chain's stream and NOT synchronised (call pmr_chain_synchronize).  n_frames is a host pointer and is
+ * valid on return (frame counts are closed-form in n_in).                                            */
+int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
+                                   void *d_pcm, void *d_audio, unsigned pcm_stride, unsigned *n_frames,
+                                   void *d_chan_out, void *d_rssi_db);
+int   pmr_chain_synchronize(pmr_chain q);
+void *pmr_chain_stream(pmr_chain q);                       /* hipStream_t the kernels are launched on   */
+
+/* ---- measurement hooks (bench.py): HIP-event time of every kernel launched by this handle ---- */
+int         pmr_chain_profile_enable(pmr_chain q, int on);
+int         pmr_chain_profile_reset(pmr_chain q);
+unsigned    pmr_chain_profile_count(pmr_chain q);                          /* number of distinct kernels   */
+const char *pmr_chain_profile_name(pmr_chain q, unsigned i);
+int         pmr_chain_profile_get(pmr_chain q, unsigned i, double *total_ms, unsigned *launches);
+
+/* ---- introspection (tests): designed coefficients / integers, and the last block's intermediates ---- */
+enum { PMR_INFO_NUM_STAGES = 0, PMR_INFO_M_STAGE = 1, PMR_INFO_ARB_STEP = 2, PMR_INFO_NCO_DTHETA = 3,
+       PMR_INFO_ARB_NPFB = 4, PMR_INFO_ARB_M = 5, PMR_INFO_PFB_P = 6 };
+enum { PMR_DESIGN_HALFBAND = 0, PMR_DESIGN_ARB = 1, PMR_DESIGN_PFB = 2 };
+unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx);
+unsigned pmr_chain_design(pmr_chain q, int what, unsigned idx, float *out, unsigned cap);
+enum { PMR_DEBUG_RESAMPLED = 0,   /* cf32 [ny]  resampler output of the last block (:796)              */
+       PMR_DEBUG_FM = 1 };        /* f32 [ns][M] discriminator output of the last block, time-major     */
+int pmr_chain_debug_enable(pmr_chain q, int on);   /* capture the intermediates of subsequent blocks */
+int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes, size_t *n_bytes);
+
+/* ---- host-only helpers: pure arithmetic, need no HIP device (used by the CPU test tier) ---- */
+unsigned pmr_cfg_info(const pmr_chain_cfg *cfg, int what, unsigned idx);
+unsigned pmr_cfg_design(const pmr_chain_cfg *cfg, int what, unsigned idx, float *out, unsigned cap);
+unsigned pmr_cfg_max_frames(const pmr_chain_cfg *cfg);        /* :730-736 sizing rule                    */
+/* The closed-form sample accounting process_block uses to size its launches: given the carried counters,
+ * how many resampled samples (ny, :796) and frames (ns, :804-823) a block of n_in samples yields.      */
+typedef struct { uint64_t n_raw; uint32_t arb_phase; unsigned leftover; } pmr_plan_state;
+int pmr_cfg_plan_block(const pmr_chain_cfg *cfg, pmr_plan_state *st, unsigned n_in, unsigned *ny, unsigned *ns);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

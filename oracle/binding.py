@@ -80,6 +80,10 @@ def lib():
         L.orc_iirfilt_crcf_create_dc_blocker.restype = C.c_void_p
         L.orc_iirfilt_crcf_destroy.argtypes = [C.c_void_p]
         L.orc_iirfilt_crcf_execute_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        L.orc_chain_info.argtypes = [C.c_void_p, C.c_int, C.c_uint]
+        L.orc_chain_info.restype = C.c_uint
+        L.orc_chain_design.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_uint]
+        L.orc_chain_design.restype = C.c_uint
         L.orc_fft_create.argtypes = [C.c_uint]
         L.orc_fft_create.restype = C.c_void_p
         L.orc_fft_destroy.argtypes = [C.c_void_p]
@@ -126,6 +130,26 @@ class OracleChain:
 
     def reset(self):
         lib().orc_chain_reset(self.h)
+
+    def info(self, what, idx=0):
+        return lib().orc_chain_info(self.h, what, idx)
+
+    def design(self, what, idx=0):
+        n = lib().orc_chain_design(self.h, what, idx, None, 0)
+        out = np.zeros(n, dtype=np.float32)
+        lib().orc_chain_design(self.h, what, idx, out.ctypes.data, n)
+        return out
+
+    def design_dict(self):
+        """All designed coefficients / integers of the chain (for the closed-form model in tests)."""
+        h = self.info(0)
+        return {
+            "num_stages": h,
+            "m_stage": [self.info(1, i) for i in range(h)],
+            "hb": [self.design(0, i) for i in range(h)],
+            "arb_step": self.info(2), "nco_dtheta": self.info(3), "arb_npfb": self.info(4), "arb_m": self.info(5),
+            "arb": self.design(1), "pfb": self.design(2), "pfb_p": self.info(6),
+        }
 
     def close(self):
         if self.h:

@@ -204,3 +204,36 @@ int orc_chain_process_block(orc_chain *q, const cf32 *iq, unsigned n_in,
     }
     return 0;
 }
+
+/* ---- introspection for tests: designed coefficients and derived integers ---- */
+unsigned orc_chain_info(const orc_chain *q, int what, unsigned idx)
+{
+    switch (what) {
+    case 0: return q->resampler->num_halfband_stages;
+    case 1: return idx < q->resampler->num_halfband_stages ? q->resampler->halfband->m_stage[idx] : 0;
+    case 2: return q->resampler->arbitrary->step;
+    case 3: return q->nco.d_theta;
+    case 4: return q->resampler->arbitrary->npfb;
+    case 5: return q->resampler->arbitrary->m;
+    case 6: return q->channelizer->p;
+    default: return 0;
+    }
+}
+
+unsigned orc_chain_design(const orc_chain *q, int what, unsigned idx, float *out, unsigned cap)
+{
+    const float *src = NULL; unsigned n = 0;
+    switch (what) {
+    case 0: /* half-band prototype of stage idx (design index; stage num_stages-1 runs first) */
+        if (idx >= q->resampler->num_halfband_stages) return 0;
+        src = q->resampler->halfband->stage[idx]->h; n = q->resampler->halfband->stage[idx]->h_len; break;
+    case 1: /* arbitrary resampler prototype, normalised to sum = npfb */
+        src = q->resampler->arbitrary->proto;
+        n = 2 * q->resampler->arbitrary->m * q->resampler->arbitrary->npfb + 1; break;
+    case 2: /* channelizer prototype */
+        src = q->channelizer->h; n = 2 * q->M * q->cfg.pfb_m + 1; break;
+    default: return 0;
+    }
+    if (out) memcpy(out, src, (n < cap ? n : cap) * sizeof(float));
+    return n;
+}

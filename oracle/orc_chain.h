@@ -75,5 +75,7 @@ int orc_chain_process_block(orc_chain *q, const cf32 *iq, unsigned n_in,
                             cf32 *chan_out, float *rssi_db, orc_taps *taps);
 
 int16_t orc_pcm_from_float(float x);
+unsigned orc_chain_info(const orc_chain *q, int what, unsigned idx);
+unsigned orc_chain_design(const orc_chain *q, int what, unsigned idx, float *out, unsigned cap);
 
 #endif

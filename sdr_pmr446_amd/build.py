@@ -1,0 +1,58 @@
+"""In-tree build of libpmr446_hip.so (gfx950) -- host C with gcc, kernels with hipcc."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpmr446_hip.so")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+
+C_SOURCES = ["pmr_chain.c", "pmr_design.c"]
+HIP_SOURCES = ["pmr_kernels.hip"]
+HEADERS = ["pmr_design.h", "pmr_kernels.h", os.path.join("..", "..", "include", "pmr_chain.h"),
+           os.path.join("..", "data", "pmr446_taps.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    for f in C_SOURCES + HIP_SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force=False, verbose=False):
+    """Compile for gfx950 (cross-compiles without a GPU).  Returns the library path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.path.join(ROCM, "bin", "hipcc")
+    objs = []
+    for f in C_SOURCES:
+        o = os.path.join(CSRC, f[:-2] + ".o")
+        cmd = ["gcc", "-std=gnu11", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
+               "-I" + os.path.join(ROCM, "include"), "-c", os.path.join(CSRC, f), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    for f in HIP_SOURCES:
+        o = os.path.join(CSRC, f[:-4] + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-parameter",
+               "-c", os.path.join(CSRC, f), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

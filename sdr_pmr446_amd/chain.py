@@ -1,0 +1,281 @@
+"""Host-side mirror of include/pmr_chain.h (ctypes over libpmr446_hip.so).
+
+This is plumbing: it owns no arithmetic.  Every call goes to the C-ABI, which enqueues the gfx950 kernels.
+If the library (or a HIP device) is missing the import/`PmrChain()` raises -- there is no CPU path here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+PMR_OK, PMR_EINVAL, PMR_ERANGE, PMR_EHIP, PMR_ENOMEM = 0, 1, 2, 3, 4
+
+INFO_NUM_STAGES, INFO_M_STAGE, INFO_ARB_STEP, INFO_NCO_DTHETA, INFO_ARB_NPFB, INFO_ARB_M, INFO_PFB_P = range(7)
+DESIGN_HALFBAND, DESIGN_ARB, DESIGN_PFB = range(3)
+DEBUG_RESAMPLED, DEBUG_FM = range(2)
+
+#: every symbol include/pmr_chain.h declares
+ABI_SYMBOLS = [
+    "pmr_chain_default_cfg", "pmr_chain_create", "pmr_chain_reset", "pmr_chain_destroy", "pmr_chain_max_frames",
+    "pmr_chain_num_channels", "pmr_chain_last_error", "pmr_chain_process_block", "pmr_chain_process_block_f32",
+    "pmr_chain_process_block_device", "pmr_chain_synchronize", "pmr_chain_stream", "pmr_chain_profile_enable",
+    "pmr_chain_profile_reset", "pmr_chain_profile_count", "pmr_chain_profile_name", "pmr_chain_profile_get",
+    "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read",
+    "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
+]
+
+
+class PlanState(C.Structure):
+    _fields_ = [("n_raw", C.c_uint64), ("arb_phase", C.c_uint32), ("leftover", C.c_uint)]
+
+
+class PmrCfg(C.Structure):
+    _fields_ = [
+        ("fs_in", C.c_double), ("num_channels", C.c_uint), ("channel_width_hz", C.c_double),
+        ("dcblock_alpha", C.c_float), ("resamp_As", C.c_float), ("pfb_m", C.c_uint), ("pfb_As", C.c_float),
+        ("fm_kf", C.c_float), ("audio_gain", C.c_float), ("lowpass", C.c_int), ("deemph_fir", C.c_int),
+        ("max_block", C.c_uint), ("device", C.c_int),
+        ("hp_taps", C.POINTER(C.c_float)), ("hp_len", C.c_uint),
+        ("lp_taps", C.POINTER(C.c_float)), ("lp_len", C.c_uint),
+        ("deemph_taps", C.POINTER(C.c_float)), ("deemph_len", C.c_uint),
+    ]
+
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load libpmr446_hip.so (building it in-tree first if needed) and declare the C-ABI prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing:
+        path = _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError("libpmr446_hip.so is missing: run sdr_pmr446_amd/build.py (no CPU fallback exists)")
+    L = C.CDLL(path)
+    vp, u, i = C.c_void_p, C.c_uint, C.c_int
+    L.pmr_chain_default_cfg.argtypes = [C.POINTER(PmrCfg)]
+    L.pmr_chain_default_cfg.restype = None
+    L.pmr_chain_create.argtypes = [C.POINTER(PmrCfg)]
+    L.pmr_chain_create.restype = vp
+    for name in ("pmr_chain_reset", "pmr_chain_destroy", "pmr_chain_synchronize", "pmr_chain_profile_reset"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = i
+    for name in ("pmr_chain_max_frames", "pmr_chain_num_channels", "pmr_chain_profile_count"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = u
+    L.pmr_chain_last_error.argtypes = [vp]
+    L.pmr_chain_last_error.restype = C.c_char_p
+    L.pmr_chain_stream.argtypes = [vp]
+    L.pmr_chain_stream.restype = vp
+    L.pmr_chain_process_block.argtypes = [vp, vp, u, vp, u, C.POINTER(u), vp, vp]
+    L.pmr_chain_process_block.restype = i
+    L.pmr_chain_process_block_f32.argtypes = [vp, vp, u, vp, vp, u, C.POINTER(u), vp, vp]
+    L.pmr_chain_process_block_f32.restype = i
+    L.pmr_chain_process_block_device.argtypes = [vp, vp, u, vp, vp, u, C.POINTER(u), vp, vp]
+    L.pmr_chain_process_block_device.restype = i
+    L.pmr_chain_profile_enable.argtypes = [vp, i]
+    L.pmr_chain_profile_enable.restype = i
+    L.pmr_chain_profile_name.argtypes = [vp, u]
+    L.pmr_chain_profile_name.restype = C.c_char_p
+    L.pmr_chain_profile_get.argtypes = [vp, u, C.POINTER(C.c_double), C.POINTER(u)]
+    L.pmr_chain_profile_get.restype = i
+    L.pmr_chain_info.argtypes = [vp, i, u]
+    L.pmr_chain_info.restype = u
+    L.pmr_chain_design.argtypes = [vp, i, u, vp, u]
+    L.pmr_chain_design.restype = u
+    L.pmr_chain_debug_enable.argtypes = [vp, i]
+    L.pmr_chain_debug_enable.restype = i
+    L.pmr_chain_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.pmr_chain_debug_read.restype = i
+    L.pmr_cfg_info.argtypes = [C.POINTER(PmrCfg), i, u]
+    L.pmr_cfg_info.restype = u
+    L.pmr_cfg_design.argtypes = [C.POINTER(PmrCfg), i, u, vp, u]
+    L.pmr_cfg_design.restype = u
+    L.pmr_cfg_max_frames.argtypes = [C.POINTER(PmrCfg)]
+    L.pmr_cfg_max_frames.restype = u
+    L.pmr_cfg_plan_block.argtypes = [C.POINTER(PmrCfg), C.POINTER(PlanState), u, C.POINTER(u), C.POINTER(u)]
+    L.pmr_cfg_plan_block.restype = i
+    _lib = L
+    return L
+
+
+def make_cfg(fs_in=1024000.0, num_channels=16, max_block=100000, **kw):
+    """Fill a pmr_chain_cfg starting from the reference's operating point."""
+    L = load()
+    cfg = PmrCfg()
+    L.pmr_chain_default_cfg(C.byref(cfg))
+    cfg.fs_in = fs_in
+    cfg.num_channels = num_channels
+    cfg.max_block = max_block
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise TypeError("unknown cfg field %r" % k)
+        setattr(cfg, k, int(v) if isinstance(v, bool) else v)
+    return cfg
+
+
+def cfg_design_dict(cfg):
+    """Host-only: designed coefficients/integers for cfg (same keys as the oracle's design_dict)."""
+    L = load()
+
+    def des(what, idx=0):
+        n = L.pmr_cfg_design(C.byref(cfg), what, idx, None, 0)
+        out = np.zeros(n, dtype=np.float32)
+        L.pmr_cfg_design(C.byref(cfg), what, idx, out.ctypes.data, n)
+        return out
+
+    info = lambda what, idx=0: L.pmr_cfg_info(C.byref(cfg), what, idx)
+    h = info(INFO_NUM_STAGES)
+    return {
+        "num_stages": h, "m_stage": [info(INFO_M_STAGE, g) for g in range(h)],
+        "hb": [des(DESIGN_HALFBAND, g) for g in range(h)],
+        "arb_step": info(INFO_ARB_STEP), "nco_dtheta": info(INFO_NCO_DTHETA), "arb_npfb": info(INFO_ARB_NPFB),
+        "arb_m": info(INFO_ARB_M), "arb": des(DESIGN_ARB), "pfb": des(DESIGN_PFB), "pfb_p": info(INFO_PFB_P),
+    }
+
+
+class PmrError(RuntimeError):
+    pass
+
+
+class PmrChain:
+    """One IQ stream on one GPU: pmr_chain_create / process_block / reset / destroy."""
+
+    def __init__(self, fs_in=1024000.0, num_channels=16, max_block=100000, audio_gain=4.0, lowpass=False,
+                 deemph_fir=False, device=-1, channel_width_hz=12500.0, pfb_m=13, pfb_As=80.0, resamp_As=60.0,
+                 dcblock_alpha=0.0005, fm_kf=0.5):
+        L = load()
+        cfg = PmrCfg()
+        L.pmr_chain_default_cfg(C.byref(cfg))
+        cfg.fs_in = fs_in
+        cfg.num_channels = num_channels
+        cfg.channel_width_hz = channel_width_hz
+        cfg.max_block = max_block
+        cfg.audio_gain = audio_gain
+        cfg.lowpass = int(lowpass)
+        cfg.deemph_fir = int(deemph_fir)
+        cfg.device = device
+        cfg.pfb_m = pfb_m
+        cfg.pfb_As = pfb_As
+        cfg.resamp_As = resamp_As
+        cfg.dcblock_alpha = dcblock_alpha
+        cfg.fm_kf = fm_kf
+        self.cfg = cfg
+        self._L = L
+        self.h = L.pmr_chain_create(C.byref(cfg))
+        if not self.h:
+            raise PmrError("pmr_chain_create failed (no HIP device, or invalid configuration)")
+        self.M = L.pmr_chain_num_channels(self.h)
+        self.max_frames = L.pmr_chain_max_frames(self.h)
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != PMR_OK:
+            raise PmrError("pmr_chain rc=%d: %s" % (rc, self._L.pmr_chain_last_error(self.h).decode()))
+
+    def reset(self):
+        self._check(self._L.pmr_chain_reset(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.pmr_chain_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._L.pmr_chain_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return self._L.pmr_chain_stream(self.h)
+
+    # -- host-buffer entry point ----------------------------------------------------------------
+    def process_block(self, iq, want=("pcm",)):
+        """iq: complex64 numpy array.  Returns dict: n_frames + requested outputs trimmed to n_frames."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        want = set(want)
+        M, S = self.M, self.max_frames
+        pcm = np.zeros((M, S), dtype=np.int16) if "pcm" in want else None
+        audio = np.zeros((M, S), dtype=np.float32) if "audio" in want else None
+        chan = np.zeros((M, S), dtype=np.complex64) if "chan" in want else None
+        rssi = np.zeros(M, dtype=np.float32) if "rssi" in want else None
+        dbg = bool(want & {"resampled", "fm"})
+        if dbg:
+            self._check(self._L.pmr_chain_debug_enable(self.h, 1))
+        ns = C.c_uint(0)
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        self._check(self._L.pmr_chain_process_block_f32(self.h, iq.ctypes.data if len(iq) else None, len(iq),
+                                                        ptr(pcm), ptr(audio), S, C.byref(ns), ptr(chan), ptr(rssi)))
+        n = ns.value
+        out = {"n_frames": n}
+        if pcm is not None:
+            out["pcm"] = pcm[:, :n].copy()
+        if audio is not None:
+            out["audio"] = audio[:, :n].copy()
+        if chan is not None:
+            out["chan"] = chan[:, :n].copy()
+        if rssi is not None:
+            out["rssi"] = rssi
+        if "resampled" in want:
+            out["resampled"] = self.debug_read(DEBUG_RESAMPLED, np.complex64)
+        if "fm" in want:
+            fm = self.debug_read(DEBUG_FM, np.float32)
+            out["fm"] = fm.reshape(-1, M).T.copy() if len(fm) else np.zeros((M, 0), np.float32)
+        return out
+
+    # -- device-buffer entry point (bench / zero-copy callers) ----------------------------------
+    def process_block_device(self, d_iq, n_in, d_pcm=None, d_audio=None, stride=None, d_chan=None, d_rssi=None):
+        """All pointers are integer HIP device addresses (e.g. torch.Tensor.data_ptr()).  Asynchronous."""
+        ns = C.c_uint(0)
+        self._check(self._L.pmr_chain_process_block_device(self.h, d_iq, n_in, d_pcm, d_audio,
+                                                           stride if stride is not None else self.max_frames,
+                                                           C.byref(ns), d_chan, d_rssi))
+        return ns.value
+
+    # -- measurement / introspection -------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self._L.pmr_chain_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._check(self._L.pmr_chain_profile_reset(self.h))
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} from HIP events on the chain's stream."""
+        out = {}
+        for i in range(self._L.pmr_chain_profile_count(self.h)):
+            ms, n = C.c_double(0), C.c_uint(0)
+            self._check(self._L.pmr_chain_profile_get(self.h, i, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[self._L.pmr_chain_profile_name(self.h, i).decode()] = (ms.value, n.value)
+        return out
+
+    def info(self, what, idx=0):
+        return self._L.pmr_chain_info(self.h, what, idx)
+
+    def design(self, what, idx=0):
+        n = self._L.pmr_chain_design(self.h, what, idx, None, 0)
+        out = np.zeros(n, dtype=np.float32)
+        self._L.pmr_chain_design(self.h, what, idx, out.ctypes.data, n)
+        return out
+
+    def debug_read(self, what, dtype):
+        nb = C.c_size_t(0)
+        self._check(self._L.pmr_chain_debug_read(self.h, what, None, 0, C.byref(nb)))
+        buf = np.zeros(nb.value // np.dtype(dtype).itemsize, dtype=dtype)
+        if nb.value:
+            self._check(self._L.pmr_chain_debug_read(self.h, what, buf.ctypes.data, nb.value, C.byref(nb)))
+        return buf

@@ -1,0 +1,708 @@
+/* pmr_chain.c -- host side of libpmr446_hip.so: the process-one-block entry points of include/pmr_chain.h.
+ *
+ * Plain C (the reference's host language).  Owns the per-stream device state that the liquid objects of
+ * reference include/sdr_pmr446.h:54-82 (struct _proc_chain_t) own on the CPU, keeps the closed-form sample
+ * counters on the host (so no device->host sync is ever needed to size a launch), and enqueues the gfx950
+ * kernels of pmr_kernels.hip on one HIP stream.  There is NO CPU fallback: without a HIP device
+ * pmr_chain_create() fails.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/pmr_chain.h"
+#include "../data/pmr446_taps.h"
+#include "pmr_design.h"
+#include "pmr_kernels.h"
+
+#define FM_HIST_FRAMES 512u     /* >= 376 (HP) + IIR warm-up; also covers 102/100-tap follow-on FIRs */
+#define AUX_HIST_FRAMES 128u    /* history of the time-major intermediates behind the HP stage        */
+#define ARB_KEEP 16             /* decimated-sample history kept for the 14-tap arbitrary resampler   */
+#define PROF_SLOTS 16
+
+typedef struct { float re, im; } cfl;
+
+enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
+       K_COUNT };
+static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
+                                        "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
+                                        "k_fir_tm<lp>" };
+
+typedef struct { hipEvent_t a, b; int slot; } prof_pending;
+
+struct pmr_chain_s {
+    pmr_chain_cfg cfg;
+    pmr_design d;
+    int device;
+    hipStream_t stream;
+    unsigned M, res_size, chan_size;
+    char err[256];
+
+    /* constant tables on the device */
+    float *d_hb_h1[PMR_MAX_STAGES];
+    float *d_arb_bank, *d_pfb_taps_t, *d_fft_tw, *d_nco_cs, *d_lam_thread_pow, *d_lam_tile_idx_pow;
+    float *d_hp_pad, *d_lp_pad, *d_de_pad;
+    unsigned hp_len, lp_len, de_len;
+    pmr_dc_consts dcc;
+
+    /* carried state / work buffers on the device */
+    cfl *d_in;                       /* staging for host blocks [max_block]                  */
+    cfl *d_dc_state, *d_dc_agg, *d_dc_W;
+    cfl *d_z[PMR_MAX_STAGES + 1];    /* z_0 .. z_h, each [keep | new]                         */
+    unsigned keep[PMR_MAX_STAGES + 1];
+    cfl *d_xr; size_t xr_cap;
+    float *d_fm, *d_aux1, *d_aux2;
+    void *d_scratch; size_t scratch_bytes;
+    int16_t *d_pcm; float *d_audio; cfl *d_chan; float *d_rssi, *d_rssi_part;
+    size_t rssi_part_cap;
+
+    /* host-side counters (all closed form in the number of samples consumed) */
+    uint64_t n_raw;                  /* raw samples consumed since reset                      */
+    uint32_t arb_phase;              /* resamp_crcf phase, 2^24 per decimated sample          */
+    unsigned xr_fill;                /* valid samples in d_xr (= p*M + leftover)              */
+    uint64_t xr_base;                /* absolute resampled index of d_xr[0]                   */
+    unsigned last_ny, last_ns;
+    int dbg_on; cfl *d_dbg_xr; float *d_dbg_fm;
+
+    /* profiling */
+    int prof_on;
+    double prof_ms[PROF_SLOTS]; unsigned prof_n[PROF_SLOTS];
+    prof_pending *pend; unsigned npend, cappend;
+    hipEvent_t *pool; unsigned npool, cappool;
+};
+
+/* ------------------------------------------------------------------------------------------- */
+
+static int fail(pmr_chain q, int code, const char *what, hipError_t e)
+{
+    if (q) snprintf(q->err, sizeof(q->err), "%s%s%s", what, e != hipSuccess ? ": " : "",
+                    e != hipSuccess ? hipGetErrorString(e) : "");
+    return code;
+}
+
+#define HIPCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(q, PMR_EHIP, what, e_); } while (0)
+
+static int dev_alloc(pmr_chain q, void **p, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(q, PMR_ENOMEM, "hipMalloc", e);
+    e = hipMemsetAsync(*p, 0, bytes, q->stream);
+    if (e != hipSuccess) return fail(q, PMR_EHIP, "hipMemsetAsync", e);
+    return PMR_OK;
+}
+
+static int dev_upload(pmr_chain q, float **p, const float *src, size_t n)
+{
+    int rc = dev_alloc(q, (void **)p, n * sizeof(float));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(*p, src, n * sizeof(float), hipMemcpyHostToDevice, q->stream), "upload");
+    HIPCHK(hipStreamSynchronize(q->stream), "upload sync");   /* src may be a temporary */
+    return PMR_OK;
+}
+
+/* zero-padded, oldest-first taps for k_fir_tm: P[j + RP-1] = h[n-1-j] */
+static int upload_padded_taps(pmr_chain q, float **p, const float *h, unsigned n)
+{
+    const unsigned rp = PMR_AUDIO_R + PMR_AUDIO_J;
+    size_t len = n + 2 * (rp - 1);
+    float *tmp = (float *)calloc(len, sizeof(float));
+    if (!tmp) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+    for (unsigned j = 0; j < n; j++) tmp[j + rp - 1] = h[n - 1 - j];
+    int rc = dev_upload(q, p, tmp, len);
+    free(tmp);
+    return rc;
+}
+
+/* ---- profiling helpers: HIP events on the chain's stream around every launch ---- */
+static void prof_begin(pmr_chain q, int slot, prof_pending *pp)
+{
+    pp->slot = -1;
+    if (!q->prof_on) return;
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; i++) {
+        if (q->npool) ev[i] = q->pool[--q->npool];
+        else if (hipEventCreate(&ev[i]) != hipSuccess) return;
+    }
+    pp->a = ev[0]; pp->b = ev[1]; pp->slot = slot;
+    hipEventRecord(pp->a, q->stream);
+}
+
+static void prof_end(pmr_chain q, prof_pending *pp)
+{
+    if (pp->slot < 0) return;
+    hipEventRecord(pp->b, q->stream);
+    if (q->npend == q->cappend) {
+        unsigned nc = q->cappend ? 2 * q->cappend : 256;
+        prof_pending *np = (prof_pending *)realloc(q->pend, nc * sizeof(*np));
+        if (!np) return;
+        q->pend = np; q->cappend = nc;
+    }
+    q->pend[q->npend++] = *pp;
+}
+
+static void prof_resolve(pmr_chain q)
+{
+    for (unsigned i = 0; i < q->npend; i++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(q->pend[i].b) == hipSuccess &&
+            hipEventElapsedTime(&ms, q->pend[i].a, q->pend[i].b) == hipSuccess) {
+            q->prof_ms[q->pend[i].slot] += ms;
+            q->prof_n[q->pend[i].slot]++;
+        }
+        if (q->npool + 2 > q->cappool) {
+            unsigned nc = q->cappool ? 2 * q->cappool : 512;
+            hipEvent_t *np = (hipEvent_t *)realloc(q->pool, nc * sizeof(*np));
+            if (np) { q->pool = np; q->cappool = nc; }
+        }
+        if (q->npool + 2 <= q->cappool) { q->pool[q->npool++] = q->pend[i].a; q->pool[q->npool++] = q->pend[i].b; }
+        else { hipEventDestroy(q->pend[i].a); hipEventDestroy(q->pend[i].b); }
+    }
+    q->npend = 0;
+}
+
+#define LAUNCH(slot, expr) do { prof_pending pp_; prof_begin(q, (slot), &pp_); int rc_ = (expr); prof_end(q, &pp_); \
+        if (rc_) return fail(q, PMR_EHIP, k_names[slot], (hipError_t)rc_); } while (0)
+
+/* keep the last `keep` elements of a [src+keep]-element buffer at its front (history for the next call) */
+static int shift_front(pmr_chain q, void *buf, size_t elem, size_t src, size_t keep)
+{
+    if (src == 0 || keep == 0) return PMR_OK;
+    char *b = (char *)buf;
+    if (src >= keep) {
+        HIPCHK(hipMemcpyAsync(b, b + src * elem, keep * elem, hipMemcpyDeviceToDevice, q->stream), "shift");
+    } else {
+        if (keep * elem > q->scratch_bytes) return fail(q, PMR_EINVAL, "scratch too small", hipSuccess);
+        HIPCHK(hipMemcpyAsync(q->d_scratch, b + src * elem, keep * elem, hipMemcpyDeviceToDevice, q->stream), "shift");
+        HIPCHK(hipMemcpyAsync(b, q->d_scratch, keep * elem, hipMemcpyDeviceToDevice, q->stream), "shift");
+    }
+    return PMR_OK;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+
+void pmr_chain_default_cfg(pmr_chain_cfg *c)
+{
+    memset(c, 0, sizeof(*c));
+    c->fs_in = 1024000.0;            /* include/sdr_pmr446.h:13 */
+    c->num_channels = 16;            /* src/sdr_pmr446.c:23 */
+    c->channel_width_hz = 12500.0;   /* :22 */
+    c->dcblock_alpha = 0.0005f;      /* :422 */
+    c->resamp_As = 60.0f;            /* :426 */
+    c->pfb_m = 13; c->pfb_As = 80.0f; /* :437 */
+    c->fm_kf = 0.5f;                 /* :440 */
+    c->audio_gain = 4.0f;            /* :33 */
+    c->lowpass = 0;                  /* :154 */
+    c->deemph_fir = 0;               /* :457 */
+    c->max_block = 100000;           /* :30 */
+    c->device = -1;
+}
+
+static int chain_init(pmr_chain q)
+{
+    const pmr_design *d = &q->d;
+    const unsigned M = q->M, p = d->pfb_p, h = d->num_stages;
+    int rc;
+
+    /* constant tables */
+    for (unsigned g = 0; g < h; g++)
+        if ((rc = dev_upload(q, &q->d_hb_h1[g], d->hb_h1[g], 2 * d->m_stage[g]))) return rc;
+    if ((rc = dev_upload(q, &q->d_arb_bank, d->arb_bank, (size_t)PMR_ARB_NPFB * 2 * PMR_ARB_M))) return rc;
+    if ((rc = dev_upload(q, &q->d_pfb_taps_t, d->pfb_taps_t, (size_t)p * M))) return rc;
+    if ((rc = dev_upload(q, &q->d_fft_tw, d->fft_tw, M))) return rc;
+    if ((rc = dev_upload(q, &q->d_nco_cs, d->nco_cs, (size_t)d->nco_period * 2))) return rc;
+
+    /* dc-block scan constants, evaluated in double */
+    q->dcc.a1 = d->dc_a1;
+    for (int j = 0; j < 8; j++) q->dcc.lam_pow16[j] = (float)pow(d->dc_lambda, 16.0 * (double)(1u << j));
+    {
+        double lt = pow(d->dc_lambda, (double)PMR_DC_TILE);
+        for (int j = 0; j < 10; j++) q->dcc.lam_tile_pow[j] = (float)pow(lt, (double)(1u << j));
+        float tmp[1024];
+        for (unsigned t = 0; t < 256; t++) tmp[t] = (float)pow(d->dc_lambda, 16.0 * t);
+        if ((rc = dev_upload(q, &q->d_lam_thread_pow, tmp, 256))) return rc;
+        for (unsigned t = 0; t < 1024; t++) tmp[t] = (float)pow(lt, (double)t);
+        if ((rc = dev_upload(q, &q->d_lam_tile_idx_pow, tmp, 1024))) return rc;
+    }
+
+    /* audio filter tables (:443-458); NULL selects the PMR446 tables of :56-136 */
+    const float *hp = q->cfg.hp_taps ? q->cfg.hp_taps : pmr446_hp_audio_taps;
+    const float *lp = q->cfg.lp_taps ? q->cfg.lp_taps : pmr446_lp_audio_taps;
+    const float *de = q->cfg.deemph_taps ? q->cfg.deemph_taps : pmr446_deemph_taps;
+    q->hp_len = q->cfg.hp_taps ? q->cfg.hp_len : PMR446_HP_AUDIO_TAPS_LEN;
+    q->lp_len = q->cfg.lp_taps ? q->cfg.lp_len : PMR446_LP_AUDIO_TAPS_LEN;
+    q->de_len = q->cfg.deemph_taps ? q->cfg.deemph_len : PMR446_DEEMPH_TAPS_LEN;
+    if (q->hp_len < 1 || q->hp_len + PMR_AUDIO_J > FM_HIST_FRAMES || q->lp_len < 1 || q->de_len < 1 ||
+        q->lp_len + PMR_AUDIO_J > AUX_HIST_FRAMES || q->de_len + PMR_AUDIO_J > AUX_HIST_FRAMES)
+        return fail(q, PMR_EINVAL, "audio filter length out of range", hipSuccess);
+    if ((rc = upload_padded_taps(q, &q->d_hp_pad, hp, q->hp_len))) return rc;
+    if ((rc = upload_padded_taps(q, &q->d_lp_pad, lp, q->lp_len))) return rc;
+    if ((rc = upload_padded_taps(q, &q->d_de_pad, de, q->de_len))) return rc;
+
+    /* state + work buffers */
+    const unsigned mb = q->cfg.max_block;
+    if ((rc = dev_alloc(q, (void **)&q->d_in, (size_t)mb * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_dc_state, sizeof(cfl)))) return rc;
+    const unsigned max_tiles = (mb + PMR_DC_TILE - 1) / PMR_DC_TILE + 1;
+    if ((rc = dev_alloc(q, (void **)&q->d_dc_agg, (size_t)max_tiles * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_dc_W, (size_t)max_tiles * sizeof(cfl)))) return rc;
+    for (unsigned e = 0; e <= h; e++) {
+        /* stage e (execution order) is design stage h-1-e; z_h feeds the arbitrary resampler */
+        q->keep[e] = e < h ? 4 * d->m_stage[h - 1 - e] : ARB_KEEP;
+        size_t cap = (size_t)q->keep[e] + ((size_t)mb >> e) + 2;
+        if ((rc = dev_alloc(q, (void **)&q->d_z[e], cap * sizeof(cfl)))) return rc;
+    }
+    q->xr_cap = (size_t)(p + 2) * M + q->res_size + 16;
+    if ((rc = dev_alloc(q, (void **)&q->d_xr, q->xr_cap * sizeof(cfl)))) return rc;
+    const size_t fm_frames = (size_t)FM_HIST_FRAMES + q->chan_size + PMR_AUDIO_R + 8;
+    if ((rc = dev_alloc(q, (void **)&q->d_fm, fm_frames * M * sizeof(float)))) return rc;
+    if (q->cfg.deemph_fir || q->cfg.lowpass) {
+        const size_t ax = (size_t)AUX_HIST_FRAMES + q->chan_size + PMR_AUDIO_R + 8;
+        if ((rc = dev_alloc(q, (void **)&q->d_aux1, ax * M * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_aux2, ax * M * sizeof(float)))) return rc;
+    }
+    q->scratch_bytes = (size_t)FM_HIST_FRAMES * M * sizeof(float);
+    if ((size_t)(p + 1) * M * sizeof(cfl) > q->scratch_bytes) q->scratch_bytes = (size_t)(p + 1) * M * sizeof(cfl);
+    if ((rc = dev_alloc(q, &q->d_scratch, q->scratch_bytes))) return rc;
+    const size_t out_n = (size_t)M * q->chan_size;
+    if ((rc = dev_alloc(q, (void **)&q->d_pcm, out_n * sizeof(int16_t)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_audio, out_n * sizeof(float)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_chan, out_n * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_rssi, (size_t)M * sizeof(float)))) return rc;
+    q->rssi_part_cap = (size_t)pmr_channelize_tiles(q->chan_size, M) * M;
+    if ((rc = dev_alloc(q, (void **)&q->d_rssi_part, q->rssi_part_cap * sizeof(float)))) return rc;
+
+    q->n_raw = 0; q->arb_phase = 0; q->xr_fill = p * M; q->xr_base = 0;
+    HIPCHK(hipStreamSynchronize(q->stream), "init sync");
+    return PMR_OK;
+}
+
+pmr_chain pmr_chain_create(const pmr_chain_cfg *cfg)
+{
+    if (!cfg) return NULL;
+    pmr_chain q = (pmr_chain)calloc(1, sizeof(*q));
+    if (!q) return NULL;
+    q->cfg = *cfg;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "pmr_chain_create: no HIP device (this library has no CPU path)\n");
+        free(q); return NULL;
+    }
+    if (cfg->device >= 0) {
+        if (cfg->device >= ndev || hipSetDevice(cfg->device) != hipSuccess) { free(q); return NULL; }
+        q->device = cfg->device;
+    } else if (hipGetDevice(&q->device) != hipSuccess) { free(q); return NULL; }
+    if (cfg->max_block == 0 ||
+        pmr_design_build(&q->d, cfg->fs_in, cfg->num_channels, cfg->channel_width_hz, cfg->dcblock_alpha,
+                         cfg->resamp_As, cfg->pfb_m, cfg->pfb_As, cfg->fm_kf)) {
+        fprintf(stderr, "pmr_chain_create: invalid configuration\n");
+        pmr_design_free(&q->d); free(q); return NULL;
+    }
+    q->M = cfg->num_channels;
+    pmr_design_buffer_sizes(&q->d, cfg->max_block, &q->res_size, &q->chan_size);
+    if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess) {
+        pmr_design_free(&q->d); free(q); return NULL;
+    }
+    if (chain_init(q) != PMR_OK) {
+        fprintf(stderr, "pmr_chain_create: %s\n", q->err);
+        pmr_chain_destroy(q);
+        return NULL;
+    }
+    return q;
+}
+
+int pmr_chain_destroy(pmr_chain q)
+{
+    if (!q) return PMR_OK;
+    hipSetDevice(q->device);
+    if (q->stream) hipStreamSynchronize(q->stream);
+    prof_resolve(q);
+    for (unsigned i = 0; i < q->npool; i++) hipEventDestroy(q->pool[i]);
+    free(q->pool); free(q->pend);
+    for (unsigned g = 0; g < PMR_MAX_STAGES; g++) if (q->d_hb_h1[g]) hipFree(q->d_hb_h1[g]);
+    for (unsigned e = 0; e <= PMR_MAX_STAGES; e++) if (q->d_z[e]) hipFree(q->d_z[e]);
+    void *bufs[] = { q->d_arb_bank, q->d_pfb_taps_t, q->d_fft_tw, q->d_nco_cs, q->d_lam_thread_pow,
+                     q->d_lam_tile_idx_pow, q->d_hp_pad, q->d_lp_pad, q->d_de_pad, q->d_in, q->d_dc_state,
+                     q->d_dc_agg, q->d_dc_W, q->d_xr, q->d_fm, q->d_aux1, q->d_aux2, q->d_scratch, q->d_pcm,
+                     q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm };
+    for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
+    if (q->stream) hipStreamDestroy(q->stream);
+    pmr_design_free(&q->d);
+    free(q);
+    return PMR_OK;
+}
+
+int pmr_chain_reset(pmr_chain q)
+{
+    if (!q) return PMR_EINVAL;
+    const unsigned M = q->M, p = q->d.pfb_p, h = q->d.num_stages;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    HIPCHK(hipMemsetAsync(q->d_dc_state, 0, sizeof(cfl), q->stream), "reset");
+    for (unsigned e = 0; e <= h; e++)
+        HIPCHK(hipMemsetAsync(q->d_z[e], 0, (size_t)q->keep[e] * sizeof(cfl), q->stream), "reset");
+    HIPCHK(hipMemsetAsync(q->d_xr, 0, q->xr_cap * sizeof(cfl), q->stream), "reset");
+    HIPCHK(hipMemsetAsync(q->d_fm, 0, (size_t)FM_HIST_FRAMES * M * sizeof(float), q->stream), "reset");
+    if (q->d_aux1) {
+        HIPCHK(hipMemsetAsync(q->d_aux1, 0, (size_t)AUX_HIST_FRAMES * M * sizeof(float), q->stream), "reset");
+        HIPCHK(hipMemsetAsync(q->d_aux2, 0, (size_t)AUX_HIST_FRAMES * M * sizeof(float), q->stream), "reset");
+    }
+    q->n_raw = 0; q->arb_phase = 0; q->xr_fill = p * M; q->xr_base = 0; q->last_ny = q->last_ns = 0;
+    HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
+    return PMR_OK;
+}
+
+unsigned pmr_chain_max_frames(pmr_chain q) { return q ? q->chan_size : 0; }
+unsigned pmr_chain_num_channels(pmr_chain q) { return q ? q->M : 0; }
+const char *pmr_chain_last_error(pmr_chain q) { return q ? q->err : "null handle"; }
+void *pmr_chain_stream(pmr_chain q) { return q ? (void *)q->stream : NULL; }
+
+int pmr_chain_synchronize(pmr_chain q)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipStreamSynchronize(q->stream), "hipStreamSynchronize");
+    prof_resolve(q);
+    return PMR_OK;
+}
+
+/* Closed-form sample accounting for a block of n_in raw samples (no device round trip):
+ *   decimated samples Q = floor((n_raw+n_in)/D) - floor(n_raw/D)      (msresamp buffer_index rule)
+ *   resampled outputs ny from the 24-bit phase accumulator            (resamp_crcf)
+ *   frames ns = floor((leftover + ny) / M)                            (ring rule, :804)             */
+static void plan_core(unsigned num_stages, uint32_t arb_step, unsigned M, uint64_t n_raw, uint32_t arb_phase,
+                      unsigned leftover, unsigned n_in, unsigned *ny_out, unsigned *ns_out, uint32_t *phase_out)
+{
+    const uint64_t Q = ((n_raw + n_in) >> num_stages) - (n_raw >> num_stages);
+    const uint64_t span = Q << 24;
+    unsigned ny = 0;
+    if (Q && (uint64_t)arb_phase < span) ny = (unsigned)((span - arb_phase + arb_step - 1) / arb_step);
+    *ny_out = ny;
+    *ns_out = (leftover + ny) / M;
+    if (phase_out) *phase_out = (uint32_t)((uint64_t)arb_phase + (uint64_t)ny * arb_step - span);
+}
+
+static void plan_counts(const struct pmr_chain_s *q, unsigned n_in, unsigned *ny_out, unsigned *ns_out)
+{
+    plan_core(q->d.num_stages, q->d.arb_step, q->M, q->n_raw, q->arb_phase, q->xr_fill - q->d.pfb_p * q->M, n_in,
+              ny_out, ns_out, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* front end, staged: dc-block (:795) -> half-band cascade -> arbitrary resampler (:796)         */
+
+static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny_out)
+{
+    const pmr_design *d = &q->d;
+    const unsigned h = d->num_stages;
+    *ny_out = 0;
+    if (n_in == 0) return PMR_OK;
+
+    const unsigned ntiles = (n_in + PMR_DC_TILE - 1) / PMR_DC_TILE;
+    const unsigned l_last = n_in - (ntiles - 1) * PMR_DC_TILE;
+    const float lam_last = (float)pow(d->dc_lambda, (double)l_last);
+    const float inv_last = (float)pow(d->dc_lambda, -(double)(PMR_DC_TILE - l_last));
+    LAUNCH(K_DC_AGG, pmr_launch_dc_agg(q->stream, d_iq, n_in, q->d_dc_agg, &q->dcc, q->d_lam_thread_pow));
+    LAUNCH(K_DC_SCAN, pmr_launch_dc_scan(q->stream, q->d_dc_agg, ntiles, q->d_dc_W, q->d_dc_state, &q->dcc,
+                                         q->d_lam_tile_idx_pow, lam_last, inv_last));
+    LAUNCH(K_DC_APPLY, pmr_launch_dc_apply(q->stream, d_iq, n_in, q->d_dc_W, q->d_z[0] + q->keep[0], &q->dcc,
+                                           q->d_lam_thread_pow));
+
+    uint64_t c_e = q->n_raw;         /* absolute count of z_e samples before this call */
+    unsigned n_e = n_in;             /* new z_e samples this call                      */
+    for (unsigned e = 0; e < h; e++) {
+        const unsigned g = h - 1 - e;
+        const unsigned n_out = (unsigned)(((c_e + n_e) >> 1) - (c_e >> 1));
+        const int par = (int)(c_e & 1u);
+        LAUNCH(K_HALFBAND, pmr_launch_halfband(q->stream, q->d_z[e], q->d_z[e + 1] + q->keep[e + 1], n_out,
+                                               (int)q->keep[e], par, (int)d->m_stage[g], q->d_hb_h1[g],
+                                               e == h - 1 ? d->zeta : 1.0f));
+        int rc = shift_front(q, q->d_z[e], sizeof(cfl), n_e, q->keep[e]);
+        if (rc) return rc;
+        c_e >>= 1; n_e = n_out;
+    }
+    /* n_e new decimated samples in z_h; resamp_crcf phase bookkeeping */
+    const uint64_t span = (uint64_t)n_e << 24;
+    unsigned ny = 0;
+    if (n_e && (uint64_t)q->arb_phase < span)
+        ny = (unsigned)((span - q->arb_phase + d->arb_step - 1) / d->arb_step);
+    if ((size_t)q->xr_fill + ny > q->xr_cap) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
+    LAUNCH(K_ARB, pmr_launch_arb(q->stream, q->d_z[h], q->d_xr + q->xr_fill, ny, q->arb_phase, d->arb_step,
+                                 q->d_arb_bank, (int)q->keep[h]));
+    q->arb_phase = (uint32_t)((uint64_t)q->arb_phase + (uint64_t)ny * d->arb_step - span);
+    int rc = shift_front(q, q->d_z[h], sizeof(cfl), n_e, q->keep[h]);
+    if (rc) return rc;
+    *ny_out = ny;
+    return PMR_OK;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+
+int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
+                                   unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db)
+{
+    if (!q) return PMR_EINVAL;
+    if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
+    if (n_in && !d_iq) return fail(q, PMR_EINVAL, "null input", hipSuccess);
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    const pmr_design *d = &q->d;
+    const unsigned M = q->M, p = d->pfb_p;
+    int rc;
+
+    /* validate against the closed-form counts BEFORE any state is advanced */
+    unsigned ny_plan = 0, ns_plan = 0;
+    plan_counts(q, n_in, &ny_plan, &ns_plan);
+    if (n_frames) *n_frames = ns_plan;
+    if (ns_plan > q->chan_size) return fail(q, PMR_ERANGE, "frame count exceeds max_frames", hipSuccess);
+    if (ns_plan > pcm_stride && (d_pcm || d_audio || d_chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
+    if ((size_t)q->xr_fill + ny_plan > q->xr_cap) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
+
+    unsigned ny = 0;
+    if ((rc = frontend_staged(q, d_iq, n_in, &ny))) return rc;
+    if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
+    q->n_raw += n_in;
+    q->last_ny = ny;
+    if (q->dbg_on && ny)
+        HIPCHK(hipMemcpyAsync(q->d_dbg_xr, q->d_xr + q->xr_fill, (size_t)ny * sizeof(cfl), hipMemcpyDeviceToDevice,
+                              q->stream), "debug copy");
+
+    /* ring carry (:797,:804): frames of M samples, 0..M-1 remainder stays for the next call */
+    const unsigned leftover = q->xr_fill - p * M;
+    const unsigned avail = leftover + ny;
+    const unsigned ns = avail / M;
+    const unsigned total = q->xr_fill + ny;
+    q->last_ns = ns;
+
+    if (ns) {
+        float *fm_new = q->d_fm + (size_t)FM_HIST_FRAMES * M;
+        unsigned ntiles = 0;
+        LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, q->d_xr, ns, M, p, q->d_pfb_taps_t, q->d_fft_tw,
+                                                   q->d_nco_cs, d->nco_period,
+                                                   (unsigned)(q->xr_base % d->nco_period), d->fm_ref, fm_new,
+                                                   d_chan_out, pcm_stride, d_rssi_db ? q->d_rssi_part : NULL,
+                                                   &ntiles));
+        if (q->dbg_on)
+            HIPCHK(hipMemcpyAsync(q->d_dbg_fm, fm_new, (size_t)ns * M * sizeof(float), hipMemcpyDeviceToDevice,
+                                  q->stream), "debug copy");
+        if (d_rssi_db)
+            LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->d_rssi_part, ntiles, M, ns, (float *)d_rssi_db));
+
+        /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906) */
+        if (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass) {
+            const int more = q->cfg.deemph_fir || q->cfg.lowpass;
+            float *a1_new = q->d_aux1 ? q->d_aux1 + (size_t)AUX_HIST_FRAMES * M : NULL;
+            float *a2_new = q->d_aux2 ? q->d_aux2 + (size_t)AUX_HIST_FRAMES * M : NULL;
+            LAUNCH(K_FIR_HP, pmr_launch_fir_tm(q->stream, fm_new, ns, M, q->d_hp_pad, q->hp_len, q->cfg.audio_gain,
+                                               !q->cfg.deemph_fir, d->de_b0, d->de_b1, d->de_a1,
+                                               more ? a1_new : NULL, more ? NULL : (int16_t *)d_pcm,
+                                               more ? NULL : (float *)d_audio, pcm_stride));
+            float *cur = a1_new;
+            if (q->cfg.deemph_fir) {
+                const int last = !q->cfg.lowpass;
+                LAUNCH(K_FIR_DE, pmr_launch_fir_tm(q->stream, cur, ns, M, q->d_de_pad, q->de_len, 1.0f, 0, 0.f, 0.f,
+                                                   0.f, last ? NULL : a2_new, last ? (int16_t *)d_pcm : NULL,
+                                                   last ? (float *)d_audio : NULL, pcm_stride));
+                cur = a2_new;
+            }
+            if (q->cfg.lowpass) {
+                LAUNCH(K_FIR_LP, pmr_launch_fir_tm(q->stream, cur, ns, M, q->d_lp_pad, q->lp_len, 1.0f, 0, 0.f, 0.f,
+                                                   0.f, NULL, (int16_t *)d_pcm, (float *)d_audio, pcm_stride));
+            }
+            if (more) {
+                if ((rc = shift_front(q, q->d_aux1, sizeof(float), (size_t)ns * M, (size_t)AUX_HIST_FRAMES * M))) return rc;
+                if ((rc = shift_front(q, q->d_aux2, sizeof(float), (size_t)ns * M, (size_t)AUX_HIST_FRAMES * M))) return rc;
+            }
+        }
+        if ((rc = shift_front(q, q->d_fm, sizeof(float), (size_t)ns * M, (size_t)FM_HIST_FRAMES * M))) return rc;
+    }
+
+    /* keep p frames of history + the new remainder at the front of the resampled stream */
+    const unsigned keep = p * M + (avail - ns * M);
+    const unsigned src = total - keep;
+    if ((rc = shift_front(q, q->d_xr, sizeof(cfl), src, keep))) return rc;
+    q->xr_fill = keep;
+    q->xr_base += src;
+    return PMR_OK;
+}
+
+int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, int16_t *pcm, float *audio,
+                                unsigned pcm_stride, unsigned *n_frames, pmr_cf32 *chan_out, float *rssi_db)
+{
+    if (!q) return PMR_EINVAL;
+    if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    if (n_in)
+        HIPCHK(hipMemcpyAsync(q->d_in, iq, (size_t)n_in * sizeof(cfl), hipMemcpyHostToDevice, q->stream), "H2D");
+    unsigned ns = 0;
+    const unsigned S = q->chan_size;
+    int rc = pmr_chain_process_block_device(q, q->d_in, n_in, (pcm || audio) ? q->d_pcm : NULL,
+                                            audio ? q->d_audio : NULL, S, &ns, chan_out ? q->d_chan : NULL,
+                                            rssi_db ? q->d_rssi : NULL);
+    if (rc) return rc;
+    if (n_frames) *n_frames = ns;
+    if (ns > pcm_stride && (pcm || audio || chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
+    if (ns) {
+        if (pcm)
+            HIPCHK(hipMemcpy2DAsync(pcm, (size_t)pcm_stride * sizeof(int16_t), q->d_pcm, (size_t)S * sizeof(int16_t),
+                                    (size_t)ns * sizeof(int16_t), q->M, hipMemcpyDeviceToHost, q->stream), "D2H pcm");
+        if (audio)
+            HIPCHK(hipMemcpy2DAsync(audio, (size_t)pcm_stride * sizeof(float), q->d_audio, (size_t)S * sizeof(float),
+                                    (size_t)ns * sizeof(float), q->M, hipMemcpyDeviceToHost, q->stream), "D2H audio");
+        if (chan_out)
+            HIPCHK(hipMemcpy2DAsync(chan_out, (size_t)pcm_stride * sizeof(cfl), q->d_chan, (size_t)S * sizeof(cfl),
+                                    (size_t)ns * sizeof(cfl), q->M, hipMemcpyDeviceToHost, q->stream), "D2H chan");
+        if (rssi_db)
+            HIPCHK(hipMemcpyAsync(rssi_db, q->d_rssi, (size_t)q->M * sizeof(float), hipMemcpyDeviceToHost, q->stream),
+                   "D2H rssi");
+    }
+    return pmr_chain_synchronize(q);
+}
+
+int pmr_chain_process_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, int16_t *pcm, unsigned pcm_stride,
+                            unsigned *n_frames, pmr_cf32 *chan_out, float *rssi_db)
+{
+    return pmr_chain_process_block_f32(q, iq, n_in, pcm, NULL, pcm_stride, n_frames, chan_out, rssi_db);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+
+int pmr_chain_profile_enable(pmr_chain q, int on) { if (!q) return PMR_EINVAL; q->prof_on = on; return PMR_OK; }
+
+int pmr_chain_profile_reset(pmr_chain q)
+{
+    if (!q) return PMR_EINVAL;
+    hipStreamSynchronize(q->stream);
+    prof_resolve(q);
+    memset(q->prof_ms, 0, sizeof(q->prof_ms));
+    memset(q->prof_n, 0, sizeof(q->prof_n));
+    return PMR_OK;
+}
+
+unsigned pmr_chain_profile_count(pmr_chain q) { (void)q; return K_COUNT; }
+const char *pmr_chain_profile_name(pmr_chain q, unsigned i) { (void)q; return i < K_COUNT ? k_names[i] : NULL; }
+
+int pmr_chain_profile_get(pmr_chain q, unsigned i, double *total_ms, unsigned *launches)
+{
+    if (!q || i >= K_COUNT) return PMR_EINVAL;
+    hipStreamSynchronize(q->stream);
+    prof_resolve(q);
+    if (total_ms) *total_ms = q->prof_ms[i];
+    if (launches) *launches = q->prof_n[i];
+    return PMR_OK;
+}
+
+unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx)
+{
+    if (!q) return 0;
+    switch (what) {
+    case PMR_INFO_NUM_STAGES: return q->d.num_stages;
+    case PMR_INFO_M_STAGE:    return idx < q->d.num_stages ? q->d.m_stage[idx] : 0;
+    case PMR_INFO_ARB_STEP:   return q->d.arb_step;
+    case PMR_INFO_NCO_DTHETA: return q->d.nco_dtheta;
+    case PMR_INFO_ARB_NPFB:   return PMR_ARB_NPFB;
+    case PMR_INFO_ARB_M:      return PMR_ARB_M;
+    case PMR_INFO_PFB_P:      return q->d.pfb_p;
+    default: return 0;
+    }
+}
+
+unsigned pmr_chain_design(pmr_chain q, int what, unsigned idx, float *out, unsigned cap)
+{
+    if (!q) return 0;
+    const float *src = NULL; unsigned n = 0;
+    switch (what) {
+    case PMR_DESIGN_HALFBAND:
+        if (idx >= q->d.num_stages) return 0;
+        src = q->d.hb_proto[idx]; n = 4 * q->d.m_stage[idx] + 1; break;
+    case PMR_DESIGN_ARB: src = q->d.arb_proto; n = 2 * PMR_ARB_M * PMR_ARB_NPFB + 1; break;
+    case PMR_DESIGN_PFB: src = q->d.pfb_proto; n = 2 * q->M * q->d.pfb_m + 1; break;
+    default: return 0;
+    }
+    if (out) memcpy(out, src, (size_t)(n < cap ? n : cap) * sizeof(float));
+    return n;
+}
+
+int pmr_chain_debug_enable(pmr_chain q, int on)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    if (on && !q->d_dbg_xr) {
+        int rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_dbg_xr, (size_t)q->res_size * sizeof(cfl)))) return rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_dbg_fm, (size_t)q->chan_size * q->M * sizeof(float)))) return rc;
+    }
+    q->dbg_on = on;
+    return PMR_OK;
+}
+
+int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes, size_t *n_bytes)
+{
+    if (!q) return PMR_EINVAL;
+    if (!q->dbg_on) return fail(q, PMR_EINVAL, "debug capture not enabled", hipSuccess);
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(q->stream), "sync");
+    const void *src = NULL; size_t n = 0;
+    if (what == PMR_DEBUG_RESAMPLED) { src = q->d_dbg_xr; n = (size_t)q->last_ny * sizeof(cfl); }
+    else if (what == PMR_DEBUG_FM)   { src = q->d_dbg_fm; n = (size_t)q->last_ns * q->M * sizeof(float); }
+    else return PMR_EINVAL;
+    if (n_bytes) *n_bytes = n;
+    if (n > cap_bytes) n = cap_bytes;
+    if (n) HIPCHK(hipMemcpy(host_buf, src, n, hipMemcpyDeviceToHost), "debug D2H");
+    return PMR_OK;
+}
+
+/* ---- host-only helpers (no device) ---- */
+static int cfg_design(const pmr_chain_cfg *cfg, pmr_design *d)
+{
+    if (!cfg) return 1;
+    return pmr_design_build(d, cfg->fs_in, cfg->num_channels, cfg->channel_width_hz, cfg->dcblock_alpha,
+                            cfg->resamp_As, cfg->pfb_m, cfg->pfb_As, cfg->fm_kf);
+}
+
+unsigned pmr_cfg_info(const pmr_chain_cfg *cfg, int what, unsigned idx)
+{
+    struct pmr_chain_s tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    if (cfg_design(cfg, &tmp.d)) { pmr_design_free(&tmp.d); return 0; }
+    tmp.M = cfg->num_channels;
+    unsigned r = pmr_chain_info(&tmp, what, idx);
+    pmr_design_free(&tmp.d);
+    return r;
+}
+
+unsigned pmr_cfg_design(const pmr_chain_cfg *cfg, int what, unsigned idx, float *out, unsigned cap)
+{
+    struct pmr_chain_s tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    if (cfg_design(cfg, &tmp.d)) { pmr_design_free(&tmp.d); return 0; }
+    tmp.M = cfg->num_channels;
+    unsigned r = pmr_chain_design(&tmp, what, idx, out, cap);
+    pmr_design_free(&tmp.d);
+    return r;
+}
+
+unsigned pmr_cfg_max_frames(const pmr_chain_cfg *cfg)
+{
+    pmr_design d;
+    unsigned rs = 0, cs = 0;
+    if (!cfg_design(cfg, &d)) pmr_design_buffer_sizes(&d, cfg->max_block, &rs, &cs);
+    pmr_design_free(&d);
+    return cs;
+}
+
+int pmr_cfg_plan_block(const pmr_chain_cfg *cfg, pmr_plan_state *st, unsigned n_in, unsigned *ny, unsigned *ns)
+{
+    pmr_design d;
+    if (!st || cfg_design(cfg, &d)) { pmr_design_free(&d); return PMR_EINVAL; }
+    unsigned ny_ = 0, ns_ = 0; uint32_t ph = 0;
+    plan_core(d.num_stages, d.arb_step, d.M, st->n_raw, st->arb_phase, st->leftover, n_in, &ny_, &ns_, &ph);
+    st->n_raw += n_in;
+    st->arb_phase = ph;
+    st->leftover = (st->leftover + ny_) - ns_ * d.M;
+    if (ny) *ny = ny_;
+    if (ns) *ns = ns_;
+    pmr_design_free(&d);
+    return PMR_OK;
+}

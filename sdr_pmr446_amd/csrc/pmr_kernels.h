@@ -1,0 +1,76 @@
+/* pmr_kernels.h -- C-callable launchers of the gfx950 kernels (internal to libpmr446_hip.so).
+ * All pointers are device pointers; every launcher enqueues on `stream` and returns the hipError_t
+ * of the launch as int (0 == hipSuccess).  Index conventions: tests/chain_model.py. */
+#ifndef PMR_KERNELS_H
+#define PMR_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pmr_stream_t;     /* hipStream_t */
+
+#define PMR_DC_TILE 4096u       /* raw samples per dc-block tile (256 threads x 16) */
+#define PMR_DC_SCAN_THREADS 1024u
+#define PMR_AUDIO_R 32u         /* outputs per thread in the time-major FIR */
+#define PMR_AUDIO_J 5u          /* IIR warm-up outputs (de-emphasis pole^J < 1e-9) */
+
+/* constants of the dc blocker, filled by the host from pmr_design */
+typedef struct {
+    float a1;                   /* -1 + alpha */
+    float lam_pow16[8];         /* lambda^(16 * 2^j), j = 0..7 : thread-chunk scan multipliers      */
+    float lam_tile_pow[10];     /* (lambda^4096)^(2^j), j = 0..9 : tile scan multipliers             */
+} pmr_dc_consts;
+
+/* dc blocker, reference src/sdr_pmr446.c:795.
+ *  pass 0: tile aggregates   agg[tile] = sum_i lambda^(4095-i) x[tile*4096+i]   (zeros beyond n_in)
+ *  scan  : W[tile] = v just before the tile; *state <- v after the last valid sample
+ *  pass 1: yb[n] written to out[n]                                                                  */
+int pmr_launch_dc_agg(pmr_stream_t s, const void *x, unsigned n_in, void *agg, const pmr_dc_consts *c,
+                      const float *lam_thread_pow /*[256] lambda^(16 t)*/);
+int pmr_launch_dc_scan(pmr_stream_t s, const void *agg, unsigned ntiles, void *W, void *state,
+                       const pmr_dc_consts *c, const float *lam_tile_idx_pow /*[1024] (lambda^4096)^t*/,
+                       float lam_last /*lambda^L_last*/, float inv_last /*lambda^-(4096-L_last)*/);
+int pmr_launch_dc_apply(pmr_stream_t s, const void *x, unsigned n_in, const void *W, void *out,
+                        const pmr_dc_consts *c, const float *lam_thread_pow);
+
+/* one half-band decimation stage (:796).  zin[keep_in + r] is the sample r positions after the
+ * first NEW input sample (r < 0: history); par = parity of the absolute index of that first new sample.    */
+int pmr_launch_halfband(pmr_stream_t s, const void *zin, void *zout, unsigned n_out, int keep_in, int par,
+                        int m, const float *h1, float scale);
+
+/* arbitrary polyphase resampler (:796).  dec[keep + q] = q-th new decimated sample.                  */
+int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out, unsigned ny, uint32_t phase0, uint32_t step,
+                   const float *bank, int keep);
+
+/* NCO shift + polyphase analysis bank + M-point FFT + discriminator (:808-821, :881).
+ *  xr        resampled stream; frame f (0 = first new frame) phase c is xr[(p + f)*M + c]
+ *  nco_cs    [period][2] (cos, sin); phase index of xr[0] is nco_idx0
+ *  fm_out    time-major [frame][M], first new frame at fm_out
+ *  chan_out  nullable, channel-major [M][chan_stride]
+ *  rssi_part nullable, [ntiles][M] partial sums of |y|                                                */
+int pmr_launch_channelize(pmr_stream_t s, const void *xr, unsigned ns, unsigned M, unsigned p,
+                          const float *taps_t, const float *fft_tw, const float *nco_cs, unsigned nco_period,
+                          unsigned nco_idx0, float fm_ref, float *fm_out, void *chan_out, unsigned chan_stride,
+                          float *rssi_part, unsigned *ntiles_out);
+unsigned pmr_channelize_tiles(unsigned ns, unsigned M);
+int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntiles, unsigned M, unsigned ns,
+                           float *rssi_db);
+
+/* time-major real FIR with optional epilogue (:882-904).
+ *  in        time-major, in[(t)*M + k], t = 0 first new frame (history at negative t)
+ *  taps_pad  [ntaps + 2*(R+J-1)] zero-padded, oldest-first (reversed) taps
+ *  gain      multiplies the FIR output (:890)
+ *  iir       if non-zero: y = b0*v0 + b1*v1, v0 = u - a1*v1 (:898)
+ *  out_tm    nullable time-major output (same indexing as `in`)
+ *  pcm/audio nullable channel-major [M][stride] final outputs                                          */
+int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, unsigned M, const float *taps_pad,
+                      unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
+                      float *out_tm, int16_t *pcm, float *audio, unsigned stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

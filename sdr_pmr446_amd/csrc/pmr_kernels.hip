@@ -1,0 +1,425 @@
+// pmr_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the per-block IQ DSP chain.
+//
+// Stage order and arithmetic follow the reference loop body src/sdr_pmr446.c:795-906 (the liquid-dsp
+// objects created at :420-480); the explicit index sums each kernel evaluates are written down and
+// checked against the CPU oracle in tests/chain_model.py.  float32 throughout, like liquid's crcf/rrrf.
+//
+// This file is the STAGED path: one kernel per stage, intermediates in HBM.  It is the correctness
+// baseline that the fused front-end (pmr_frontend.hip) is A/B-tested against.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmr_kernels.h"
+
+typedef float2 cf;
+
+static __device__ __forceinline__ cf cf_make(float r, float i) { cf v; v.x = r; v.y = i; return v; }
+
+// ------------------------------------------------------------------------------------------------
+// DC blocker  H(z) = (1 - z^-1) / (1 + a1 z^-1),  a1 = -1 + alpha          (:422, :795)
+//   direct form II as liquid runs it:  v0 = x - a1*v1 ;  y = v0 - v1
+// The recurrence is a first-order linear scan: inside a 4096-sample tile every thread runs 16 samples
+// serially, then a decayed Hillis-Steele scan (multipliers lambda^(16*2^j)) gives each thread its carry.
+// Across tiles the same scan runs on tile aggregates (pmr_launch_dc_scan).
+// ------------------------------------------------------------------------------------------------
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void k_dcblock(const cf *__restrict__ x, unsigned n_in,
+                                                 const cf *__restrict__ W, cf *__restrict__ agg_out,
+                                                 cf *__restrict__ out, pmr_dc_consts c,
+                                                 const float *__restrict__ lam_thread_pow)
+{
+    __shared__ cf sh[256];
+    const unsigned tile = blockIdx.x, t = threadIdx.x;
+    const size_t base = (size_t)tile * PMR_DC_TILE + (size_t)t * 16;
+    cf xs[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        size_t n = base + j;
+        xs[j] = n < n_in ? x[n] : cf_make(0.f, 0.f);
+    }
+    // local recurrence from zero state
+    float vr = 0.f, vi = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        vr = __fsub_rn(xs[j].x, __fmul_rn(c.a1, vr));
+        vi = __fsub_rn(xs[j].y, __fmul_rn(c.a1, vi));
+    }
+    sh[t] = cf_make(vr, vi);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const unsigned d = 1u << j;
+        cf tmp = t >= d ? sh[t - d] : cf_make(0.f, 0.f);
+        __syncthreads();
+        if (t >= d) {
+            cf cur = sh[t];
+            cur.x = fmaf(c.lam_pow16[j], tmp.x, cur.x);
+            cur.y = fmaf(c.lam_pow16[j], tmp.y, cur.y);
+            sh[t] = cur;
+        }
+        __syncthreads();
+    }
+    if (!APPLY) {
+        if (t == 255) agg_out[tile] = sh[255];
+        return;
+    }
+    // v just before this thread's first sample
+    cf w = W[tile];
+    cf ex = t > 0 ? sh[t - 1] : cf_make(0.f, 0.f);
+    const float lp = lam_thread_pow[t];
+    float v1r = fmaf(lp, w.x, ex.x), v1i = fmaf(lp, w.y, ex.y);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        float v0r = __fsub_rn(xs[j].x, __fmul_rn(c.a1, v1r));
+        float v0i = __fsub_rn(xs[j].y, __fmul_rn(c.a1, v1i));
+        size_t n = base + j;
+        if (n < n_in) out[n] = cf_make(__fsub_rn(v0r, v1r), __fsub_rn(v0i, v1i));
+        v1r = v0r; v1i = v0i;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_dc_scan(const cf *__restrict__ agg, unsigned ntiles,
+                                                  cf *__restrict__ W, cf *__restrict__ state,
+                                                  pmr_dc_consts c, const float *__restrict__ idx_pow,
+                                                  float lam_last, float inv_last)
+{
+    __shared__ cf sh[1024];
+    __shared__ cf carry_s;
+    const unsigned t = threadIdx.x;
+    if (t == 0) carry_s = *state;
+    __syncthreads();
+    for (unsigned base = 0; base < ntiles; base += 1024) {
+        const unsigned i = base + t;
+        const cf a = i < ntiles ? agg[i] : cf_make(0.f, 0.f);
+        const cf carry = carry_s;
+        sh[t] = a;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            const unsigned d = 1u << j;
+            cf tmp = t >= d ? sh[t - d] : cf_make(0.f, 0.f);
+            __syncthreads();
+            if (t >= d) {
+                cf cur = sh[t];
+                cur.x = fmaf(c.lam_tile_pow[j], tmp.x, cur.x);
+                cur.y = fmaf(c.lam_tile_pow[j], tmp.y, cur.y);
+                sh[t] = cur;
+            }
+            __syncthreads();
+        }
+        const cf inc = sh[t];
+        const cf ex = t > 0 ? sh[t - 1] : cf_make(0.f, 0.f);
+        const float ip = idx_pow[t];
+        const cf Wi = cf_make(fmaf(ip, carry.x, ex.x), fmaf(ip, carry.y, ex.y));
+        if (i < ntiles) W[i] = Wi;
+        if (i == ntiles - 1) {
+            // v after the last VALID sample: undo the decay over the zero padding of the last tile
+            *state = cf_make(fmaf(lam_last, Wi.x, inv_last * a.x), fmaf(lam_last, Wi.y, inv_last * a.y));
+        }
+        __syncthreads();
+        if (t == 1023) carry_s = inc;     // (lambda^4096)^1024 underflows to 0: older carry is gone
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Half-band decimator stage: z1[i] = z0[2i+1-2m] + sum_j h1[j] * z0[2i - 2(2m-1-j)]   
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halfband(const cf *__restrict__ zin, cf *__restrict__ zout,
+                                                  unsigned n_out, int keep_in, int par, int m,
+                                                  const float *__restrict__ h1, float scale)
+{
+    const unsigned o = blockIdx.x * 256u + threadIdx.x;
+    if (o >= n_out) return;
+    const cf *p = zin + keep_in + 2 * (long)o - par;   // -> absolute index 2i
+    float yr = 0.f, yi = 0.f;
+    const int L = 2 * m;
+    for (int j = 0; j < L; j++) {
+        const cf s = p[-2 * (L - 1 - j)];
+        const float h = h1[j];
+        yr = fmaf(h, s.x, yr);
+        yi = fmaf(h, s.y, yi);
+    }
+    const cf d = p[1 - 2 * m];
+    zout[o] = cf_make((d.x + yr) * scale, (d.y + yi) * scale);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Arbitrary polyphase resampler with 24-bit phase: out[j] = sum_k bank[idx_j][k] * dec[q_j - 13 + k]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_arb(const cf *__restrict__ dec, cf *__restrict__ out, unsigned ny,
+                                             uint32_t phase0, uint32_t step, const float *__restrict__ bank,
+                                             int keep)
+{
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= ny) return;
+    const uint64_t ph = (uint64_t)phase0 + (uint64_t)j * step;
+    const long q = (long)(ph >> 24);
+    const unsigned idx = (unsigned)(ph & 0xffffffu) >> 16;
+    const float *b = bank + idx * 14u;
+    const cf *p = dec + keep + q - 13;
+    float yr = 0.f, yi = 0.f;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        const cf s = p[k];
+        yr = fmaf(b[k], s.x, yr);
+        yi = fmaf(b[k], s.y, yi);
+    }
+    out[j] = cf_make(yr, yi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCO shift (:808-812) + polyphase analysis filter bank + M-point FFT (:814) + discriminator (:881).
+// One workgroup owns FT frames in LDS (the first one is the frame BEFORE its range, recomputed so the
+// discriminator has conj(prev) without a cross-workgroup dependency).
+// ------------------------------------------------------------------------------------------------
+static __host__ __device__ inline unsigned chan_ft(unsigned M) { unsigned ft = 8192u / M; return ft < 4u ? 4u : ft; }
+
+__global__ __launch_bounds__(256) void k_channelize(const cf *__restrict__ xr, unsigned ns, unsigned M,
+                                                    unsigned log2M, unsigned p,
+                                                    const float *__restrict__ taps_t,
+                                                    const cf *__restrict__ fft_tw,
+                                                    const cf *__restrict__ nco_cs, unsigned nco_mask,
+                                                    unsigned nco_idx0, float fm_ref, float *__restrict__ fm_out,
+                                                    cf *__restrict__ chan_out, unsigned chan_stride,
+                                                    float *__restrict__ rssi_part)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned FT = chan_ft(M), TFN = FT - 1;
+    cf *Xs = reinterpret_cast<cf *>(smem);            // [FT][M]
+    cf *tw = Xs + (size_t)FT * M;                     // [M/2]
+    const unsigned tid = threadIdx.x;
+    const unsigned t0 = blockIdx.x * TFN;             // first NEW frame of this tile
+    const unsigned nf = min(TFN, ns - t0);            // new frames in this tile
+
+    for (unsigned k = tid; k < M / 2; k += 256) tw[k] = fft_tw[k];
+
+    // phase 1: X[f][c] = sum_k taps_t[k][c] * xm[(t0 + f + k) * M + c],  f = 0 is frame t0-1
+    const unsigned items = (nf + 1) * M;
+    for (unsigned w = tid; w < items; w += 256) {
+        const unsigned f = w >> log2M, c = w & (M - 1);
+        float ar = 0.f, ai = 0.f;
+        const size_t s0 = (size_t)(t0 + f) * M + c;
+        for (unsigned k = 0; k < p; k++) {
+            const size_t s = s0 + (size_t)k * M;
+            const cf x = xr[s];
+            const cf cs = nco_cs[(nco_idx0 + (unsigned)s) & nco_mask];
+            const float xmr = fmaf(x.x, cs.x, x.y * cs.y);       // x * conj(e^{j theta})
+            const float xmi = fmaf(x.y, cs.x, -(x.x * cs.y));
+            const float h = taps_t[k * M + c];
+            ar = fmaf(h, xmr, ar);
+            ai = fmaf(h, xmi, ai);
+        }
+        const unsigned rc = __brev(c) >> (32 - log2M);
+        Xs[f * M + rc] = cf_make(ar, ai);
+    }
+    __syncthreads();
+
+    // phase 2: in-place radix-2 DIT FFT of every frame (forward, unscaled)
+    const unsigned nb = (nf + 1) * (M / 2);
+    for (unsigned len = 2, lg = 1; len <= M; len <<= 1, lg++) {
+        const unsigned half = len >> 1, tstep = M >> lg;
+        for (unsigned b = tid; b < nb; b += 256) {
+            const unsigned f = b >> (log2M - 1), r = b & (M / 2 - 1);
+            const unsigned grp = r >> (lg - 1), k = r & (half - 1);
+            const unsigned i0 = f * M + grp * len + k, i1 = i0 + half;
+            const cf wv = tw[k * tstep];
+            const cf a = Xs[i0], bb = Xs[i1];
+            const float tr = fmaf(bb.x, wv.x, -(bb.y * wv.y));
+            const float ti = fmaf(bb.x, wv.y, bb.y * wv.x);
+            Xs[i0] = cf_make(a.x + tr, a.y + ti);
+            Xs[i1] = cf_make(a.x - tr, a.y - ti);
+        }
+        __syncthreads();
+    }
+
+    // phase 3: discriminator m = arg(conj(prev) * cur) / (2 pi kf), plus tap-offs
+    const unsigned oitems = nf * M;
+    for (unsigned w = tid; w < oitems; w += 256) {
+        const unsigned f = w >> log2M, k = w & (M - 1);
+        const cf pv = Xs[f * M + k], cu = Xs[(f + 1) * M + k];
+        const float re = fmaf(pv.x, cu.x, pv.y * cu.y);
+        const float im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
+        fm_out[(size_t)(t0 + f) * M + k] = atan2f(im, re) * fm_ref;
+        if (chan_out) chan_out[(size_t)k * chan_stride + t0 + f] = cu;
+    }
+    if (rssi_part) {
+        for (unsigned k = tid; k < M; k += 256) {
+            float a = 0.f;
+            for (unsigned f = 0; f < nf; f++) {
+                const cf cu = Xs[(f + 1) * M + k];
+                a += hypotf(cu.x, cu.y);
+            }
+            rssi_part[(size_t)blockIdx.x * M + k] = a;
+        }
+    }
+}
+
+__global__ void k_rssi_finish(const float *__restrict__ part, unsigned ntiles, unsigned M, unsigned ns,
+                              float *__restrict__ rssi_db)
+{
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    float a = 0.f;
+    for (unsigned t = 0; t < ntiles; t++) a += part[(size_t)t * M + k];
+    rssi_db[k] = 20.f * log10f(a / (float)ns);       // average_power(), :330-336
+}
+
+// ------------------------------------------------------------------------------------------------
+// Time-major real FIR, R outputs per thread, taps wave-uniform (scalar loads), optional epilogue:
+//   gain (:890) -> de-emphasis IIR (:898) -> int16 PCM (src/dsd_in.c:174) / float audio (:904)
+// lane <-> (channel k, time segment); y[t] = sum_d h[d] x[t-d], accumulated oldest sample first.
+// ------------------------------------------------------------------------------------------------
+#define RP (PMR_AUDIO_R + PMR_AUDIO_J)
+
+__global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, unsigned ns, unsigned M,
+                                                unsigned log2M, const float *__restrict__ taps_pad,
+                                                unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
+                                                float *__restrict__ out_tm, int16_t *__restrict__ pcm,
+                                                float *__restrict__ audio, unsigned stride)
+{
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+    const unsigned k = gid & (M - 1), seg = gid >> log2M;
+    const long t0 = (long)seg * PMR_AUDIO_R;
+    if (t0 >= (long)ns) return;
+    float acc[RP];
+#pragma unroll
+    for (int i = 0; i < (int)RP; i++) acc[i] = 0.f;
+    // input sample index of step e: s = t0 - J - (ntaps-1) + e
+    const float *px = in + ((t0 - (long)PMR_AUDIO_J - (long)(ntaps - 1)) * (long)M + (long)k);
+    const unsigned steps = ntaps + RP - 1;
+    for (unsigned e = 0; e < steps; e++) {
+        const float x = px[(size_t)e * M];
+        const float *tp = taps_pad + e;               // wave-uniform -> scalar loads
+#pragma unroll
+        for (int i = 0; i < (int)RP; i++) acc[i] = fmaf(tp[RP - 1 - i], x, acc[i]);
+    }
+    float v1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < (int)RP; i++) {
+        float u = __fmul_rn(acc[i], gain);
+        float y = u;
+        if (iir) {
+            const float v0 = __fsub_rn(u, __fmul_rn(a1, v1));
+            y = __fadd_rn(__fmul_rn(b0, v0), __fmul_rn(b1, v1));
+            v1 = v0;
+        }
+        if (i >= (int)PMR_AUDIO_J) {
+            const long t = t0 + (i - (int)PMR_AUDIO_J);
+            if (t < (long)ns) {
+                if (out_tm) out_tm[(size_t)t * M + k] = y;
+                if (audio) audio[(size_t)k * stride + t] = y;
+                if (pcm) {
+                    float s = y * 32767.0f;
+                    int16_t q;
+                    if (!(s == s)) q = 0;
+                    else if (s >= 32767.0f) q = 32767;
+                    else if (s <= -32768.0f) q = -32768;
+                    else q = (int16_t)s;                  // truncation toward zero
+                    pcm[(size_t)k * stride + t] = q;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline unsigned ilog2(unsigned v) { unsigned l = 0; while ((1u << l) < v) l++; return l; }
+
+extern "C" int pmr_launch_dc_agg(pmr_stream_t s, const void *x, unsigned n_in, void *agg,
+                                 const pmr_dc_consts *c, const float *lam_thread_pow)
+{
+    const unsigned ntiles = (n_in + PMR_DC_TILE - 1) / PMR_DC_TILE;
+    if (!ntiles) return 0;
+    hipLaunchKernelGGL(k_dcblock<false>, dim3(ntiles), dim3(256), 0, (hipStream_t)s, (const cf *)x, n_in,
+                       (const cf *)nullptr, (cf *)agg, (cf *)nullptr, *c, lam_thread_pow);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_dc_scan(pmr_stream_t s, const void *agg, unsigned ntiles, void *W, void *state,
+                                  const pmr_dc_consts *c, const float *lam_tile_idx_pow, float lam_last,
+                                  float inv_last)
+{
+    if (!ntiles) return 0;
+    hipLaunchKernelGGL(k_dc_scan, dim3(1), dim3(PMR_DC_SCAN_THREADS), 0, (hipStream_t)s, (const cf *)agg, ntiles,
+                       (cf *)W, (cf *)state, *c, lam_tile_idx_pow, lam_last, inv_last);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_dc_apply(pmr_stream_t s, const void *x, unsigned n_in, const void *W, void *out,
+                                   const pmr_dc_consts *c, const float *lam_thread_pow)
+{
+    const unsigned ntiles = (n_in + PMR_DC_TILE - 1) / PMR_DC_TILE;
+    if (!ntiles) return 0;
+    hipLaunchKernelGGL(k_dcblock<true>, dim3(ntiles), dim3(256), 0, (hipStream_t)s, (const cf *)x, n_in,
+                       (const cf *)W, (cf *)nullptr, (cf *)out, *c, lam_thread_pow);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_halfband(pmr_stream_t s, const void *zin, void *zout, unsigned n_out, int keep_in,
+                                   int par, int m, const float *h1, float scale)
+{
+    if (!n_out) return 0;
+    hipLaunchKernelGGL(k_halfband, dim3((n_out + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)zin,
+                       (cf *)zout, n_out, keep_in, par, m, h1, scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out, unsigned ny, uint32_t phase0,
+                              uint32_t step, const float *bank, int keep)
+{
+    if (!ny) return 0;
+    hipLaunchKernelGGL(k_arb, dim3((ny + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)dec, (cf *)out, ny,
+                       phase0, step, bank, keep);
+    return (int)hipGetLastError();
+}
+
+extern "C" unsigned pmr_channelize_tiles(unsigned ns, unsigned M)
+{
+    const unsigned tfn = chan_ft(M) - 1;
+    return (ns + tfn - 1) / tfn;
+}
+
+extern "C" int pmr_launch_channelize(pmr_stream_t s, const void *xr, unsigned ns, unsigned M, unsigned p,
+                                     const float *taps_t, const float *fft_tw, const float *nco_cs,
+                                     unsigned nco_period, unsigned nco_idx0, float fm_ref, float *fm_out,
+                                     void *chan_out, unsigned chan_stride, float *rssi_part, unsigned *ntiles_out)
+{
+    const unsigned ntiles = pmr_channelize_tiles(ns, M);
+    if (ntiles_out) *ntiles_out = ntiles;
+    if (!ns) return 0;
+    const size_t lds = ((size_t)chan_ft(M) * M + M / 2) * sizeof(cf);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_channelize, dim3(ntiles), dim3(256), lds, (hipStream_t)s, (const cf *)xr, ns, M, ilog2(M),
+                       p, taps_t, (const cf *)fft_tw, (const cf *)nco_cs, nco_period - 1, nco_idx0, fm_ref, fm_out,
+                       (cf *)chan_out, chan_stride, rssi_part);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntiles, unsigned M,
+                                      unsigned ns, float *rssi_db)
+{
+    hipLaunchKernelGGL(k_rssi_finish, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)s, rssi_part, ntiles, M, ns,
+                       rssi_db);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, unsigned M, const float *taps_pad,
+                                 unsigned ntaps, float gain, int iir, float b0, float b1, float a1, float *out_tm,
+                                 int16_t *pcm, float *audio, unsigned stride)
+{
+    if (!ns) return 0;
+    const unsigned segs = (ns + PMR_AUDIO_R - 1) / PMR_AUDIO_R;
+    const size_t threads = (size_t)segs * M;
+    hipLaunchKernelGGL(k_fir_tm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, ns, M,
+                       ilog2(M), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
+    return (int)hipGetLastError();
+}
