@@ -1,0 +1,160 @@
+"""GPU tier: the HIP chain (through the C-ABI of include/pmr_chain.h) against the CPU oracle on identical
+seeded synthetic IQ.  Tolerances: int16 PCM within +-1 LSB (BASELINE.json north_star) on every channel that
+carries a signal (empty channels excluded: the discriminator of pure noise is ill-conditioned);
+float intermediates within a few float32 ulps of the signal scale."""
+import numpy as np
+import pytest
+
+import oracle
+from parity_util import CFG2, CFG3, CFG5, CFG_REF, active_channels, pcm_diff, rel_err, run_blocks
+from sdr_pmr446_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+WANT = ("pcm", "audio", "chan", "rssi", "resampled", "fm")
+
+
+def _pair(fs, M, mb, **kw):
+    from sdr_pmr446_amd import chain
+    return oracle.OracleChain(fs_in=fs, num_channels=M, max_block=mb, **kw), \
+        chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb, **kw)
+
+
+def _compare(fs, M, x, splits, synth_ch=None, skip_frames=40, **kw):
+    o, g = _pair(fs, M, max(max(splits), 1), **kw)
+    ro, rg = run_blocks(o, x, splits, WANT), run_blocks(g, x, splits, WANT)
+    assert rg["n_frames"] == ro["n_frames"]
+    assert len(rg["resampled"]) == len(ro["resampled"])
+    assert rel_err(rg["resampled"], ro["resampled"]) < 1e-5           # resampler output (:796)
+    assert rel_err(rg["chan"], ro["chan"]) < 1e-5                     # channelizer tap-off (:814-821)
+    act = active_channels(M, synth_ch)
+    ns = ro["n_frames"]
+    assert np.abs(rg["audio"][act] - ro["audio"][act]).max() < 1e-4 if ns else True
+    if ns > skip_frames:                                              # first frames: |chan| ~ 0, arg() ill-conditioned
+        assert np.abs(rg["fm"][act][:, skip_frames:] - ro["fm"][act][:, skip_frames:]).max() < 2e-6
+    settle = skip_frames + 377 + 103 + 101                            # ... and that error rings through the audio FIRs
+    if ns > settle:
+        assert np.abs(rg["audio"][act][:, settle:] - ro["audio"][act][:, settle:]).max() < 5e-6
+    d = pcm_diff(rg["pcm"][act], ro["pcm"][act])
+    assert d.size == 0 or d.max() <= 1                                # +-1 LSB
+    for a, b, n in zip(rg["rssi"], ro["rssi"], [1] * len(ro["rssi"])):
+        m = np.isfinite(b)
+        assert np.allclose(a[m], b[m], atol=1e-3)                     # dB
+    o.close(); g.close()
+    return ro, rg
+
+
+@pytest.mark.parametrize("dev_hz", [500.0, 2500.0])
+def test_cfg2_one_reference_block(dev_hz):
+    fs, M = CFG2
+    x = synth.synth_iq(100000, fs, M, dev_hz=dev_hz)                   # 100000 = SDR_INPUT_CHUNK (:30)
+    ro, _ = _compare(fs, M, x, [100000])
+    assert ro["n_frames"] == 520
+
+
+def test_reference_operating_point_two_blocks():
+    fs, M = CFG_REF
+    x = synth.synth_iq(200000, fs, M, dev_hz=500.0)
+    ro, _ = _compare(fs, M, x, [100000, 100000])
+    assert ro["n_frames"] == 2441                                      # :736
+
+
+def test_block_split_invariance_random_splits():
+    fs, M = CFG2
+    x = synth.synth_iq(300000, fs, M, dev_hz=500.0)
+    rng = np.random.default_rng(11)
+    sp, left = [], len(x)
+    while left:
+        n = int(min(left, rng.integers(0, 60000)))
+        sp.append(n); left -= n
+    _compare(fs, M, x, sp)
+
+
+def test_ragged_and_empty_blocks():
+    fs, M = CFG2
+    sp = [1, 7, 0, 100, 4095, 4096, 4097, 3000, 16, 8, 0, 4580]
+    x = synth.synth_iq(sum(sp), fs, M, dev_hz=500.0)
+    _compare(fs, M, x, sp)
+
+
+@pytest.mark.parametrize("opts", [dict(lowpass=True), dict(deemph_fir=True), dict(lowpass=True, deemph_fir=True),
+                                  dict(audio_gain=1.0)])
+def test_audio_options(opts):
+    fs, M = CFG2
+    x = synth.synth_iq(200000, fs, M, dev_hz=500.0)
+    _compare(fs, M, x, [100000, 60000, 40000], **opts)
+
+
+def test_dc_offset_is_blocked():
+    fs, M = CFG2
+    x = synth.synth_iq(200000, fs, M, dev_hz=500.0, dc_offset=0.25 + 0.1j)
+    _compare(fs, M, x, [100000, 100000])
+
+
+def test_cfg3_256_channels():
+    fs, M = CFG3
+    ks = list(range(0, M, 5))
+    x = synth.synth_iq(1 << 22, fs, M, channels=ks, dev_hz=500.0)
+    _compare(fs, M, x, [1 << 21, 1 << 21], synth_ch=ks)
+
+
+def test_cfg5_1024_channels():
+    fs, M = CFG5
+    ks = list(range(0, M, 73))
+    x = synth.synth_iq(1 << 25, fs, M, channels=ks, dev_hz=500.0)
+    _compare(fs, M, x, [1 << 24, 1 << 24], synth_ch=ks)
+
+
+def test_reset_restarts_the_stream():
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    x = synth.synth_iq(100000, fs, M, dev_hz=500.0)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=100000)
+    a = g.process_block(x)["pcm"]
+    g.process_block(x[:33333])
+    g.reset()
+    b = g.process_block(x)["pcm"]
+    assert np.array_equal(a, b)
+
+
+def test_errors_do_not_abort():
+    from sdr_pmr446_amd import chain
+    g = chain.PmrChain(fs_in=2.4e6, num_channels=16, max_block=1000)
+    with pytest.raises(chain.PmrError):
+        g.process_block(np.zeros(1001, dtype=np.complex64))             # n_in > max_block -> PMR_ERANGE
+    out = g.process_block(np.zeros(0, dtype=np.complex64))
+    assert out["n_frames"] == 0
+
+
+def test_full_size_split_invariance_and_known_answer():
+    """BASELINE-size block (2^24 samples, cfg2) generated in HBM: (a) one call vs 16 calls agree within 1 LSB,
+    (b) the FM tone of every 'fm' channel has the analytic discriminator amplitude."""
+    import torch
+    from sdr_pmr446_amd import chain
+    from sdr_pmr446_amd.synth_torch import synth_iq_torch
+    fs, M = CFG2
+    n = 1 << 24
+    iq = synth_iq_torch(n, fs, M, torch.device("cuda", 0), dev_hz=500.0)
+    g1 = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n)
+    g2 = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n // 16)
+    S1, S2 = g1.max_frames, g2.max_frames
+    pcm1 = torch.zeros((M, S1), dtype=torch.int16, device="cuda")
+    au1 = torch.zeros((M, S1), dtype=torch.float32, device="cuda")
+    ns1 = g1.process_block_device(iq.data_ptr(), n, d_pcm=pcm1.data_ptr(), d_audio=au1.data_ptr(), stride=S1)
+    g1.synchronize()
+    parts = []
+    for b in range(16):
+        pcm2 = torch.zeros((M, S2), dtype=torch.int16, device="cuda")
+        ns = g2.process_block_device(iq.data_ptr() + b * (n // 16) * 8, n // 16, d_pcm=pcm2.data_ptr(), stride=S2)
+        g2.synchronize()
+        parts.append(pcm2[:, :ns].cpu())
+    p2 = torch.cat(parts, dim=1).numpy().astype(np.int32)
+    p1 = pcm1[:, :ns1].cpu().numpy().astype(np.int32)
+    act = active_channels(M)
+    assert p1.shape == p2.shape and np.abs(p1[act] - p2[act]).max() <= 1
+    a = au1[:, 1000:ns1].cpu().numpy()
+    for k in act:
+        if synth.channel_kind(k) == "fm":
+            fa = synth.audio_tone_hz(k)
+            expect = 4.0 * (2 * 500.0 / 12500.0) / np.sqrt(1 + (fa / 3183.1) ** 2)
+            assert abs(np.abs(a[k]).max() - expect) < 0.03 * expect + 0.01
