@@ -22,15 +22,15 @@
 #define FM_HIST_FRAMES 512u     /* >= 376 (HP) + IIR warm-up; also covers 102/100-tap follow-on FIRs */
 #define AUX_HIST_FRAMES 128u    /* history of the time-major intermediates behind the HP stage        */
 #define ARB_KEEP 16             /* decimated-sample history kept for the 14-tap arbitrary resampler   */
-#define PROF_SLOTS 16
+#define PROF_SLOTS 24
 
 typedef struct { float re, im; } cfl;
 
 enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
-       K_COUNT };
+       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_COUNT };
 static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
                                         "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
-                                        "k_fir_tm<lp>" };
+                                        "k_fir_tm<lp>", "k_frontend", "k_fe_tiles", "k_fe_dcfix", "k_fe_hist" };
 
 typedef struct { hipEvent_t a, b; int slot; } prof_pending;
 
@@ -59,6 +59,16 @@ struct pmr_chain_s {
     void *d_scratch; size_t scratch_bytes;
     int16_t *d_pcm; float *d_audio; cfl *d_chan; float *d_rssi, *d_rssi_part;
     size_t rssi_part_cap;
+
+    /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
+    int fe_on, fe_nt;                /* fused path selected; threads per tile workgroup (256 / 1024)  */
+    int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
+    int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
+    float fe_Kgain, fe_lam_wave, fe_lam_pow16[6];
+    float *d_fe_taps, *d_fe_GA, *d_fe_T1, *d_fe_T2, *d_fe_lam_lane;
+    cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V;
+    int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
+    unsigned fe_max_tiles;
 
     /* host-side counters (all closed form in the number of samples consumed) */
     uint64_t n_raw;                  /* raw samples consumed since reset                      */
@@ -202,6 +212,112 @@ void pmr_chain_default_cfg(pmr_chain_cfg *c)
     c->device = -1;
 }
 
+/* ------------------------------------------------------------------------------------------- */
+/* fused front end: tile geometry and the closed-form gains of the cascade for an exponential     */
+
+static int fe_init(pmr_chain q)
+{
+    const pmr_design *d = &q->d;
+    const unsigned h = d->num_stages, D = d->decim;
+    int rc;
+    q->fe_on = 0;
+    const char *env = getenv("PMR_FRONTEND");
+    if (env && !strcmp(env, "staged")) return PMR_OK;
+    if (h > PMR_FE_MAX_STAGES) return PMR_OK;
+
+    /* raw-sample history the cascade needs: S = sum_e (4 m_e - 2) 2^e (execution order) + 13 decimated samples */
+    unsigned long S = 0;
+    for (unsigned e = 0; e < h; e++) {
+        q->fe_m[e] = (int)d->m_stage[h - 1 - e];
+        S += (unsigned long)(4 * q->fe_m[e] - 2) << e;
+    }
+    const unsigned long H = S + 13ul * D;
+    const unsigned long L = D > 16 ? D : 16;
+    int nt = 0;
+    unsigned long T_own = 0;
+    for (int cand = 256; cand <= 1024; cand *= 4) {
+        const unsigned long N0 = (unsigned long)cand * 16;
+        if (N0 % L || H + L > N0) continue;
+        const unsigned long t = (N0 - H) / L * L;
+        if (t * 4 >= N0 * 3 || cand == 1024) { if (t * 2 >= N0) { nt = cand; T_own = t; } break; }
+    }
+    if (!nt) return PMR_OK;                      /* cascade too deep for one LDS tile: staged path */
+    const unsigned long N0 = (unsigned long)nt * 16;
+    q->fe_nt = nt;
+    q->fe_T_own = (int)T_own;
+    q->fe_Hh = (int)(N0 - T_own);
+    q->fe_HhQ = q->fe_Hh / (int)D;
+    q->fe_TQ = (int)(T_own / D);
+    q->fe_hcap = (int)((q->fe_Hh + D + 15) / 16 * 16);
+    q->fe_max_tiles = (unsigned)((q->cfg.max_block + D) / T_own + 2);
+
+    /* branch taps of all stages, execution order */
+    {
+        float tmp[PMR_FE_MAX_STAGES * 64];
+        int off = 0;
+        for (unsigned e = 0; e < h; e++) {
+            const unsigned g = h - 1 - e, n = 2 * d->m_stage[g];
+            if (off + n > sizeof(tmp) / sizeof(tmp[0])) return PMR_OK;
+            q->fe_tap_off[e] = off;
+            memcpy(tmp + off, d->hb_h1[g], n * sizeof(float));
+            off += (int)n;
+        }
+        if ((rc = dev_upload(q, &q->d_fe_taps, tmp, off ? off : 1))) return rc;
+    }
+
+    /* gains for yb_err[r] = alpha V lambda^r:  stage e maps A mu^n -> A G_e (mu^2)^i with
+     * G_e = mu * sum_k hb_e[k] mu^-k;  after the cascade dec_err[q'] = alpha zeta prod(G_e) V mu_h^q';
+     * the arbitrary resampler adds GA[idx] = sum_n hA[idx + 256 n] mu_h^-n.  All in double.          */
+    const double lam = d->dc_lambda, alpha = 1.0 - lam;
+    double mu = lam, G = 1.0;
+    for (unsigned e = 0; e < h; e++) {
+        const unsigned g = h - 1 - e, n = 4 * d->m_stage[g] + 1;
+        double acc = 0.0;
+        for (unsigned k = 0; k < n; k++) acc += (double)d->hb_proto[g][k] * pow(mu, -(double)k);
+        G *= mu * acc;
+        mu *= mu;
+    }
+    q->fe_Kgain = (float)(alpha * (double)d->zeta * G);
+    {
+        float ga[PMR_ARB_NPFB];
+        for (unsigned idx = 0; idx < PMR_ARB_NPFB; idx++) {
+            double acc = 0.0;
+            for (unsigned n = 0; n < 2 * PMR_ARB_M; n++)
+                acc += (double)d->arb_proto[idx + PMR_ARB_NPFB * n] * pow(mu, -(double)n);
+            ga[idx] = (float)acc;
+        }
+        if ((rc = dev_upload(q, &q->d_fe_GA, ga, PMR_ARB_NPFB))) return rc;
+        const unsigned nq = (unsigned)(N0 / D), n1 = nq / 32 + 2;
+        float *t1 = (float *)calloc(n1, sizeof(float)), t2[32];
+        if (!t1) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+        for (unsigned i = 0; i < n1; i++) t1[i] = (float)pow(mu, 32.0 * i);
+        for (unsigned i = 0; i < 32; i++) t2[i] = (float)pow(mu, (double)i);
+        rc = dev_upload(q, &q->d_fe_T1, t1, n1);
+        free(t1);
+        if (rc) return rc;
+        if ((rc = dev_upload(q, &q->d_fe_T2, t2, 32))) return rc;
+    }
+    {
+        float ll[64];
+        for (unsigned l = 0; l < 64; l++) ll[l] = (float)pow(lam, 16.0 * l);
+        if ((rc = dev_upload(q, &q->d_fe_lam_lane, ll, 64))) return rc;
+        for (int j = 0; j < 6; j++) q->fe_lam_pow16[j] = (float)pow(lam, 16.0 * (double)(1u << j));
+        q->fe_lam_wave = (float)pow(lam, 1024.0);
+    }
+    for (int i = 0; i < 2; i++) {
+        if ((rc = dev_alloc(q, (void **)&q->d_fe_hist[i], (size_t)q->fe_hcap * sizeof(cfl)))) return rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_fe_vstate[i], sizeof(cfl)))) return rc;
+    }
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeA, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeB, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_V, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeL, sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeE, sizeof(cfl)))) return rc;
+    q->fe_sel = 0;
+    q->fe_on = 1;
+    return PMR_OK;
+}
+
 static int chain_init(pmr_chain q)
 {
     const pmr_design *d = &q->d;
@@ -276,6 +392,8 @@ static int chain_init(pmr_chain q)
     q->rssi_part_cap = (size_t)pmr_channelize_tiles(q->chan_size, M) * M;
     if ((rc = dev_alloc(q, (void **)&q->d_rssi_part, q->rssi_part_cap * sizeof(float)))) return rc;
 
+    if ((rc = fe_init(q))) return rc;
+
     q->n_raw = 0; q->arb_phase = 0; q->xr_fill = p * M; q->xr_base = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "init sync");
     return PMR_OK;
@@ -328,7 +446,9 @@ int pmr_chain_destroy(pmr_chain q)
     void *bufs[] = { q->d_arb_bank, q->d_pfb_taps_t, q->d_fft_tw, q->d_nco_cs, q->d_lam_thread_pow,
                      q->d_lam_tile_idx_pow, q->d_hp_pad, q->d_lp_pad, q->d_de_pad, q->d_in, q->d_dc_state,
                      q->d_dc_agg, q->d_dc_W, q->d_xr, q->d_fm, q->d_aux1, q->d_aux2, q->d_scratch, q->d_pcm,
-                     q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm };
+                     q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
+                     q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
+                     q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     if (q->stream) hipStreamDestroy(q->stream);
     pmr_design_free(&q->d);
@@ -350,6 +470,11 @@ int pmr_chain_reset(pmr_chain q)
         HIPCHK(hipMemsetAsync(q->d_aux1, 0, (size_t)AUX_HIST_FRAMES * M * sizeof(float), q->stream), "reset");
         HIPCHK(hipMemsetAsync(q->d_aux2, 0, (size_t)AUX_HIST_FRAMES * M * sizeof(float), q->stream), "reset");
     }
+    if (q->fe_on) for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMemsetAsync(q->d_fe_hist[i], 0, (size_t)q->fe_hcap * sizeof(cfl), q->stream), "reset");
+        HIPCHK(hipMemsetAsync(q->d_fe_vstate[i], 0, sizeof(cfl), q->stream), "reset");
+    }
+    q->fe_sel = 0;
     q->n_raw = 0; q->arb_phase = 0; q->xr_fill = p * M; q->xr_base = 0; q->last_ny = q->last_ns = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
     return PMR_OK;
@@ -438,6 +563,67 @@ static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigne
     return PMR_OK;
 }
 
+/* front end, fused: one pass over the raw block (pmr_frontend.hip) */
+static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny_out)
+{
+    const pmr_design *d = &q->d;
+    const unsigned h = d->num_stages, D = d->decim;
+    *ny_out = 0;
+    if (n_in == 0) return PMR_OK;
+    const unsigned pend = (unsigned)(q->n_raw & (D - 1));
+    const unsigned Q = (unsigned)(((q->n_raw + n_in) >> h) - (q->n_raw >> h));
+    unsigned ny = 0, ns_unused = 0; uint32_t new_phase = 0;
+    plan_core(h, d->arb_step, q->M, q->n_raw, q->arb_phase, 0, n_in, &ny, &ns_unused, &new_phase);
+    const unsigned long total = (unsigned long)pend + n_in;
+    const unsigned ntiles = (unsigned)((total + q->fe_T_own - 1) / q->fe_T_own);
+    const unsigned c_end = (unsigned)((total - 1) / q->fe_T_own);
+    const int off_end = (int)((total - 1) - (unsigned long)c_end * q->fe_T_own) + q->fe_Hh;
+    if (ntiles > q->fe_max_tiles) return fail(q, PMR_ERANGE, "tile count", hipSuccess);
+    const int cur = q->fe_sel, nxt = cur ^ 1;
+
+    pmr_fe_params p;
+    memset(&p, 0, sizeof(p));
+    p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.out = q->d_xr + q->xr_fill;
+    p.probeA = q->d_fe_probeA; p.probeB = q->d_fe_probeB; p.probeL = q->d_fe_probeL; p.probeE = q->d_fe_probeE;
+    p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
+    p.n_in = n_in; p.ny = ny; p.Q = Q; p.phi0 = q->arb_phase; p.step = d->arb_step;
+    p.h = (int)h; p.T_own = q->fe_T_own; p.Hh = q->fe_Hh; p.HhQ = q->fe_HhQ; p.TQ = q->fe_TQ;
+    p.pend = (int)pend; p.hcap = q->fe_hcap; p.c_end = (int)c_end; p.off_end = off_end;
+    memcpy(p.m, q->fe_m, sizeof(p.m)); memcpy(p.tap_off, q->fe_tap_off, sizeof(p.tap_off));
+    p.dc_a1 = d->dc_a1; p.zeta = d->zeta; p.lam_wave = q->fe_lam_wave;
+    memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
+    LAUNCH(K_FE, pmr_launch_frontend(q->stream, &p, ntiles, q->fe_nt));
+
+    pmr_fe_tiles_params t;
+    memset(&t, 0, sizeof(t));
+    const double lam = d->dc_lambda;
+    const double rho = pow(lam, (double)q->fe_T_own);
+    double kterms = rho > 0.0 && rho < 1.0 ? ceil(log(1e-12) / log(rho)) : 1.0;
+    if (kterms < 1.0) kterms = 1.0;
+    if (kterms > 1e6) kterms = 1e6;
+    t.probeA = q->d_fe_probeA; t.probeB = q->d_fe_probeB; t.probeL = q->d_fe_probeL; t.probeE = q->d_fe_probeE;
+    t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V;
+    t.ntiles = ntiles; t.K = (unsigned)kterms; t.c_end = c_end;
+    t.rho = (float)rho; t.lamHh = (float)pow(lam, (double)q->fe_Hh); t.inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
+    t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
+    LAUNCH(K_FE_TILES, pmr_launch_fe_tiles(q->stream, &t));
+
+    if (ny) {
+        pmr_fe_fix_params f;
+        memset(&f, 0, sizeof(f));
+        f.xr = q->d_xr + q->xr_fill; f.V = q->d_fe_V; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
+        f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
+        f.Kgain = q->fe_Kgain;
+        LAUNCH(K_FE_FIX, pmr_launch_fe_dcfix(q->stream, &f));
+    }
+    LAUNCH(K_FE_HIST, pmr_launch_fe_hist(q->stream, q->d_fe_hist[cur], d_iq, n_in, q->d_fe_hist[nxt],
+                                         (unsigned)q->fe_hcap));
+    q->fe_sel = nxt;
+    q->arb_phase = new_phase;
+    *ny_out = ny;
+    return PMR_OK;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 
 int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
@@ -460,7 +646,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
     if ((size_t)q->xr_fill + ny_plan > q->xr_cap) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
 
     unsigned ny = 0;
-    if ((rc = frontend_staged(q, d_iq, n_in, &ny))) return rc;
+    if ((rc = q->fe_on ? frontend_fused(q, d_iq, n_in, &ny) : frontend_staged(q, d_iq, n_in, &ny))) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
     q->n_raw += n_in;
     q->last_ny = ny;

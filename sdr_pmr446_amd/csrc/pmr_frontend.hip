@@ -1,0 +1,361 @@
+// pmr_frontend.hip -- FUSED front end for gfx950: dc-block -> half-band cascade -> arbitrary resampler
+// (reference src/sdr_pmr446.c:795-796) in ONE pass over the raw cf32 block.
+//
+// HBM traffic: every raw sample is read once (8 B), plus a tile halo that is normally L2-resident;
+// only the resampled stream (8*rate B per input sample) is written.  Everything else lives in LDS.
+//
+// Tiling.  Workgroup c owns decimated samples [c*TQ, (c+1)*TQ) and computes them from raw samples
+// [c*T_own - Hh, (c+1)*T_own) of the "raw_rel" axis (origin = first sample of the first new decimation
+// group, i.e. `pend` samples before the new block; negative block indices come from the raw history the
+// chain keeps).  The tile holds N0 = 16*NT samples; Hh >= sum of all filter histories is recomputed.
+//
+// DC blocker without a serial dependency.  v[n] = x[n] + lambda v[n-1] is a linear scan; inside the tile it
+// runs from ZERO state (thread-serial over 16 samples, wave shuffle scan, cross-wave Horner).  The missing
+// carry-in V_c = v[tile start - 1] only adds  alpha*V_c*lambda^r  to yb, an exponential, and exponentials
+// are eigenfunctions of every later (linear) stage.  So the tile also records two probes of its local scan,
+// a tiny kernel (k_fe_tiles) turns the probes of all tiles into the V_c, and k_fe_dcfix subtracts
+// V_c * K * mu^q' * GA[idx] from the resampled samples, where K, mu, GA are the closed-form gains of the
+// cascade for that exponential (tests/chain_model.py documents the sums; the identity is exact in exact
+// arithmetic and was checked to 1e-15 in float64).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmr_kernels.h"
+
+typedef float2 cf;
+static __device__ __forceinline__ cf cfm(float r, float i) { cf v; v.x = r; v.y = i; return v; }
+
+// LDS layout L(G): element e lives at e + e/G (one 8-byte pad per G elements) so that threads whose chunks
+// are G elements apart hit distinct banks with ds_read_b64 / ds_write_b64 (stride 2G+2 dwords, gcd with 64 = 2).
+template <int G> static __device__ __forceinline__ int lidx(int e) { return e + e / G; }
+static __device__ __forceinline__ int lidx_rt(int e, int g_shift) { return e + (e >> g_shift); }
+
+// ---------------------------------------------------------------------------------------------
+// one half-band stage out of LDS, P outputs per thread, 2*MM branch taps   
+//   z1[o] = z0[2o+1-2m] + sum_j h1[j] * z0[2o - 2(2m-1-j)]
+// reads layout L(2P), writes layout L(max(P,2)) in place (two barriers).  Every LDS address is
+// thread_base + compile-time constant (floor division keeps that true left of the tile, where the
+// reads land in the zero pad in front of the buffer and only feed outputs inside the halo).
+// ---------------------------------------------------------------------------------------------
+#define FE_PAD 64      /* elements in front of the tile buffer; >= (4*10-2) * (1 + 1/2) */
+
+static constexpr int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+template <int G> static constexpr int loff(int e) { return e + fdiv(e, G); }   // layout offset of a constant index
+
+template <int P>
+static __device__ __forceinline__ void hb_store(cf *buf, int tid, int n_threads, const cf (&y)[P])
+{
+    __syncthreads();
+    if (tid < n_threads) {
+        if constexpr (P >= 2) {
+            cf *o = buf + tid * (P + 1);               // L(P): element tid*P + p at tid*(P+1) + p
+#pragma unroll
+            for (int p = 0; p < P; p++) o[p] = y[p];
+        } else {
+            buf[tid + (tid >> 1)] = y[0];              // L(2)
+        }
+    }
+    __syncthreads();
+}
+
+template <int P, int MM>
+static __device__ __forceinline__ void hb_stage(cf *buf, int tid, int n_threads, const float *__restrict__ h1,
+                                                float scale)
+{
+    constexpr int NE = P + 2 * MM - 1;             // even-offset window elements
+    constexpr int G = 2 * P;
+    cf y[P];
+    if (tid < n_threads) {
+        const cf *w = buf + tid * (G + 1);         // thread chunk base: element 2*tid*P
+        cf we[NE], wd[P];
+#pragma unroll
+        for (int i = 0; i < NE; i++) we[i] = w[loff<G>(2 * i - (4 * MM - 2))];
+#pragma unroll
+        for (int p = 0; p < P; p++) wd[p] = w[loff<G>(2 * p + 1 - 2 * MM)];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * MM; j++) {
+                const float h = h1[j];
+                ar = fmaf(h, we[p + j].x, ar);
+                ai = fmaf(h, we[p + j].y, ai);
+            }
+            y[p] = cfm((wd[p].x + ar) * scale, (wd[p].y + ai) * scale);
+        }
+    }
+    hb_store<P>(buf, tid, n_threads, y);
+}
+
+// fallback for other half-band lengths: taps looped, window read straight from LDS
+template <int P>
+static __device__ void hb_stage_generic(cf *buf, int tid, int n_threads, int mm, const float *__restrict__ h1,
+                                        float scale)
+{
+    constexpr int G = 2 * P;
+    cf y[P];
+    if (tid < n_threads) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const int o = tid * P + p;
+            float ar = 0.f, ai = 0.f;
+            for (int j = 0; j < 2 * mm; j++) {
+                int e = 2 * o - 2 * (2 * mm - 1 - j);
+                e = e < 0 ? 0 : e;
+                const cf s = buf[lidx<G>(e)];
+                ar = fmaf(h1[j], s.x, ar);
+                ai = fmaf(h1[j], s.y, ai);
+            }
+            int e = 2 * o + 1 - 2 * mm;
+            e = e < 0 ? 0 : e;
+            const cf d = buf[lidx<G>(e)];
+            y[p] = cfm((d.x + ar) * scale, (d.y + ai) * scale);
+        }
+    }
+    hb_store<P>(buf, tid, n_threads, y);
+}
+
+template <int P>
+static __device__ __forceinline__ void hb_dispatch(cf *buf, int tid, int n_threads, int mm,
+                                                   const float *__restrict__ h1, float scale)
+{
+    // register-window variants for the (P, m) pairs the As = 60 dB cascade produces (m = 3,..,3,5,10 in
+    // execution order: long filters only ever meet small P, except in 1- and 2-stage cascades)
+    if (mm == 3)                 hb_stage<P, 3>(buf, tid, n_threads, h1, scale);
+    else if (mm == 5)            hb_stage<P, 5>(buf, tid, n_threads, h1, scale);
+    else if (mm == 10 && P <= 4) hb_stage<(P <= 4 ? P : 1), 10>(buf, tid, n_threads, h1, scale);
+    else                         hb_stage_generic<P>(buf, tid, n_threads, mm, h1, scale);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int N0 = NT * 16;
+    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;        // [FE_PAD zero pad | N0 + N0/16 elements | scan scratch]
+    cf *wagg = buf + (N0 + N0 / 16);                        // [NT/64] wave aggregates of the dc scan
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x;
+    const long b0 = (long)c * p.T_own - p.Hh - p.pend;      // block-relative index of tile sample 0
+
+    // ---- phase A: raw samples -> LDS (layout L(16)); history for b < 0, zeros beyond the block ----
+    if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
+    {
+        const cf *__restrict__ x = (const cf *)p.x;
+        const cf *__restrict__ hist = (const cf *)p.hist;
+#pragma unroll 4
+        for (int i = tid; i < N0; i += NT) {
+            const long b = b0 + i;
+            cf v = cfm(0.f, 0.f);
+            if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) v = hist[hi]; }
+            else if (b < (long)p.n_in) v = x[b];
+            buf[lidx<16>(i)] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: dc blocker (:795) from zero state, in place ----
+    {
+        cf xs[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) xs[j] = buf[17 * tid + j];
+        const float a1 = p.dc_a1;
+        float vr = 0.f, vi = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            vr = __fsub_rn(xs[j].x, __fmul_rn(a1, vr));
+            vi = __fsub_rn(xs[j].y, __fmul_rn(a1, vi));
+        }
+        // inclusive decayed scan across the wave: inc_l = sum_{s<=l} lambda^(16 (l-s)) agg_s
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int d = 1 << j;
+            const float tr = __shfl_up(vr, d), ti = __shfl_up(vi, d);
+            if (lane >= d) { vr = fmaf(p.lam_pow16[j], tr, vr); vi = fmaf(p.lam_pow16[j], ti, vi); }
+        }
+        if (lane == 63) wagg[wave] = cfm(vr, vi);
+        float exr = __shfl_up(vr, 1), exi = __shfl_up(vi, 1);
+        if (lane == 0) { exr = 0.f; exi = 0.f; }
+        __syncthreads();
+        float cwr = 0.f, cwi = 0.f;                          // v (local) at the end of the previous wave
+        for (int w = 0; w < wave; w++) {
+            const cf a = wagg[w];
+            cwr = fmaf(p.lam_wave, cwr, a.x);
+            cwi = fmaf(p.lam_wave, cwi, a.y);
+        }
+        const float lp = p.lam_lane_pow[lane];               // lambda^(16 lane)
+        float v1r = fmaf(lp, cwr, exr), v1i = fmaf(lp, cwi, exi);
+        // stray probes (block start - 1 in tile 0, block end in the last tile) sit at arbitrary offsets
+        const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
+        const int pE = (c == p.c_end) ? p.off_end : -1;
+        const bool stray = (pL >> 4) == tid || (pE >> 4) == tid;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const float v0r = __fsub_rn(xs[j].x, __fmul_rn(a1, v1r));
+            const float v0i = __fsub_rn(xs[j].y, __fmul_rn(a1, v1i));
+            buf[17 * tid + j] = cfm(__fsub_rn(v0r, v1r), __fsub_rn(v0i, v1i));
+            v1r = v0r; v1i = v0i;
+            if (stray) {
+                if (16 * tid + j == pL) ((cf *)p.probeL)[0] = cfm(v0r, v0i);
+                if (16 * tid + j == pE) ((cf *)p.probeE)[0] = cfm(v0r, v0i);
+            }
+        }
+        if (tid == (p.Hh >> 4) - 1) ((cf *)p.probeA)[c] = cfm(v1r, v1i);   // local v at tile offset Hh-1
+        if (tid == NT - 1) ((cf *)p.probeB)[c] = cfm(v1r, v1i);             // local v at tile offset N0-1
+    }
+    __syncthreads();
+
+    // ---- phase C: half-band cascade, in place (stage e halves the sample count) ----
+    int g_shift = 4;                                         // layout of the current signal: L(1 << g_shift)
+    {
+        const float *__restrict__ taps = p.hb_taps;
+        int n_out = N0 >> 1;
+        for (int e = 0; e < p.h; e++) {
+            const int mm = p.m[e];
+            const float *h1 = taps + p.tap_off[e];
+            const float scale = (e == p.h - 1) ? p.zeta : 1.0f;
+            const int pp = n_out >= NT ? n_out / NT : 1;     // outputs per thread: 8, 4, 2, 1, 1, ...
+            const int n_threads = n_out / pp;
+            if (pp == 8)      hb_dispatch<8>(buf, tid, n_threads, mm, h1, scale);
+            else if (pp == 4) hb_dispatch<4>(buf, tid, n_threads, mm, h1, scale);
+            else if (pp == 2) hb_dispatch<2>(buf, tid, n_threads, mm, h1, scale);
+            else              hb_dispatch<1>(buf, tid, n_threads, mm, h1, scale);
+            const int gout_shift = pp == 8 ? 3 : (pp == 4 ? 2 : 1);   // output layout L(max(pp, 2))
+            g_shift = gout_shift;
+            n_out >>= 1;
+        }
+    }
+
+    // ---- phase D: arbitrary resampler (24-bit phase) for the outputs whose input sample is owned here ----
+    {
+        const unsigned long long qa = (unsigned long long)c * p.TQ;
+        unsigned long long qb = qa + p.TQ;
+        if (qb > p.Q) qb = p.Q;
+        if (qa < qb) {
+            const unsigned long long sa = qa << 24, sb = qb << 24;
+            const unsigned long long ja = sa <= p.phi0 ? 0ull : (sa - p.phi0 + p.step - 1) / p.step;
+            unsigned long long jb = sb <= p.phi0 ? 0ull : (sb - p.phi0 + p.step - 1) / p.step;
+            if (jb > p.ny) jb = p.ny;
+            const float *__restrict__ bank = p.arb_bank;
+            cf *__restrict__ out = (cf *)p.out;
+            for (unsigned long long j = ja + tid; j < jb; j += NT) {
+                const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
+                const int ql = (int)((ph >> 24) - qa) + p.HhQ;          // tile-local decimated index
+                const unsigned idx = (unsigned)(ph & 0xffffffu) >> 16;
+                const float *b = bank + idx * 14u;
+                float yr = 0.f, yi = 0.f;
+#pragma unroll
+                for (int k = 0; k < 14; k++) {
+                    const cf s = buf[lidx_rt(ql - 13 + k, g_shift)];
+                    yr = fmaf(b[k], s.x, yr);
+                    yi = fmaf(b[k], s.y, yi);
+                }
+                out[j] = cfm(yr, yi);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile carries from the probes.  W_c = v just before tile c's OWN range, V_c = v just before its halo:
+//   W_{c+1} = rho W_c + (probeB_c - rho probeA_c),  rho = lambda^T_own;   V_c = (W_c - probeA_c) lambda^-Hh
+// rho^k vanishes after K terms, so every tile sums its K predecessors independently (no serial chain).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fe_tiles(pmr_fe_tiles_params p)
+{
+    const unsigned c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= p.ntiles) return;
+    const cf *pa = (const cf *)p.probeA, *pb = (const cf *)p.probeB;
+    const cf vs = *(const cf *)p.v_in, pl = *(const cf *)p.probeL;
+    const float V0r = (vs.x - pl.x) * p.inv_lamL, V0i = (vs.y - pl.y) * p.inv_lamL;
+    const cf a0 = pa[0];
+    const float W0r = fmaf(p.lamHh, V0r, a0.x), W0i = fmaf(p.lamHh, V0i, a0.y);
+    float ar = 0.f, ai = 0.f, pw = 1.f;
+    const unsigned kmax = c < p.K ? c : p.K;
+    for (unsigned k = 1; k <= kmax; k++) {
+        const cf A = pa[c - k], B = pb[c - k];
+        ar = fmaf(pw, fmaf(-p.rho, A.x, B.x), ar);
+        ai = fmaf(pw, fmaf(-p.rho, A.y, B.y), ai);
+        pw *= p.rho;
+    }
+    if (c <= p.K) { ar = fmaf(pw, W0r, ar); ai = fmaf(pw, W0i, ai); }
+    const cf Ac = pa[c];
+    const float Vr = (ar - Ac.x) * p.inv_lamHh, Vi = (ai - Ac.y) * p.inv_lamHh;
+    ((cf *)p.V)[c] = cfm(Vr, Vi);
+    if (c == p.c_end) {
+        const cf pe = *(const cf *)p.probeE;
+        *(cf *)p.v_out = cfm(fmaf(p.lamEnd, Vr, pe.x), fmaf(p.lamEnd, Vi, pe.y));
+    }
+}
+
+// resampled-domain dc correction: xr[j] -= V_c * K * mu^q' * GA[idx_j]
+__global__ __launch_bounds__(256) void k_fe_dcfix(pmr_fe_fix_params p)
+{
+    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= p.ny) return;
+    const unsigned long long ph = (unsigned long long)p.phi0 + (unsigned long long)j * p.step;
+    const unsigned q = (unsigned)(ph >> 24);
+    const unsigned idx = (unsigned)(ph & 0xffffffu) >> 16;
+    const unsigned c = q / p.TQ;
+    const unsigned ql = q - c * p.TQ + p.HhQ;
+    const float g = p.Kgain * p.GA[idx] * (p.T1[ql >> 5] * p.T2[ql & 31]);
+    const cf V = ((const cf *)p.V)[c];
+    cf *o = (cf *)p.xr + j;
+    cf v = *o;
+    v.x = fmaf(-V.x, g, v.x);
+    v.y = fmaf(-V.y, g, v.y);
+    *o = v;
+}
+
+// raw history for the next call: last hcap samples of (old history || block)
+__global__ __launch_bounds__(256) void k_fe_hist(const cf *__restrict__ old_hist, const cf *__restrict__ x,
+                                                 unsigned n_in, cf *__restrict__ new_hist, unsigned hcap)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= hcap) return;
+    const long s = (long)i + (long)n_in - (long)hcap;        // block-relative index
+    new_hist[i] = s < 0 ? old_hist[(long)i + n_in] : x[s];
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt)
+{
+    if (!ntiles) return 0;
+    const size_t n0 = (size_t)nt * 16;
+    const size_t lds = (64 + n0 + n0 / 16 + 32) * sizeof(cf);   /* FE_PAD + tile + scan scratch */
+    static bool attr[2] = { false, false };
+    if (nt == 256) {
+        if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_frontend<256>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
+        hipLaunchKernelGGL(k_frontend<256>, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p);
+    } else if (nt == 1024) {
+        if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_frontend<1024>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
+        hipLaunchKernelGGL(k_frontend<1024>, dim3(ntiles), dim3(1024), lds, (hipStream_t)s, *p);
+    } else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_fe_tiles(pmr_stream_t s, const pmr_fe_tiles_params *p)
+{
+    if (!p->ntiles) return 0;
+    hipLaunchKernelGGL(k_fe_tiles, dim3((p->ntiles + 255) / 256), dim3(256), 0, (hipStream_t)s, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_fe_dcfix(pmr_stream_t s, const pmr_fe_fix_params *p)
+{
+    if (!p->ny) return 0;
+    hipLaunchKernelGGL(k_fe_dcfix, dim3((p->ny + 255) / 256), dim3(256), 0, (hipStream_t)s, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_fe_hist(pmr_stream_t s, const void *old_hist, const void *x, unsigned n_in,
+                                  void *new_hist, unsigned hcap)
+{
+    hipLaunchKernelGGL(k_fe_hist, dim3((hcap + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)old_hist,
+                       (const cf *)x, n_in, (cf *)new_hist, hcap);
+    return (int)hipGetLastError();
+}

@@ -70,6 +70,47 @@ int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, unsigned M, 
                       unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                       float *out_tm, int16_t *pcm, float *audio, unsigned stride);
 
+/* ---- fused front end (pmr_frontend.hip): dc-block + half-band cascade + arbitrary resampler in one pass ---- */
+#define PMR_FE_MAX_STAGES 16
+typedef struct {
+    const void *x;              /* new block [n_in] cf32                                             */
+    const void *hist;           /* raw history: the hcap samples before the block                    */
+    void *out;                  /* resampled outputs of this block [ny] cf32                         */
+    void *probeA, *probeB;      /* [ntiles] local dc state at tile offsets Hh-1 and N0-1             */
+    void *probeL, *probeE;      /* local dc state at (block start - 1) in tile 0, (block end) in tile c_end */
+    const float *hb_taps;       /* branch taps of all stages, execution order, oldest-first          */
+    const float *arb_bank;      /* [256][14]                                                         */
+    const float *lam_lane_pow;  /* [64] lambda^(16 l)                                                */
+    unsigned n_in, ny, Q;       /* raw samples, resampled outputs, decimated samples of this block   */
+    uint32_t phi0, step;        /* resamp_crcf phase before the block's first decimated sample, step */
+    int h, T_own, Hh, HhQ, TQ;  /* stages; owned raw samples per tile, halo (raw / decimated), owned decimated */
+    int pend, hcap, c_end, off_end;
+    int m[PMR_FE_MAX_STAGES], tap_off[PMR_FE_MAX_STAGES];
+    float dc_a1, zeta, lam_wave;
+    float lam_pow16[6];         /* lambda^(16 * 2^j)                                                 */
+} pmr_fe_params;
+
+typedef struct {
+    const void *probeA, *probeB, *probeL, *probeE, *v_in;
+    void *v_out, *V;
+    unsigned ntiles, K, c_end;
+    float rho, lamHh, inv_lamHh, inv_lamL, lamEnd;
+} pmr_fe_tiles_params;
+
+typedef struct {
+    void *xr; const void *V;
+    const float *GA, *T1, *T2;
+    unsigned ny, TQ, HhQ;
+    uint32_t phi0, step;
+    float Kgain;
+} pmr_fe_fix_params;
+
+int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt);
+int pmr_launch_fe_tiles(pmr_stream_t s, const pmr_fe_tiles_params *p);
+int pmr_launch_fe_dcfix(pmr_stream_t s, const pmr_fe_fix_params *p);
+int pmr_launch_fe_hist(pmr_stream_t s, const void *old_hist, const void *x, unsigned n_in, void *new_hist,
+                       unsigned hcap);
+
 #ifdef __cplusplus
 }
 #endif
