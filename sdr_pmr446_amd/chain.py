@@ -55,6 +55,15 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # Two HIP runtimes can end up in one process: this library links the system libamdhip64.so.7, a PyTorch
+    # wheel bundles its own (different SONAME).  They coexist as long as PyTorch's is initialised FIRST, so when
+    # torch is installed let it initialise before libpmr446_hip.so pulls in the system runtime.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     path = _build.LIB
     if build_if_missing:
         path = _build.build()

@@ -27,10 +27,11 @@
 typedef struct { float re, im; } cfl;
 
 enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
-       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_COUNT };
+       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_CHANNELIZE_SMALL, K_COUNT };
 static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
                                         "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
-                                        "k_fir_tm<lp>", "k_frontend", "k_fe_tiles", "k_fe_dcfix", "k_fe_hist" };
+                                        "k_fir_tm<lp>", "k_frontend", "k_fe_tiles", "k_fe_dcfix", "k_fe_hist",
+                                        "k_channelize_small" };
 
 typedef struct { hipEvent_t a, b; int slot; } prof_pending;
 
@@ -61,6 +62,7 @@ struct pmr_chain_s {
     size_t rssi_part_cap;
 
     /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
+    int chan_small;                  /* small-M channelizer (pmr_channelize_small.hip) selected       */
     int fe_on, fe_nt;                /* fused path selected; threads per tile workgroup (256 / 1024)  */
     int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
     int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
@@ -115,14 +117,15 @@ static int dev_upload(pmr_chain q, float **p, const float *src, size_t n)
     return PMR_OK;
 }
 
-/* zero-padded, oldest-first taps for k_fir_tm: P[j + RP-1] = h[n-1-j] */
+/* taps for k_fir_tm: h zero-padded by RP-1 on both sides, natural order: Q[(RP-1) + d] = h[d].
+ * Step e (input sample t0-J-(n-1)+e) meets accumulator i (output t0-J+i) with h[(n-1)+i-e] = Q[(n+RP-2-e)+i]. */
 static int upload_padded_taps(pmr_chain q, float **p, const float *h, unsigned n)
 {
     const unsigned rp = PMR_AUDIO_R + PMR_AUDIO_J;
     size_t len = n + 2 * (rp - 1);
     float *tmp = (float *)calloc(len, sizeof(float));
     if (!tmp) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
-    for (unsigned j = 0; j < n; j++) tmp[j + rp - 1] = h[n - 1 - j];
+    for (unsigned j = 0; j < n; j++) tmp[j + rp - 1] = h[j];
     int rc = dev_upload(q, p, tmp, len);
     free(tmp);
     return rc;
@@ -393,6 +396,10 @@ static int chain_init(pmr_chain q)
     if ((rc = dev_alloc(q, (void **)&q->d_rssi_part, q->rssi_part_cap * sizeof(float)))) return rc;
 
     if ((rc = fe_init(q))) return rc;
+    {
+        const char *env = getenv("PMR_CHANNELIZER");
+        q->chan_small = !(env && !strcmp(env, "generic")) && pmr_channelize_small_supported(M, p, d->nco_period);
+    }
 
     q->n_raw = 0; q->arb_phase = 0; q->xr_fill = p * M; q->xr_base = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "init sync");
@@ -591,6 +598,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     p.pend = (int)pend; p.hcap = q->fe_hcap; p.c_end = (int)c_end; p.off_end = off_end;
     memcpy(p.m, q->fe_m, sizeof(p.m)); memcpy(p.tap_off, q->fe_tap_off, sizeof(p.tap_off));
     p.dc_a1 = d->dc_a1; p.zeta = d->zeta; p.lam_wave = q->fe_lam_wave;
+    { const char *ab = getenv("PMR_FE_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     LAUNCH(K_FE, pmr_launch_frontend(q->stream, &p, ntiles, q->fe_nt));
 
@@ -664,11 +672,18 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
     if (ns) {
         float *fm_new = q->d_fm + (size_t)FM_HIST_FRAMES * M;
         unsigned ntiles = 0;
-        LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, q->d_xr, ns, M, p, q->d_pfb_taps_t, q->d_fft_tw,
-                                                   q->d_nco_cs, d->nco_period,
-                                                   (unsigned)(q->xr_base % d->nco_period), d->fm_ref, fm_new,
-                                                   d_chan_out, pcm_stride, d_rssi_db ? q->d_rssi_part : NULL,
-                                                   &ntiles));
+        if (q->chan_small)
+            LAUNCH(K_CHANNELIZE_SMALL,
+                   pmr_launch_channelize_small(q->stream, q->d_xr, total, ns, M, p, q->d_pfb_taps_t, q->d_fft_tw,
+                                               q->d_nco_cs, d->nco_period, (unsigned)(q->xr_base % d->nco_period),
+                                               d->fm_ref, fm_new, d_chan_out, pcm_stride,
+                                               d_rssi_db ? q->d_rssi_part : NULL, &ntiles));
+        else
+            LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, q->d_xr, ns, M, p, q->d_pfb_taps_t, q->d_fft_tw,
+                                                       q->d_nco_cs, d->nco_period,
+                                                       (unsigned)(q->xr_base % d->nco_period), d->fm_ref, fm_new,
+                                                       d_chan_out, pcm_stride, d_rssi_db ? q->d_rssi_part : NULL,
+                                                       &ntiles));
         if (q->dbg_on)
             HIPCHK(hipMemcpyAsync(q->d_dbg_fm, fm_new, (size_t)ns * M * sizeof(float), hipMemcpyDeviceToDevice,
                                   q->stream), "debug copy");

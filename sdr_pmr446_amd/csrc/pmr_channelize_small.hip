@@ -1,0 +1,251 @@
+// pmr_channelize_small.hip -- channelizer + discriminator for SMALL M (M = 16, the PMR446 case) on gfx950.
+//
+// reference: NCO shift src/sdr_pmr446.c:808-812, firpfbch_crcf_analyzer_execute :814, transpose :819-821,
+// freqdem :881.  Sums: tests/chain_model.py  (X_c[t] = sum_k taps_t[k][c] * xm[(t+k)*M + c], y = FFT(X)).
+//
+// Mapping ("commutator and its small M-point FFT fused per thread"): one thread owns TWO consecutive frames
+// with all M polyphase branches in registers (2*M complex accumulators), so
+//   * the NCO-mixed samples are staged once per workgroup in LDS (16-byte coalesced HBM loads, 144-byte
+//     padded frame rows => conflict-free ds_read_b128),
+//   * every tap is a wave-uniform scalar (s_load), each LDS sample feeds two frames,
+//   * the M-point FFT runs in registers (radix-2 DIT, same butterfly order and twiddles as the oracle),
+//   * the discriminator needs the previous frame: frame B uses frame A of the same thread, frame A uses
+//     the neighbour thread's frame B through one LDS exchange.  Local frame 0 of a tile is the frame before
+//     its range, recomputed so tiles are independent.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmr_kernels.h"
+
+typedef float2 cf;
+static __device__ __forceinline__ cf cfm(float r, float i) { cf v; v.x = r; v.y = i; return v; }
+
+template <int M> struct log2c { static constexpr int v = 1 + log2c<M / 2>::v; };
+template <> struct log2c<1> { static constexpr int v = 0; };
+
+static constexpr unsigned brev_c(unsigned v, int bits)
+{
+    unsigned r = 0;
+    for (int b = 0; b < bits; b++) if (v & (1u << b)) r |= 1u << (bits - 1 - b);
+    return r;
+}
+
+// in-register forward DFT, radix-2 decimation in time; x must already be in bit-reversed order
+template <int M>
+static __device__ __forceinline__ void fft_dit(cf (&x)[M], const cf *__restrict__ tw /*[M/2], wave-uniform*/)
+{
+#pragma unroll
+    for (int len = 2; len <= M; len <<= 1) {
+        const int half = len >> 1, tstep = M / len;
+#pragma unroll
+        for (int base = 0; base < M; base += len) {
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                const cf w = tw[k * tstep];
+                const cf a = x[base + k], b = x[base + k + half];
+                const float tr = fmaf(b.x, w.x, -(b.y * w.y));
+                const float ti = fmaf(b.x, w.y, b.y * w.x);
+                x[base + k] = cfm(a.x + tr, a.y + ti);
+                x[base + k + half] = cfm(a.x - tr, a.y - ti);
+            }
+        }
+    }
+}
+
+#define CS_NT 256
+#define CS_FPT 2                          /* frames per thread */
+
+template <int M>
+__global__ __launch_bounds__(CS_NT) void k_channelize_small(const cf *__restrict__ xr, unsigned n_valid,
+                                                            unsigned ns, unsigned p,
+                                                            const float *__restrict__ taps_t,
+                                                            const cf *__restrict__ fft_tw,
+                                                            const cf *__restrict__ nco_cs, unsigned nco_mask,
+                                                            unsigned nco_idx0, float fm_ref,
+                                                            float *__restrict__ fm_out, cf *__restrict__ chan_out,
+                                                            unsigned chan_stride, float *__restrict__ rssi_part)
+{
+    constexpr int L2M = log2c<M>::v;
+    constexpr int FS = M + 2;                             // padded frame row in LDS (cf elements): M*8 + 16 bytes
+    constexpr int NFT = CS_NT * CS_FPT;                   // frames computed per tile (local frame 0 = frame t0-1)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf *xs = reinterpret_cast<cf *>(smem);                // [(NFT + p - 1)][FS]
+
+    const int tid = threadIdx.x;
+    const long t0 = (long)blockIdx.x * (NFT - 1);         // first NEW frame of this tile
+    // local frame l <-> frame t0-1+l; it needs buffer frames (t0 + l) .. (t0 + l + p - 1)   [history = p frames]
+    const unsigned nfl = NFT + p - 1;                     // buffer frames staged
+    const size_t s_base = (size_t)t0 * M;                 // first staged sample in xr
+
+    // ---- stage: HBM -> NCO mix -> LDS (two samples per lane per load) ----
+    {
+        const unsigned units = nfl * (M / 2);
+        // NCO phase index of a lane's sample pair is the same for every iteration: 2*CS_NT is a multiple of the period
+        const unsigned i0 = (nco_idx0 + (unsigned)s_base + 2u * tid) & nco_mask;
+        const cf c0 = nco_cs[i0], c1 = nco_cs[(i0 + 1) & nco_mask];
+        for (unsigned u = tid; u < units; u += CS_NT) {
+            const size_t s = s_base + 2 * (size_t)u;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s + 1 < n_valid) v = *reinterpret_cast<const float4 *>(xr + s);
+            else if (s < n_valid) { const cf a = xr[s]; v.x = a.x; v.y = a.y; }
+            float4 o;
+            o.x = fmaf(v.x, c0.x, v.y * c0.y);            // x * conj(e^{j theta})
+            o.y = fmaf(v.y, c0.x, -(v.x * c0.y));
+            o.z = fmaf(v.z, c1.x, v.w * c1.y);
+            o.w = fmaf(v.w, c1.x, -(v.z * c1.y));
+            const unsigned f = (2 * u) >> L2M, c = (2 * u) & (M - 1);
+            *reinterpret_cast<float4 *>(xs + f * FS + c) = o;
+        }
+    }
+    __syncthreads();
+
+    // ---- polyphase filter bank: two frames per thread, taps wave-uniform ----
+    cf XA[M], XB[M];
+#pragma unroll
+    for (int c = 0; c < M; c++) { XA[c] = cfm(0.f, 0.f); XB[c] = cfm(0.f, 0.f); }
+    {
+        const cf *row = xs + (size_t)(CS_FPT * tid) * FS;
+        for (unsigned j = 0; j <= p; j++) {               // buffer frame (local 2*tid + j) feeds A with tap j, B with tap j-1
+            cf s[M];
+#pragma unroll
+            for (int c = 0; c < M; c += 2) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + j * FS + c);
+                s[c] = cfm(v.x, v.y); s[c + 1] = cfm(v.z, v.w);
+            }
+            if (j < p) {
+                const float *ta = taps_t + j * M;
+#pragma unroll
+                for (int c = 0; c < M; c++) {
+                    XA[c].x = fmaf(ta[c], s[c].x, XA[c].x);
+                    XA[c].y = fmaf(ta[c], s[c].y, XA[c].y);
+                }
+            }
+            if (j >= 1) {
+                const float *tb = taps_t + (j - 1) * M;
+#pragma unroll
+                for (int c = 0; c < M; c++) {
+                    XB[c].x = fmaf(tb[c], s[c].x, XB[c].x);
+                    XB[c].y = fmaf(tb[c], s[c].y, XB[c].y);
+                }
+            }
+        }
+    }
+
+    // ---- M-point FFT in registers (bit-reversed load order is a compile-time renaming) ----
+    cf YA[M], YB[M];
+#pragma unroll
+    for (int c = 0; c < M; c++) { YA[brev_c(c, L2M)] = XA[c]; YB[brev_c(c, L2M)] = XB[c]; }
+    fft_dit<M>(YA, fft_tw);
+    fft_dit<M>(YB, fft_tw);
+
+    // ---- previous frame for frame A: neighbour thread's frame B, through LDS ----
+    __syncthreads();                                      // everyone is done reading the staged samples
+    {
+        cf *ex = xs + (size_t)tid * FS;
+#pragma unroll
+        for (int c = 0; c < M; c += 2)
+            *reinterpret_cast<float4 *>(ex + c) = make_float4(YB[c].x, YB[c].y, YB[c + 1].x, YB[c + 1].y);
+    }
+    __syncthreads();
+    cf PV[M];
+    if (tid > 0) {
+        const cf *ex = xs + (size_t)(tid - 1) * FS;
+#pragma unroll
+        for (int c = 0; c < M; c += 2) {
+            const float4 v = *reinterpret_cast<const float4 *>(ex + c);
+            PV[c] = cfm(v.x, v.y); PV[c + 1] = cfm(v.z, v.w);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < M; c++) PV[c] = cfm(0.f, 0.f);   // unused: local frame 0 produces no output
+    }
+
+    // ---- discriminator (:881) + tap-offs ----
+    const long tA = t0 - 1 + CS_FPT * tid, tB = tA + 1;   // global frame numbers of this thread
+    const bool outA = tid > 0 && tA < (long)ns;
+    const bool outB = tB < (long)ns;
+    if (outA) {
+        float *o = fm_out + (size_t)tA * M;
+#pragma unroll
+        for (int k = 0; k < M; k += 4) {
+            float4 r;
+            float *rr = &r.x;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const cf pv = PV[k + i], cu = YA[k + i];
+                rr[i] = atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
+            }
+            *reinterpret_cast<float4 *>(o + k) = r;
+        }
+    }
+    if (outB) {
+        float *o = fm_out + (size_t)tB * M;
+#pragma unroll
+        for (int k = 0; k < M; k += 4) {
+            float4 r;
+            float *rr = &r.x;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const cf pv = YA[k + i], cu = YB[k + i];
+                rr[i] = atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
+            }
+            *reinterpret_cast<float4 *>(o + k) = r;
+        }
+    }
+    if (chan_out) {
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            if (outA) chan_out[(size_t)k * chan_stride + tA] = YA[k];
+            if (outB) chan_out[(size_t)k * chan_stride + tB] = YB[k];
+        }
+    }
+    if (rssi_part) {
+        // per-channel sum of |y| over the tile's new frames: wave butterfly, then one LDS pass
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(xs);       // [CS_NT/64][M]
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            float a = (outA ? hypotf(YA[k].x, YA[k].y) : 0.f) + (outB ? hypotf(YB[k].x, YB[k].y) : 0.f);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+            if (lane == 0) red[wave * M + k] = a;
+        }
+        __syncthreads();
+        if (tid < M) {
+            float a = 0.f;
+            for (int w = 0; w < CS_NT / 64; w++) a += red[w * M + tid];
+            rssi_part[(size_t)blockIdx.x * M + tid] = a;
+        }
+    }
+}
+
+extern "C" unsigned pmr_channelize_small_tiles(unsigned ns) { return (ns + CS_NT * CS_FPT - 2) / (CS_NT * CS_FPT - 1); }
+
+extern "C" int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned nco_period)
+{
+    return M == 16 && p >= 2 && p <= 64 && nco_period && (2u * CS_NT) % nco_period == 0;
+}
+
+extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const void *xr, unsigned n_valid, unsigned ns, unsigned M,
+                                           unsigned p, const float *taps_t, const float *fft_tw, const float *nco_cs,
+                                           unsigned nco_period, unsigned nco_idx0, float fm_ref, float *fm_out,
+                                           void *chan_out, unsigned chan_stride, float *rssi_part,
+                                           unsigned *ntiles_out)
+{
+    const unsigned ntiles = pmr_channelize_small_tiles(ns);
+    if (ntiles_out) *ntiles_out = ntiles;
+    if (!ns) return 0;
+    if (M != 16) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)(CS_NT * CS_FPT + p - 1) * (M + 2) * sizeof(cf);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_small<16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_channelize_small<16>, dim3(ntiles), dim3(CS_NT), lds, (hipStream_t)s, (const cf *)xr, n_valid,
+                       ns, p, taps_t, (const cf *)fft_tw, (const cf *)nco_cs, nco_period - 1, nco_idx0, fm_ref, fm_out,
+                       (cf *)chan_out, chan_stride, rssi_part);
+    return (int)hipGetLastError();
+}

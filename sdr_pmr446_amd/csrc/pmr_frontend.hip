@@ -142,22 +142,37 @@ __global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
 
     // ---- phase A: raw samples -> LDS (layout L(16)); history for b < 0, zeros beyond the block ----
     if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
-    {
+    if (!(p.ablate & 1)) {
         const cf *__restrict__ x = (const cf *)p.x;
         const cf *__restrict__ hist = (const cf *)p.hist;
+        // interior tile, 16-byte aligned: all loads of the thread are issued before the first LDS write
+        const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
+        if (fast) {
+            const float4 *__restrict__ src = reinterpret_cast<const float4 *>(x + b0);
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = src[tid + NT * i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                cf *d = buf + lidx<16>(2 * (tid + NT * i));       // the pair never straddles a 16-sample chunk
+                d[0] = cfm(v[i].x, v[i].y);
+                d[1] = cfm(v[i].z, v[i].w);
+            }
+        } else {
 #pragma unroll 4
-        for (int i = tid; i < N0; i += NT) {
-            const long b = b0 + i;
-            cf v = cfm(0.f, 0.f);
-            if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) v = hist[hi]; }
-            else if (b < (long)p.n_in) v = x[b];
-            buf[lidx<16>(i)] = v;
+            for (int i = tid; i < N0; i += NT) {
+                const long b = b0 + i;
+                cf v = cfm(0.f, 0.f);
+                if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) v = hist[hi]; }
+                else if (b < (long)p.n_in) v = x[b];
+                buf[lidx<16>(i)] = v;
+            }
         }
     }
     __syncthreads();
 
     // ---- phase B: dc blocker (:795) from zero state, in place ----
-    {
+    if (!(p.ablate & 2)) {
         cf xs[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) xs[j] = buf[17 * tid + j];
@@ -209,7 +224,7 @@ __global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
 
     // ---- phase C: half-band cascade, in place (stage e halves the sample count) ----
     int g_shift = 4;                                         // layout of the current signal: L(1 << g_shift)
-    {
+    if (!(p.ablate & 4)) {
         const float *__restrict__ taps = p.hb_taps;
         int n_out = N0 >> 1;
         for (int e = 0; e < p.h; e++) {
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
     }
 
     // ---- phase D: arbitrary resampler (24-bit phase) for the outputs whose input sample is owned here ----
-    {
+    if (!(p.ablate & 8)) {
         const unsigned long long qa = (unsigned long long)c * p.TQ;
         unsigned long long qb = qa + p.TQ;
         if (qb > p.Q) qb = p.Q;

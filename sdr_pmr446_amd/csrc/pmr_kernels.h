@@ -15,7 +15,7 @@ typedef void *pmr_stream_t;     /* hipStream_t */
 #define PMR_DC_TILE 4096u       /* raw samples per dc-block tile (256 threads x 16) */
 #define PMR_DC_SCAN_THREADS 1024u
 #define PMR_AUDIO_R 32u         /* outputs per thread in the time-major FIR */
-#define PMR_AUDIO_J 5u          /* IIR warm-up outputs (de-emphasis pole^J < 1e-9) */
+#define PMR_AUDIO_J 6u          /* IIR warm-up outputs (de-emphasis pole^J < 1e-10); R+J even (packed FMA) */
 
 /* constants of the dc blocker, filled by the host from pmr_design */
 typedef struct {
@@ -59,9 +59,19 @@ unsigned pmr_channelize_tiles(unsigned ns, unsigned M);
 int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntiles, unsigned M, unsigned ns,
                            float *rssi_db);
 
+/* small-M specialisation (pmr_channelize_small.hip): thread-per-frame-pair, FFT in registers.  n_valid = valid
+ * samples in xr (zeros are read beyond).  Same outputs as pmr_launch_channelize.                       */
+int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned nco_period);
+unsigned pmr_channelize_small_tiles(unsigned ns);
+int pmr_launch_channelize_small(pmr_stream_t s, const void *xr, unsigned n_valid, unsigned ns, unsigned M,
+                                unsigned p, const float *taps_t, const float *fft_tw, const float *nco_cs,
+                                unsigned nco_period, unsigned nco_idx0, float fm_ref, float *fm_out,
+                                void *chan_out, unsigned chan_stride, float *rssi_part, unsigned *ntiles_out);
+
 /* time-major real FIR with optional epilogue (:882-904).
  *  in        time-major, in[(t)*M + k], t = 0 first new frame (history at negative t)
- *  taps_pad  [ntaps + 2*(R+J-1)] zero-padded, oldest-first (reversed) taps
+ *  taps_pad  [ntaps + 2*(R+J-1)]: tap(e, i) = taps_pad[(ntaps + R+J - 2 - e) + i] is the weight of input step e
+ *            in accumulator i, i.e. h zero-padded by R+J-1 on both sides, in natural order
  *  gain      multiplies the FIR output (:890)
  *  iir       if non-zero: y = b0*v0 + b1*v1, v0 = u - a1*v1 (:898)
  *  out_tm    nullable time-major output (same indexing as `in`)
@@ -85,6 +95,7 @@ typedef struct {
     uint32_t phi0, step;        /* resamp_crcf phase before the block's first decimated sample, step */
     int h, T_own, Hh, HhQ, TQ;  /* stages; owned raw samples per tile, halo (raw / decimated), owned decimated */
     int pend, hcap, c_end, off_end;
+    int ablate;                 /* timing experiments only (PMR_FE_ABLATE): bit0 skip load, 1 dc, 2 cascade, 3 resampler */
     int m[PMR_FE_MAX_STAGES], tap_off[PMR_FE_MAX_STAGES];
     float dc_a1, zeta, lam_wave;
     float lam_pow16[6];         /* lambda^(16 * 2^j)                                                 */

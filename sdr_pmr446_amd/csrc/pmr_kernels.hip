@@ -272,9 +272,11 @@ __global__ void k_rssi_finish(const float *__restrict__ part, unsigned ntiles, u
 // lane <-> (channel k, time segment); y[t] = sum_d h[d] x[t-d], accumulated oldest sample first.
 // ------------------------------------------------------------------------------------------------
 #define RP (PMR_AUDIO_R + PMR_AUDIO_J)
+typedef float v2f __attribute__((ext_vector_type(2)));
+static_assert(RP % 2 == 0, "packed accumulators come in pairs");
 
 __global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, unsigned ns, unsigned M,
-                                                unsigned log2M, const float *__restrict__ taps_pad,
+                                                unsigned log2M, const float *__restrict__ taps_q,
                                                 unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                                                 float *__restrict__ out_tm, int16_t *__restrict__ pcm,
                                                 float *__restrict__ audio, unsigned stride)
@@ -283,22 +285,32 @@ __global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, un
     const unsigned k = gid & (M - 1), seg = gid >> log2M;
     const long t0 = (long)seg * PMR_AUDIO_R;
     if (t0 >= (long)ns) return;
-    float acc[RP];
+    // acc[i] <-> output t0 - J + i.  Step e brings input sample s = t0 - J - (ntaps-1) + e, which meets output i
+    // with tap h[(ntaps-1) + i - e]; taps_q is that sequence zero-padded and stored so that the RP taps of one
+    // step are ASCENDING in i: tap(e, i) = taps_q[(ntaps + RP - 2 - e) + i].  Two adjacent accumulators share
+    // one v_pk_fma_f32 (x broadcast, tap pair from scalar registers).
+    v2f acc[RP / 2];
 #pragma unroll
-    for (int i = 0; i < (int)RP; i++) acc[i] = 0.f;
-    // input sample index of step e: s = t0 - J - (ntaps-1) + e
+    for (int i = 0; i < RP / 2; i++) acc[i] = v2f{0.f, 0.f};
     const float *px = in + ((t0 - (long)PMR_AUDIO_J - (long)(ntaps - 1)) * (long)M + (long)k);
     const unsigned steps = ntaps + RP - 1;
+    const float *tq0 = taps_q + (ntaps + RP - 2);
+#pragma unroll 4
     for (unsigned e = 0; e < steps; e++) {
         const float x = px[(size_t)e * M];
-        const float *tp = taps_pad + e;               // wave-uniform -> scalar loads
+        const float *tp = tq0 - e;                    // wave-uniform -> scalar loads
+        const v2f xx = v2f{x, x};
 #pragma unroll
-        for (int i = 0; i < (int)RP; i++) acc[i] = fmaf(tp[RP - 1 - i], x, acc[i]);
+        for (int i = 0; i < RP / 2; i++) {
+            const v2f t = v2f{tp[2 * i], tp[2 * i + 1]};
+            acc[i] = __builtin_elementwise_fma(t, xx, acc[i]);
+        }
     }
     float v1 = 0.f;
 #pragma unroll
     for (int i = 0; i < (int)RP; i++) {
-        float u = __fmul_rn(acc[i], gain);
+        const float a = (i & 1) ? acc[i / 2].y : acc[i / 2].x;
+        float u = __fmul_rn(a, gain);
         float y = u;
         if (iir) {
             const float v0 = __fsub_rn(u, __fmul_rn(a1, v1));

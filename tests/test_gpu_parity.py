@@ -20,23 +20,23 @@ def _pair(fs, M, mb, **kw):
         chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb, **kw)
 
 
-def _compare(fs, M, x, splits, synth_ch=None, skip_frames=40, **kw):
+def _compare(fs, M, x, splits, synth_ch=None, skip_frames=40, tol=1e-5, pcm_tol=1, **kw):
     o, g = _pair(fs, M, max(max(splits), 1), **kw)
     ro, rg = run_blocks(o, x, splits, WANT), run_blocks(g, x, splits, WANT)
     assert rg["n_frames"] == ro["n_frames"]
     assert len(rg["resampled"]) == len(ro["resampled"])
-    assert rel_err(rg["resampled"], ro["resampled"]) < 1e-5           # resampler output (:796)
-    assert rel_err(rg["chan"], ro["chan"]) < 1e-5                     # channelizer tap-off (:814-821)
+    assert rel_err(rg["resampled"], ro["resampled"]) < tol            # resampler output (:796)
+    assert rel_err(rg["chan"], ro["chan"]) < tol                      # channelizer tap-off (:814-821)
     act = active_channels(M, synth_ch)
     ns = ro["n_frames"]
     assert np.abs(rg["audio"][act] - ro["audio"][act]).max() < 1e-4 if ns else True
     if ns > skip_frames:                                              # first frames: |chan| ~ 0, arg() ill-conditioned
-        assert np.abs(rg["fm"][act][:, skip_frames:] - ro["fm"][act][:, skip_frames:]).max() < 2e-6
+        assert np.abs(rg["fm"][act][:, skip_frames:] - ro["fm"][act][:, skip_frames:]).max() < 0.2 * tol
     settle = skip_frames + 377 + 103 + 101                            # ... and that error rings through the audio FIRs
     if ns > settle:
-        assert np.abs(rg["audio"][act][:, settle:] - ro["audio"][act][:, settle:]).max() < 5e-6
+        assert np.abs(rg["audio"][act][:, settle:] - ro["audio"][act][:, settle:]).max() < 0.5 * tol
     d = pcm_diff(rg["pcm"][act], ro["pcm"][act])
-    assert d.size == 0 or d.max() <= 1                                # +-1 LSB
+    assert d.size == 0 or d.max() <= pcm_tol                          # +-1 LSB
     for a, b, n in zip(rg["rssi"], ro["rssi"], [1] * len(ro["rssi"])):
         m = np.isfinite(b)
         assert np.allclose(a[m], b[m], atol=1e-3)                     # dB
@@ -86,9 +86,20 @@ def test_audio_options(opts):
 
 
 def test_dc_offset_is_blocked():
+    """A receiver-like DC spike (-40 dBFS): the dc-blocker state and the deferred dc carry must be right."""
+    fs, M = CFG2
+    x = synth.synth_iq(200000, fs, M, dev_hz=500.0, dc_offset=0.01 + 0.004j)
+    _compare(fs, M, x, [100000, 60000, 40000])
+
+
+def test_huge_dc_offset_is_bounded_by_the_reference_own_rounding():
+    """-12 dBFS of DC: liquid's float32 direct-form-II state sits at v ~ d/alpha ~ 540, so the REFERENCE arithmetic
+    itself carries ~ulp(540)/2 = 3e-5 of white rounding noise per sample (1e-5 after decimation).  The scan-based
+    GPU dc-blocker does not replicate that noise realisation; parity is bounded by it (and PCM by 2 LSB)."""
     fs, M = CFG2
     x = synth.synth_iq(200000, fs, M, dev_hz=500.0, dc_offset=0.25 + 0.1j)
-    _compare(fs, M, x, [100000, 100000])
+    ro, rg = _compare(fs, M, x, [100000, 100000], tol=1e-4, pcm_tol=2)
+    assert abs(np.mean(rg["resampled"][5000:])) < 1e-3                # and the offset really is gone
 
 
 def test_cfg3_256_channels():
@@ -152,9 +163,15 @@ def test_full_size_split_invariance_and_known_answer():
     p1 = pcm1[:, :ns1].cpu().numpy().astype(np.int32)
     act = active_channels(M)
     assert p1.shape == p2.shape and np.abs(p1[act] - p2[act]).max() <= 1
-    a = au1[:, 1000:ns1].cpu().numpy()
+    a = au1[:, 1000:ns1].cpu().numpy().astype(np.float64)
+    tt = np.arange(1000, ns1) / 12500.0
     for k in act:
         if synth.channel_kind(k) == "fm":
             fa = synth.audio_tone_hz(k)
-            expect = 4.0 * (2 * 500.0 / 12500.0) / np.sqrt(1 + (fa / 3183.1) ** 2)
-            assert abs(np.abs(a[k]).max() - expect) < 0.03 * expect + 0.01
+            amp = 2.0 * abs(np.mean(a[k] * np.exp(-2j * np.pi * fa * tt)))      # tone amplitude by correlation
+            # gain 4 * (2 dev / fs_ch) * |de-emphasis(fa)| (bilinear 50 us), high-pass flat at fa >= 400 Hz
+            w = 2 * np.pi * fa / 12500.0
+            b0, a1 = 0.507301437230636, 0.014602874461272194
+            de = abs(b0 * (1 + np.exp(-1j * w)) / (1 + a1 * np.exp(-1j * w)))
+            expect = 4.0 * (2 * 500.0 / 12500.0) * de
+            assert abs(amp - expect) < 0.03 * expect, (k, amp, expect)
