@@ -10,6 +10,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 C_SOURCES = ["pmr_chain.c", "pmr_design.c"]
 HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_channelize_small.hip"]
+EXTRA_HIP_FLAGS = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
 HEADERS = ["pmr_design.h", "pmr_kernels.h", os.path.join("..", "..", "include", "pmr_chain.h"),
            os.path.join("..", "data", "pmr446_taps.h")]
 
@@ -41,8 +42,10 @@ def build(force=False, verbose=False):
         objs.append(o)
     for f in HIP_SOURCES:
         o = os.path.join(CSRC, f[:-4] + ".o")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-parameter",
-               "-c", os.path.join(CSRC, f), "-o", o]
+        # -fno-slp-vectorize: keep f32 FMAs as v_fma/v_fmac; hipcc otherwise SLP-packs adjacent ones into
+        # v_pk_fma_f32, which is slower than two plain FMAs on gfx950 (measured on k_fir_*; MI355X_MICROARCH.md)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-parameter"] + \
+              EXTRA_HIP_FLAGS + ["-c", os.path.join(CSRC, f), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -63,12 +63,13 @@ struct pmr_chain_s {
 
     /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
     int chan_small;                  /* small-M channelizer (pmr_channelize_small.hip) selected       */
-    int fe_on, fe_nt;                /* fused path selected; threads per tile workgroup (256 / 1024)  */
+    int fe_on, fe_nt, fe_spt;        /* fused path selected; threads per tile workgroup, samples per thread */
     int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
     int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
     float fe_Kgain, fe_lam_wave, fe_lam_pow16[6];
     float *d_fe_taps, *d_fe_GA, *d_fe_T1, *d_fe_T2, *d_fe_lam_lane;
     cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V;
+    uint64_t *d_fe_stamps;           /* diagnostic per-phase cycle sums (PMR_FE_STAMP)                */
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     unsigned fe_max_tiles;
 
@@ -117,15 +118,15 @@ static int dev_upload(pmr_chain q, float **p, const float *src, size_t n)
     return PMR_OK;
 }
 
-/* taps for k_fir_tm: h zero-padded by RP-1 on both sides, natural order: Q[(RP-1) + d] = h[d].
- * Step e (input sample t0-J-(n-1)+e) meets accumulator i (output t0-J+i) with h[(n-1)+i-e] = Q[(n+RP-2-e)+i]. */
+/* FIR tap table for the audio kernels: h zero-padded by PMR_TAP_PAD on both sides, natural order:
+ * Q[PMR_TAP_PAD + d] = h[d].  Input step e (frame t0-J-(n-1)+e) meets accumulator i (frame t0-J+i) with
+ * h[(n-1)+i-e] = Q[PMR_TAP_PAD + (n-1) + i - e]. */
 static int upload_padded_taps(pmr_chain q, float **p, const float *h, unsigned n)
 {
-    const unsigned rp = PMR_AUDIO_R + PMR_AUDIO_J;
-    size_t len = n + 2 * (rp - 1);
+    size_t len = n + 2 * PMR_TAP_PAD;
     float *tmp = (float *)calloc(len, sizeof(float));
     if (!tmp) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
-    for (unsigned j = 0; j < n; j++) tmp[j + rp - 1] = h[j];
+    for (unsigned j = 0; j < n; j++) tmp[j + PMR_TAP_PAD] = h[j];
     int rc = dev_upload(q, p, tmp, len);
     free(tmp);
     return rc;
@@ -246,7 +247,11 @@ static int fe_init(pmr_chain q)
     }
     if (!nt) return PMR_OK;                      /* cascade too deep for one LDS tile: staged path */
     const unsigned long N0 = (unsigned long)nt * 16;
-    q->fe_nt = nt;
+    q->fe_nt = nt; q->fe_spt = 16;
+    if (nt == 256) {                             /* alternative geometry for experiments: 512 threads x 8 samples */
+        const char *g = getenv("PMR_FE_GEOM");
+        if (g && !strcmp(g, "512x8")) { q->fe_nt = 512; q->fe_spt = 8; }   /* measured slower than 256 x 16 */
+    }
     q->fe_T_own = (int)T_own;
     q->fe_Hh = (int)(N0 - T_own);
     q->fe_HhQ = q->fe_Hh / (int)D;
@@ -302,10 +307,11 @@ static int fe_init(pmr_chain q)
     }
     {
         float ll[64];
-        for (unsigned l = 0; l < 64; l++) ll[l] = (float)pow(lam, 16.0 * l);
+        const double spt = (double)q->fe_spt;
+        for (unsigned l = 0; l < 64; l++) ll[l] = (float)pow(lam, spt * l);
         if ((rc = dev_upload(q, &q->d_fe_lam_lane, ll, 64))) return rc;
-        for (int j = 0; j < 6; j++) q->fe_lam_pow16[j] = (float)pow(lam, 16.0 * (double)(1u << j));
-        q->fe_lam_wave = (float)pow(lam, 1024.0);
+        for (int j = 0; j < 6; j++) q->fe_lam_pow16[j] = (float)pow(lam, spt * (double)(1u << j));
+        q->fe_lam_wave = (float)pow(lam, 64.0 * spt);
     }
     for (int i = 0; i < 2; i++) {
         if ((rc = dev_alloc(q, (void **)&q->d_fe_hist[i], (size_t)q->fe_hcap * sizeof(cfl)))) return rc;
@@ -590,7 +596,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
 
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
-    p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.out = q->d_xr + q->xr_fill;
+    p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr + q->xr_fill;
     p.probeA = q->d_fe_probeA; p.probeB = q->d_fe_probeB; p.probeL = q->d_fe_probeL; p.probeE = q->d_fe_probeE;
     p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
     p.n_in = n_in; p.ny = ny; p.Q = Q; p.phi0 = q->arb_phase; p.step = d->arb_step;
@@ -599,8 +605,12 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     memcpy(p.m, q->fe_m, sizeof(p.m)); memcpy(p.tap_off, q->fe_tap_off, sizeof(p.tap_off));
     p.dc_a1 = d->dc_a1; p.zeta = d->zeta; p.lam_wave = q->fe_lam_wave;
     { const char *ab = getenv("PMR_FE_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+    if (getenv("PMR_FE_STAMP")) {
+        if (!q->d_fe_stamps) { int rc_ = dev_alloc(q, (void **)&q->d_fe_stamps, 8 * sizeof(uint64_t)); if (rc_) return rc_; }
+        p.stamps = q->d_fe_stamps;
+    }
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
-    LAUNCH(K_FE, pmr_launch_frontend(q->stream, &p, ntiles, q->fe_nt));
+    LAUNCH(K_FE, pmr_launch_frontend(q->stream, &p, ntiles, q->fe_nt, q->fe_spt));
 
     pmr_fe_tiles_params t;
     memset(&t, 0, sizeof(t));
@@ -624,8 +634,6 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
         f.Kgain = q->fe_Kgain;
         LAUNCH(K_FE_FIX, pmr_launch_fe_dcfix(q->stream, &f));
     }
-    LAUNCH(K_FE_HIST, pmr_launch_fe_hist(q->stream, q->d_fe_hist[cur], d_iq, n_in, q->d_fe_hist[nxt],
-                                         (unsigned)q->fe_hcap));
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
     *ny_out = ny;
@@ -841,12 +849,13 @@ int pmr_chain_debug_enable(pmr_chain q, int on)
 int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes, size_t *n_bytes)
 {
     if (!q) return PMR_EINVAL;
-    if (!q->dbg_on) return fail(q, PMR_EINVAL, "debug capture not enabled", hipSuccess);
+    if (!q->dbg_on && what != 2) return fail(q, PMR_EINVAL, "debug capture not enabled", hipSuccess);
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
     HIPCHK(hipStreamSynchronize(q->stream), "sync");
     const void *src = NULL; size_t n = 0;
     if (what == PMR_DEBUG_RESAMPLED) { src = q->d_dbg_xr; n = (size_t)q->last_ny * sizeof(cfl); }
     else if (what == PMR_DEBUG_FM)   { src = q->d_dbg_fm; n = (size_t)q->last_ns * q->M * sizeof(float); }
+    else if (what == 2 && q->d_fe_stamps) { src = q->d_fe_stamps; n = 8 * sizeof(uint64_t); }
     else return PMR_EINVAL;
     if (n_bytes) *n_bytes = n;
     if (n > cap_bytes) n = cap_bytes;

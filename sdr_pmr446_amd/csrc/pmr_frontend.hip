@@ -22,8 +22,14 @@
 
 #include "pmr_kernels.h"
 
-typedef float2 cf;
-static __device__ __forceinline__ cf cfm(float r, float i) { cf v; v.x = r; v.y = i; return v; }
+// complex sample = clang ext-vector pair: (re, im) arithmetic with a real scalar tap maps onto v_pk_fma_f32 with the tap
+// broadcast from one SGPR.  Measured on MI355X (tools/ubench/valu_rate.hip): v_fma_f32 peaks at ~67 TFLOP/s,
+// v_pk_fma_f32 at ~115-120 TFLOP/s, so packed math is worth ~1.8x wherever the kernel is VALU-bound.
+typedef float cf __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ cf cfm(float r, float i) { return cf{r, i}; }
+static __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+static __device__ __forceinline__ cf cadd_scale(cf a, cf b, float s) { return (a + b) * cf{s, s}; }
+static __device__ __forceinline__ cf cfma(float h, cf x, cf acc) { return __builtin_elementwise_fma(cf{h, h}, x, acc); }
 
 // LDS layout L(G): element e lives at e + e/G (one 8-byte pad per G elements) so that threads whose chunks
 // are G elements apart hit distinct banks with ds_read_b64 / ds_write_b64 (stride 2G+2 dwords, gcd with 64 = 2).
@@ -37,6 +43,9 @@ static __device__ __forceinline__ int lidx_rt(int e, int g_shift) { return e + (
 // thread_base + compile-time constant (floor division keeps that true left of the tile, where the
 // reads land in the zero pad in front of the buffer and only feed outputs inside the halo).
 // ---------------------------------------------------------------------------------------------
+#ifndef FE_WAVES_512
+#define FE_WAVES_512 8      /* waves per SIMD requested for the 512 x 8 geometry (4 workgroups = 32 waves per CU) */
+#endif
 #define FE_PAD 64      /* elements in front of the tile buffer; >= (4*10-2) * (1 + 1/2) */
 
 static constexpr int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -74,14 +83,10 @@ static __device__ __forceinline__ void hb_stage(cf *buf, int tid, int n_threads,
         for (int p = 0; p < P; p++) wd[p] = w[loff<G>(2 * p + 1 - 2 * MM)];
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            float ar = 0.f, ai = 0.f;
+            cf a = cfm(0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < 2 * MM; j++) {
-                const float h = h1[j];
-                ar = fmaf(h, we[p + j].x, ar);
-                ai = fmaf(h, we[p + j].y, ai);
-            }
-            y[p] = cfm((wd[p].x + ar) * scale, (wd[p].y + ai) * scale);
+            for (int j = 0; j < 2 * MM; j++) a = cfma(h1[j], we[p + j], a);
+            y[p] = cadd_scale(wd[p], a, scale);
         }
     }
     hb_store<P>(buf, tid, n_threads, y);
@@ -98,18 +103,15 @@ static __device__ void hb_stage_generic(cf *buf, int tid, int n_threads, int mm,
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const int o = tid * P + p;
-            float ar = 0.f, ai = 0.f;
+            cf a = cfm(0.f, 0.f);
             for (int j = 0; j < 2 * mm; j++) {
                 int e = 2 * o - 2 * (2 * mm - 1 - j);
                 e = e < 0 ? 0 : e;
-                const cf s = buf[lidx<G>(e)];
-                ar = fmaf(h1[j], s.x, ar);
-                ai = fmaf(h1[j], s.y, ai);
+                a = cfma(h1[j], buf[lidx<G>(e)], a);
             }
             int e = 2 * o + 1 - 2 * mm;
             e = e < 0 ? 0 : e;
-            const cf d = buf[lidx<G>(e)];
-            y[p] = cfm((d.x + ar) * scale, (d.y + ai) * scale);
+            y[p] = cadd_scale(buf[lidx<G>(e)], a, scale);
         }
     }
     hb_store<P>(buf, tid, n_threads, y);
@@ -123,38 +125,54 @@ static __device__ __forceinline__ void hb_dispatch(cf *buf, int tid, int n_threa
     // execution order: long filters only ever meet small P, except in 1- and 2-stage cascades)
     if (mm == 3)                 hb_stage<P, 3>(buf, tid, n_threads, h1, scale);
     else if (mm == 5)            hb_stage<P, 5>(buf, tid, n_threads, h1, scale);
-    else if (mm == 10 && P <= 4) hb_stage<(P <= 4 ? P : 1), 10>(buf, tid, n_threads, h1, scale);
+    else if (mm == 10 && P <= 2) hb_stage<(P <= 2 ? P : 1), 10>(buf, tid, n_threads, h1, scale);
     else                         hb_stage_generic<P>(buf, tid, n_threads, mm, h1, scale);
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
+// exact ceil(num / den) for num < 2^58, den < 2^26 without the 64-bit integer division routine:
+// double-precision estimate, then an integer fix-up
+static __device__ __forceinline__ unsigned long long ceil_div_u64(unsigned long long num, unsigned den)
+{
+    unsigned long long q = (unsigned long long)((double)num / (double)den);
+    while (q * den < num) q++;
+    while (q > 0 && (q - 1) * den >= num) q--;
+    return q;
+}
+
+// NT threads own a tile of N0 = NT * SPT raw samples (SPT consecutive samples per thread in the dc scan).
+template <int NT, int SPT>
+__global__ __launch_bounds__(NT, NT == 512 ? FE_WAVES_512 : 4) void k_frontend(pmr_fe_params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int N0 = NT * 16;
-    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;        // [FE_PAD zero pad | N0 + N0/16 elements | scan scratch]
-    cf *wagg = buf + (N0 + N0 / 16);                        // [NT/64] wave aggregates of the dc scan
+    constexpr int N0 = NT * SPT;
+    constexpr int LPT = N0 / 2 / NT;                        // 16-byte loads per thread in phase A
+    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;        // [FE_PAD zero pad | N0 + N0/SPT elements | scan scratch]
+    cf *wagg = buf + (N0 + N0 / SPT);                       // [NT/64] wave aggregates of the dc scan
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const cf *__restrict__ x = (const cf *)p.x;
+    const cf *__restrict__ hist = (const cf *)p.hist;
+    const float lam = -p.dc_a1;
     const int c = blockIdx.x;
     const long b0 = (long)c * p.T_own - p.Hh - p.pend;      // block-relative index of tile sample 0
+    unsigned long long *stamps = (unsigned long long *)p.stamps;   // diagnostic build only (PMR_FE_STAMP)
+    long long ts[5] = {0, 0, 0, 0, 0};
+    if (stamps) ts[0] = clock64();
 
-    // ---- phase A: raw samples -> LDS (layout L(16)); history for b < 0, zeros beyond the block ----
+    // ---- phase A: raw samples -> LDS (layout L(SPT)); history for b < 0, zeros beyond the block ----
     if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
     if (!(p.ablate & 1)) {
-        const cf *__restrict__ x = (const cf *)p.x;
-        const cf *__restrict__ hist = (const cf *)p.hist;
         // interior tile, 16-byte aligned: all loads of the thread are issued before the first LDS write
         const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
         if (fast) {
             const float4 *__restrict__ src = reinterpret_cast<const float4 *>(x + b0);
-            float4 v[8];
+            float4 v[LPT];
 #pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = src[tid + NT * i];
+            for (int i = 0; i < LPT; i++) v[i] = src[tid + NT * i];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                cf *d = buf + lidx<16>(2 * (tid + NT * i));       // the pair never straddles a 16-sample chunk
+            for (int i = 0; i < LPT; i++) {
+                cf *d = buf + lidx<SPT>(2 * (tid + NT * i));      // the pair never straddles an SPT-sample chunk
                 d[0] = cfm(v[i].x, v[i].y);
                 d[1] = cfm(v[i].z, v[i].w);
             }
@@ -165,65 +183,58 @@ __global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
                 cf v = cfm(0.f, 0.f);
                 if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) v = hist[hi]; }
                 else if (b < (long)p.n_in) v = x[b];
-                buf[lidx<16>(i)] = v;
+                buf[lidx<SPT>(i)] = v;
             }
         }
     }
     __syncthreads();
+    if (stamps) ts[1] = clock64();
 
     // ---- phase B: dc blocker (:795) from zero state, in place ----
     if (!(p.ablate & 2)) {
-        cf xs[16];
+        const float lp = p.lam_lane_pow[lane];              // lambda^(SPT lane)
+        cf xs[SPT];
 #pragma unroll
-        for (int j = 0; j < 16; j++) xs[j] = buf[17 * tid + j];
-        const float a1 = p.dc_a1;
-        float vr = 0.f, vi = 0.f;
+        for (int j = 0; j < SPT; j++) xs[j] = buf[(SPT + 1) * tid + j];
+        cf v = cfm(0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            vr = __fsub_rn(xs[j].x, __fmul_rn(a1, vr));
-            vi = __fsub_rn(xs[j].y, __fmul_rn(a1, vi));
-        }
-        // inclusive decayed scan across the wave: inc_l = sum_{s<=l} lambda^(16 (l-s)) agg_s
+        for (int j = 0; j < SPT; j++) v = cfma(lam, v, xs[j]);             // v0 = x - a1 v1
+        // inclusive decayed scan across the wave: inc_l = sum_{s<=l} lambda^(SPT (l-s)) agg_s
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const int d = 1 << j;
-            const float tr = __shfl_up(vr, d), ti = __shfl_up(vi, d);
-            if (lane >= d) { vr = fmaf(p.lam_pow16[j], tr, vr); vi = fmaf(p.lam_pow16[j], ti, vi); }
+            const cf t = cfm(__shfl_up(v.x, d), __shfl_up(v.y, d));
+            if (lane >= d) v = cfma(p.lam_pow16[j], t, v);
         }
-        if (lane == 63) wagg[wave] = cfm(vr, vi);
-        float exr = __shfl_up(vr, 1), exi = __shfl_up(vi, 1);
-        if (lane == 0) { exr = 0.f; exi = 0.f; }
+        if (lane == 63) wagg[wave] = v;
+        cf ex = cfm(__shfl_up(v.x, 1), __shfl_up(v.y, 1));
+        if (lane == 0) ex = cfm(0.f, 0.f);
         __syncthreads();
-        float cwr = 0.f, cwi = 0.f;                          // v (local) at the end of the previous wave
-        for (int w = 0; w < wave; w++) {
-            const cf a = wagg[w];
-            cwr = fmaf(p.lam_wave, cwr, a.x);
-            cwi = fmaf(p.lam_wave, cwi, a.y);
-        }
-        const float lp = p.lam_lane_pow[lane];               // lambda^(16 lane)
-        float v1r = fmaf(lp, cwr, exr), v1i = fmaf(lp, cwi, exi);
+        cf cw = cfm(0.f, 0.f);                                             // v (local) at the end of the previous wave
+        for (int w = 0; w < wave; w++) cw = cfma(p.lam_wave, cw, wagg[w]);
+        cf v1 = cfma(lp, cw, ex);
         // stray probes (block start - 1 in tile 0, block end in the last tile) sit at arbitrary offsets
         const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
         const int pE = (c == p.c_end) ? p.off_end : -1;
-        const bool stray = (pL >> 4) == tid || (pE >> 4) == tid;
+        const bool stray = (pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const float v0r = __fsub_rn(xs[j].x, __fmul_rn(a1, v1r));
-            const float v0i = __fsub_rn(xs[j].y, __fmul_rn(a1, v1i));
-            buf[17 * tid + j] = cfm(__fsub_rn(v0r, v1r), __fsub_rn(v0i, v1i));
-            v1r = v0r; v1i = v0i;
+        for (int j = 0; j < SPT; j++) {
+            const cf v0 = cfma(lam, v1, xs[j]);
+            buf[(SPT + 1) * tid + j] = csub(v0, v1);                       // y = v0 - v1
+            v1 = v0;
             if (stray) {
-                if (16 * tid + j == pL) ((cf *)p.probeL)[0] = cfm(v0r, v0i);
-                if (16 * tid + j == pE) ((cf *)p.probeE)[0] = cfm(v0r, v0i);
+                if (SPT * tid + j == pL) ((cf *)p.probeL)[0] = v0;
+                if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = v0;
             }
         }
-        if (tid == (p.Hh >> 4) - 1) ((cf *)p.probeA)[c] = cfm(v1r, v1i);   // local v at tile offset Hh-1
-        if (tid == NT - 1) ((cf *)p.probeB)[c] = cfm(v1r, v1i);             // local v at tile offset N0-1
+        if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;               // local v at tile offset Hh-1
+        if (tid == NT - 1) ((cf *)p.probeB)[c] = v1;                       // local v at tile offset N0-1
     }
     __syncthreads();
+    if (stamps) ts[2] = clock64();
 
     // ---- phase C: half-band cascade, in place (stage e halves the sample count) ----
-    int g_shift = 4;                                         // layout of the current signal: L(1 << g_shift)
+    int g_shift = SPT == 16 ? 4 : 3;                         // layout of the current signal: L(1 << g_shift)
     if (!(p.ablate & 4)) {
         const float *__restrict__ taps = p.hb_taps;
         int n_out = N0 >> 1;
@@ -231,17 +242,17 @@ __global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
             const int mm = p.m[e];
             const float *h1 = taps + p.tap_off[e];
             const float scale = (e == p.h - 1) ? p.zeta : 1.0f;
-            const int pp = n_out >= NT ? n_out / NT : 1;     // outputs per thread: 8, 4, 2, 1, 1, ...
+            const int pp = n_out >= NT ? n_out / NT : 1;     // outputs per thread: SPT/2, ..., 2, 1, 1, ...
             const int n_threads = n_out / pp;
-            if (pp == 8)      hb_dispatch<8>(buf, tid, n_threads, mm, h1, scale);
-            else if (pp == 4) hb_dispatch<4>(buf, tid, n_threads, mm, h1, scale);
-            else if (pp == 2) hb_dispatch<2>(buf, tid, n_threads, mm, h1, scale);
-            else              hb_dispatch<1>(buf, tid, n_threads, mm, h1, scale);
-            const int gout_shift = pp == 8 ? 3 : (pp == 4 ? 2 : 1);   // output layout L(max(pp, 2))
-            g_shift = gout_shift;
+            if (SPT >= 16 && pp == 8) hb_dispatch<8>(buf, tid, n_threads, mm, h1, scale);
+            else if (pp == 4)         hb_dispatch<4>(buf, tid, n_threads, mm, h1, scale);
+            else if (pp == 2)         hb_dispatch<2>(buf, tid, n_threads, mm, h1, scale);
+            else                      hb_dispatch<1>(buf, tid, n_threads, mm, h1, scale);
+            g_shift = pp == 8 ? 3 : (pp == 4 ? 2 : 1);       // output layout L(max(pp, 2))
             n_out >>= 1;
         }
     }
+    if (stamps) ts[3] = clock64();
 
     // ---- phase D: arbitrary resampler (24-bit phase) for the outputs whose input sample is owned here ----
     if (!(p.ablate & 8)) {
@@ -250,8 +261,8 @@ __global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
         if (qb > p.Q) qb = p.Q;
         if (qa < qb) {
             const unsigned long long sa = qa << 24, sb = qb << 24;
-            const unsigned long long ja = sa <= p.phi0 ? 0ull : (sa - p.phi0 + p.step - 1) / p.step;
-            unsigned long long jb = sb <= p.phi0 ? 0ull : (sb - p.phi0 + p.step - 1) / p.step;
+            const unsigned long long ja = sa <= p.phi0 ? 0ull : ceil_div_u64(sa - p.phi0, p.step);
+            unsigned long long jb = sb <= p.phi0 ? 0ull : ceil_div_u64(sb - p.phi0, p.step);
             if (jb > p.ny) jb = p.ny;
             const float *__restrict__ bank = p.arb_bank;
             cf *__restrict__ out = (cf *)p.out;
@@ -260,16 +271,31 @@ __global__ __launch_bounds__(NT) void k_frontend(pmr_fe_params p)
                 const int ql = (int)((ph >> 24) - qa) + p.HhQ;          // tile-local decimated index
                 const unsigned idx = (unsigned)(ph & 0xffffffu) >> 16;
                 const float *b = bank + idx * 14u;
-                float yr = 0.f, yi = 0.f;
+                float bk[14];
 #pragma unroll
-                for (int k = 0; k < 14; k++) {
-                    const cf s = buf[lidx_rt(ql - 13 + k, g_shift)];
-                    yr = fmaf(b[k], s.x, yr);
-                    yi = fmaf(b[k], s.y, yi);
-                }
-                out[j] = cfm(yr, yi);
+                for (int k = 0; k < 14; k++) bk[k] = b[k];
+                cf y = cfm(0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 14; k++) y = cfma(bk[k], buf[lidx_rt(ql - 13 + k, g_shift)], y);
+                out[j] = y;
             }
         }
+    }
+    // ---- raw history for the next call (last hcap samples of old history || block), by workgroup 0 ----
+    if (c == 0 && p.new_hist) {
+        cf *__restrict__ nh = (cf *)p.new_hist;
+        for (int i = tid; i < p.hcap; i += NT) {
+            const long sb = (long)i + (long)p.n_in - (long)p.hcap;      // block-relative index
+            nh[i] = sb < 0 ? hist[(long)i + p.n_in] : x[sb];
+        }
+    }
+    if (stamps && tid == 0) {
+        ts[4] = clock64();
+        atomicAdd(&stamps[0], (unsigned long long)(ts[1] - ts[0]));   // A: load + LDS write
+        atomicAdd(&stamps[1], (unsigned long long)(ts[2] - ts[1]));   // B: dc scan
+        atomicAdd(&stamps[2], (unsigned long long)(ts[3] - ts[2]));   // C: cascade
+        atomicAdd(&stamps[3], (unsigned long long)(ts[4] - ts[3]));   // D: resampler
+        atomicAdd(&stamps[4], 1ull);
     }
 }
 
@@ -335,22 +361,31 @@ __global__ __launch_bounds__(256) void k_fe_hist(const cf *__restrict__ old_hist
 }
 
 // ---------------------------------------------------------------------------------------------
-extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt)
+template <int NT, int SPT>
+static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
+{
+    const size_t n0 = (size_t)NT * SPT;
+    const size_t lds = (FE_PAD + n0 + n0 / SPT + 32) * sizeof(cf);   /* pad + tile + scan scratch */
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend<NT, SPT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    auto kern = k_frontend<NT, SPT>;
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), lds, st, *p);
+    return (int)hipGetLastError();
+}
+
+/* tile geometries: (threads, samples per thread).  4096-sample tiles as 512 x 8 (default: twice the waves per CU
+ * of 256 x 16 for the same LDS) or 256 x 16; 16384-sample tiles (deep cascades) as 1024 x 16.                 */
+extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt)
 {
     if (!ntiles) return 0;
-    const size_t n0 = (size_t)nt * 16;
-    const size_t lds = (64 + n0 + n0 / 16 + 32) * sizeof(cf);   /* FE_PAD + tile + scan scratch */
-    static bool attr[2] = { false, false };
-    if (nt == 256) {
-        if (!attr[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_frontend<256>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[0] = true; }
-        hipLaunchKernelGGL(k_frontend<256>, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p);
-    } else if (nt == 1024) {
-        if (!attr[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_frontend<1024>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[1] = true; }
-        hipLaunchKernelGGL(k_frontend<1024>, dim3(ntiles), dim3(1024), lds, (hipStream_t)s, *p);
-    } else return (int)hipErrorInvalidValue;
-    return (int)hipGetLastError();
+    if (nt == 512 && spt == 8) return launch_frontend_t<512, 8>((hipStream_t)s, p, ntiles);
+    if (nt == 256 && spt == 16) return launch_frontend_t<256, 16>((hipStream_t)s, p, ntiles);
+    if (nt == 1024 && spt == 16) return launch_frontend_t<1024, 16>((hipStream_t)s, p, ntiles);
+    return (int)hipErrorInvalidValue;
 }
 
 extern "C" int pmr_launch_fe_tiles(pmr_stream_t s, const pmr_fe_tiles_params *p)

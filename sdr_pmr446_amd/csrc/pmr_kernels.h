@@ -14,6 +14,7 @@ typedef void *pmr_stream_t;     /* hipStream_t */
 
 #define PMR_DC_TILE 4096u       /* raw samples per dc-block tile (256 threads x 16) */
 #define PMR_DC_SCAN_THREADS 1024u
+#define PMR_TAP_PAD 64u         /* zeros on both sides of every FIR tap table handed to the FIR kernels */
 #define PMR_AUDIO_R 32u         /* outputs per thread in the time-major FIR */
 #define PMR_AUDIO_J 6u          /* IIR warm-up outputs (de-emphasis pole^J < 1e-10); R+J even (packed FMA) */
 
@@ -85,20 +86,22 @@ int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, unsigned M, 
 typedef struct {
     const void *x;              /* new block [n_in] cf32                                             */
     const void *hist;           /* raw history: the hcap samples before the block                    */
+    void *new_hist;             /* raw history for the NEXT call (other ping-pong buffer), written by tile 0 */
     void *out;                  /* resampled outputs of this block [ny] cf32                         */
     void *probeA, *probeB;      /* [ntiles] local dc state at tile offsets Hh-1 and N0-1             */
     void *probeL, *probeE;      /* local dc state at (block start - 1) in tile 0, (block end) in tile c_end */
     const float *hb_taps;       /* branch taps of all stages, execution order, oldest-first          */
     const float *arb_bank;      /* [256][14]                                                         */
-    const float *lam_lane_pow;  /* [64] lambda^(16 l)                                                */
+    const float *lam_lane_pow;  /* [64] lambda^(spt l)                                               */
     unsigned n_in, ny, Q;       /* raw samples, resampled outputs, decimated samples of this block   */
     uint32_t phi0, step;        /* resamp_crcf phase before the block's first decimated sample, step */
     int h, T_own, Hh, HhQ, TQ;  /* stages; owned raw samples per tile, halo (raw / decimated), owned decimated */
     int pend, hcap, c_end, off_end;
+    void *stamps;               /* diagnostic: 8 x u64 per-phase cycle sums (PMR_FE_STAMP), else NULL  */
     int ablate;                 /* timing experiments only (PMR_FE_ABLATE): bit0 skip load, 1 dc, 2 cascade, 3 resampler */
     int m[PMR_FE_MAX_STAGES], tap_off[PMR_FE_MAX_STAGES];
     float dc_a1, zeta, lam_wave;
-    float lam_pow16[6];         /* lambda^(16 * 2^j)                                                 */
+    float lam_pow16[6];         /* lambda^(spt * 2^j)                                                */
 } pmr_fe_params;
 
 typedef struct {
@@ -116,7 +119,7 @@ typedef struct {
     float Kgain;
 } pmr_fe_fix_params;
 
-int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt);
+int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt);
 int pmr_launch_fe_tiles(pmr_stream_t s, const pmr_fe_tiles_params *p);
 int pmr_launch_fe_dcfix(pmr_stream_t s, const pmr_fe_fix_params *p);
 int pmr_launch_fe_hist(pmr_stream_t s, const void *old_hist, const void *x, unsigned n_in, void *new_hist,

@@ -8,6 +8,8 @@
 // baseline that the fused front-end (pmr_frontend.hip) is A/B-tested against.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "pmr_kernels.h"
 
@@ -275,6 +277,38 @@ __global__ void k_rssi_finish(const float *__restrict__ part, unsigned ntiles, u
 typedef float v2f __attribute__((ext_vector_type(2)));
 static_assert(RP % 2 == 0, "packed accumulators come in pairs");
 
+// Inner loop shared by the FIR kernels.  acc[i] <-> output t0 - J + i; step e brings input sample
+// s = t0 - J - (ntaps-1) + e, which meets output i with tap taps_q[(ntaps + RP - 2 - e) + i] (taps_q = h zero-padded
+// by RP-1 on both sides).  Four steps share ONE window of RP+3 wave-uniform taps (a few wide scalar loads instead
+// of one s_load per tap pair); every tap is then an SGPR operand of a plain v_fmac_f32.
+template <typename LoadX>
+static __device__ __forceinline__ void fir_accumulate(float (&acc)[RP], const float *__restrict__ taps_q,
+                                                      unsigned ntaps, LoadX loadx)
+{
+    const unsigned steps = ntaps + RP - 1;
+    const float *tq0 = taps_q + PMR_TAP_PAD + (ntaps - 1) - (RP - 1) + (RP - 1);
+    unsigned e = 0;
+    for (; e + 4 <= steps; e += 4) {
+        const float x0 = loadx(e), x1 = loadx(e + 1), x2 = loadx(e + 2), x3 = loadx(e + 3);
+        const float *tp = tq0 - e - 3;                // tap(e + u, i) = tp[3 - u + i]
+#pragma unroll
+        for (int i = 0; i < (int)RP; i++) {
+            float a = acc[i];
+            a = fmaf(tp[3 + i], x0, a);
+            a = fmaf(tp[2 + i], x1, a);
+            a = fmaf(tp[1 + i], x2, a);
+            a = fmaf(tp[i], x3, a);
+            acc[i] = a;
+        }
+    }
+    for (; e < steps; e++) {
+        const float x = loadx(e);
+        const float *tp = tq0 - e;
+#pragma unroll
+        for (int i = 0; i < (int)RP; i++) acc[i] = fmaf(tp[i], x, acc[i]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, unsigned ns, unsigned M,
                                                 unsigned log2M, const float *__restrict__ taps_q,
                                                 unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
@@ -289,28 +323,15 @@ __global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, un
     // with tap h[(ntaps-1) + i - e]; taps_q is that sequence zero-padded and stored so that the RP taps of one
     // step are ASCENDING in i: tap(e, i) = taps_q[(ntaps + RP - 2 - e) + i].  Two adjacent accumulators share
     // one v_pk_fma_f32 (x broadcast, tap pair from scalar registers).
-    v2f acc[RP / 2];
+    float acc[RP];
 #pragma unroll
-    for (int i = 0; i < RP / 2; i++) acc[i] = v2f{0.f, 0.f};
+    for (int i = 0; i < (int)RP; i++) acc[i] = 0.f;
     const float *px = in + ((t0 - (long)PMR_AUDIO_J - (long)(ntaps - 1)) * (long)M + (long)k);
-    const unsigned steps = ntaps + RP - 1;
-    const float *tq0 = taps_q + (ntaps + RP - 2);
-#pragma unroll 4
-    for (unsigned e = 0; e < steps; e++) {
-        const float x = px[(size_t)e * M];
-        const float *tp = tq0 - e;                    // wave-uniform -> scalar loads
-        const v2f xx = v2f{x, x};
-#pragma unroll
-        for (int i = 0; i < RP / 2; i++) {
-            const v2f t = v2f{tp[2 * i], tp[2 * i + 1]};
-            acc[i] = __builtin_elementwise_fma(t, xx, acc[i]);
-        }
-    }
+    fir_accumulate(acc, taps_q, ntaps, [&](unsigned e) { return px[(size_t)e * M]; });
     float v1 = 0.f;
 #pragma unroll
     for (int i = 0; i < (int)RP; i++) {
-        const float a = (i & 1) ? acc[i / 2].y : acc[i / 2].x;
-        float u = __fmul_rn(a, gain);
+        float u = __fmul_rn(acc[i], gain);
         float y = u;
         if (iir) {
             const float v0 = __fsub_rn(u, __fmul_rn(a1, v1));
@@ -332,6 +353,200 @@ __global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, un
                     pcm[(size_t)k * stride + t] = q;
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled version of k_fir_tm: one workgroup = 16 channels x 512 output frames.  The 16-channel slab of the
+// time-major input (rows of 64 bytes) is staged once with 16-byte loads; each thread (channel k, 32-output
+// segment) then walks its inputs out of LDS while the tap pairs stay wave-uniform in SGPRs (v_pk_fma_f32).
+// LDS row r lives at r*16 + 16*(r>>5) floats: neighbouring 32-row segments land on opposite bank halves, so the
+// 32 lanes of one ds_read_b32 (16 channels x 2 segments) never collide.
+// ------------------------------------------------------------------------------------------------
+#define FL_SEGS 16
+#define FL_T (FL_SEGS * PMR_AUDIO_R)          /* 512 output frames per tile */
+
+__global__ __launch_bounds__(256) void k_fir_lds(const float *__restrict__ in, unsigned ns, unsigned M,
+                                                 const float *__restrict__ taps_q, unsigned ntaps, float gain,
+                                                 int iir, float b0, float b1, float a1, float *__restrict__ out_tm,
+                                                 int16_t *__restrict__ pcm, float *__restrict__ audio,
+                                                 unsigned stride)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    float *tile = reinterpret_cast<float *>(smem_f);
+    const int tid = threadIdx.x;
+    const unsigned groups = M >> 4;
+    const unsigned g = blockIdx.x % groups, tb = blockIdx.x / groups;
+    const long t0w = (long)tb * FL_T;                              // first output frame of the tile
+    const long r0 = t0w - (long)PMR_AUDIO_J - (long)(ntaps - 1);   // frame of tile row 0
+    const unsigned rows = FL_T + PMR_AUDIO_J + ntaps - 1;
+
+    // stage [rows][16] (frames >= ns read as zero; history lives at negative frames of `in`)
+    for (unsigned u = tid; u < rows * 4; u += 256) {
+        const unsigned r = u >> 2, q4 = (u & 3) * 4;
+        const long t = r0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < (long)ns) v = *reinterpret_cast<const float4 *>(in + t * (long)M + g * 16 + q4);
+        *reinterpret_cast<float4 *>(tile + r * 16 + 16 * (r >> 5) + q4) = v;
+    }
+    __syncthreads();
+
+    const unsigned k = tid & 15, seg = tid >> 4;
+    const long t0 = t0w + (long)seg * PMR_AUDIO_R;
+    if (t0 >= (long)ns) return;
+    float acc[RP];
+#pragma unroll
+    for (int i = 0; i < (int)RP; i++) acc[i] = 0.f;
+    const float *px = tile + seg * (PMR_AUDIO_R * 16 + 16) + k;    // row seg*32 of the tile, column k
+    fir_accumulate(acc, taps_q, ntaps, [&](unsigned e) { return px[e * 16 + 16 * (e >> 5)]; });
+    const unsigned kk = g * 16 + k;
+    float v1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < (int)RP; i++) {
+        float u = __fmul_rn(acc[i], gain);
+        float y = u;
+        if (iir) {
+            const float v0 = __fsub_rn(u, __fmul_rn(a1, v1));
+            y = __fadd_rn(__fmul_rn(b0, v0), __fmul_rn(b1, v1));
+            v1 = v0;
+        }
+        if (i >= (int)PMR_AUDIO_J) {
+            const long t = t0 + (i - (int)PMR_AUDIO_J);
+            if (t < (long)ns) {
+                if (out_tm) out_tm[(size_t)t * M + kk] = y;
+                if (audio) audio[(size_t)kk * stride + t] = y;
+                if (pcm) {
+                    float s = y * 32767.0f;
+                    int16_t q;
+                    if (!(s == s)) q = 0;
+                    else if (s >= 32767.0f) q = 32767;
+                    else if (s <= -32768.0f) q = -32768;
+                    else q = (int16_t)s;                  // truncation toward zero
+                    pcm[(size_t)kk * stride + t] = q;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fir_pair: the same FIR + epilogue, PACKED ACROSS TWO ADJACENT CHANNELS.  lane <-> (channel pair, 16-output
+// segment); accumulator i is the v2f (channel 2c, channel 2c+1) of output t0 - J + i, so one v_pk_fma_f32 per
+// (step, output) does two MACs with the tap broadcast from a single SGPR (no SGPR-pair alignment, no moves) and
+// the input pair is one 8-byte load from the time-major stream.  v_pk_fma_f32 sustains ~1.8x the FLOP rate of
+// v_fma_f32 on gfx950 (tools/ubench/valu_rate.hip).  taps_c is h zero-padded by PMR_TAP_PAD on both sides.
+// ------------------------------------------------------------------------------------------------
+#define FP_R 16
+#define FP_J 4                                 /* de-emphasis pole^4 = 4.5e-8: below float32 resolution */
+#define FP_RP (FP_R + FP_J)
+
+static __device__ __forceinline__ int16_t pcm_from_float(float y)
+{
+    const float s = y * 32767.0f;
+    if (!(s == s)) return 0;
+    if (s >= 32767.0f) return 32767;
+    if (s <= -32768.0f) return -32768;
+    return (int16_t)s;                                 // truncation toward zero (src/dsd_in.c:174)
+}
+
+__global__ __launch_bounds__(256) void k_fir_pair(const float *__restrict__ in, unsigned ns, unsigned M,
+                                                  unsigned log2Mh, const float *__restrict__ taps_c,
+                                                  unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
+                                                  float *__restrict__ out_tm, int16_t *__restrict__ pcm,
+                                                  float *__restrict__ audio, unsigned stride)
+{
+    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+    const unsigned cp = gid & ((M >> 1) - 1), seg = gid >> log2Mh;
+    const long t0 = (long)seg * FP_R;
+    if (t0 >= (long)ns) return;
+    v2f acc[FP_RP];
+#pragma unroll
+    for (int i = 0; i < FP_RP; i++) acc[i] = v2f{0.f, 0.f};
+    // step e brings input frame s = t0 - J - (ntaps-1) + e; it meets accumulator i with tap h[ntaps-1 + i - e]
+    const float *px = in + ((t0 - (long)FP_J - (long)(ntaps - 1)) * (long)M + 2 * (long)cp);
+    const float *tq0 = taps_c + PMR_TAP_PAD + (ntaps - 1);
+    const unsigned steps = ntaps + FP_RP - 1;
+    unsigned e = 0;
+    for (; e + 4 <= steps; e += 4) {
+        const v2f x0 = *reinterpret_cast<const v2f *>(px + (size_t)(e + 0) * M);
+        const v2f x1 = *reinterpret_cast<const v2f *>(px + (size_t)(e + 1) * M);
+        const v2f x2 = *reinterpret_cast<const v2f *>(px + (size_t)(e + 2) * M);
+        const v2f x3 = *reinterpret_cast<const v2f *>(px + (size_t)(e + 3) * M);
+        const float *tp = tq0 - (long)e - 3;           // tap(e + u, i) = tp[3 - u + i]: one window for 4 steps
+#pragma unroll
+        for (int i = 0; i < FP_RP; i++) {
+            v2f a = acc[i];
+            a = __builtin_elementwise_fma(v2f{tp[3 + i], tp[3 + i]}, x0, a);
+            a = __builtin_elementwise_fma(v2f{tp[2 + i], tp[2 + i]}, x1, a);
+            a = __builtin_elementwise_fma(v2f{tp[1 + i], tp[1 + i]}, x2, a);
+            a = __builtin_elementwise_fma(v2f{tp[i], tp[i]}, x3, a);
+            acc[i] = a;
+        }
+    }
+    for (; e < steps; e++) {
+        const v2f x = *reinterpret_cast<const v2f *>(px + (size_t)e * M);
+        const float *tp = tq0 - (long)e;
+#pragma unroll
+        for (int i = 0; i < FP_RP; i++) acc[i] = __builtin_elementwise_fma(v2f{tp[i], tp[i]}, x, acc[i]);
+    }
+    // epilogue per channel of the pair: gain (:890) -> de-emphasis IIR (:898) -> float audio (:904) / int16 PCM
+    float ya[FP_R], yb[FP_R];
+    {
+        float va = 0.f, vb = 0.f;
+#pragma unroll
+        for (int i = 0; i < FP_RP; i++) {
+            float ua = __fmul_rn(acc[i].x, gain), ub = __fmul_rn(acc[i].y, gain);
+            float oa = ua, ob = ub;
+            if (iir) {
+                const float wa = __fsub_rn(ua, __fmul_rn(a1, va)), wb = __fsub_rn(ub, __fmul_rn(a1, vb));
+                oa = __fadd_rn(__fmul_rn(b0, wa), __fmul_rn(b1, va));
+                ob = __fadd_rn(__fmul_rn(b0, wb), __fmul_rn(b1, vb));
+                va = wa; vb = wb;
+            }
+            if (i >= FP_J) { ya[i - FP_J] = oa; yb[i - FP_J] = ob; }
+        }
+    }
+    const unsigned ka = 2 * cp, kb = 2 * cp + 1;
+    const bool full = t0 + FP_R <= (long)ns;
+    if (out_tm) {
+#pragma unroll
+        for (int i = 0; i < FP_R; i++)
+            if (t0 + i < (long)ns) *reinterpret_cast<v2f *>(out_tm + (size_t)(t0 + i) * M + ka) = v2f{ya[i], yb[i]};
+    }
+    if (audio) {
+        float *oa = audio + (size_t)ka * stride + t0, *ob = audio + (size_t)kb * stride + t0;
+        if (full && ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0)) {
+#pragma unroll
+            for (int i = 0; i < FP_R; i += 4) {
+                *reinterpret_cast<float4 *>(oa + i) = make_float4(ya[i], ya[i + 1], ya[i + 2], ya[i + 3]);
+                *reinterpret_cast<float4 *>(ob + i) = make_float4(yb[i], yb[i + 1], yb[i + 2], yb[i + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FP_R; i++) if (t0 + i < (long)ns) { oa[i] = ya[i]; ob[i] = yb[i]; }
+        }
+    }
+    if (pcm) {
+        int16_t *oa = pcm + (size_t)ka * stride + t0, *ob = pcm + (size_t)kb * stride + t0;
+        if (full && ((stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0)) {
+            // 16 consecutive int16 per channel = two 16-byte stores
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                unsigned wa[4], wb[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int i = 8 * h + 2 * j;
+                    wa[j] = (unsigned)(uint16_t)pcm_from_float(ya[i]) | ((unsigned)(uint16_t)pcm_from_float(ya[i + 1]) << 16);
+                    wb[j] = (unsigned)(uint16_t)pcm_from_float(yb[i]) | ((unsigned)(uint16_t)pcm_from_float(yb[i + 1]) << 16);
+                }
+                *reinterpret_cast<uint4 *>(oa + 8 * h) = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                *reinterpret_cast<uint4 *>(ob + 8 * h) = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FP_R; i++)
+                if (t0 + i < (long)ns) { oa[i] = pcm_from_float(ya[i]); ob[i] = pcm_from_float(yb[i]); }
         }
     }
 }
@@ -429,6 +644,32 @@ extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, u
                                  int16_t *pcm, float *audio, unsigned stride)
 {
     if (!ns) return 0;
+    static int mode = -1;                    /* 0 = pair (default), 1 = lds, 2 = global */
+    if (mode < 0) {
+        const char *e = getenv("PMR_FIR");
+        mode = (e && !strcmp(e, "lds")) ? 1 : (e && !strcmp(e, "global")) ? 2 : 0;
+    }
+    if (mode == 0 && M >= 2) {
+        const unsigned segs = (ns + FP_R - 1) / FP_R;
+        const size_t threads = (size_t)segs * (M >> 1);
+        hipLaunchKernelGGL(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, ns, M,
+                           ilog2(M >> 1), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
+        return (int)hipGetLastError();
+    }
+    if (mode == 1 && M >= 16 && ntaps <= 512) {
+        const unsigned rows = FL_T + PMR_AUDIO_J + ntaps - 1;
+        const size_t lds = ((size_t)rows * 16 + 16 * ((rows >> 5) + 1)) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_lds),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        const unsigned tiles = (ns + FL_T - 1) / FL_T;
+        hipLaunchKernelGGL(k_fir_lds, dim3(tiles * (M >> 4)), dim3(256), lds, (hipStream_t)s, in, ns, M, taps_pad,
+                           ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
+        return (int)hipGetLastError();
+    }
     const unsigned segs = (ns + PMR_AUDIO_R - 1) / PMR_AUDIO_R;
     const size_t threads = (size_t)segs * M;
     hipLaunchKernelGGL(k_fir_tm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, ns, M,
