@@ -65,11 +65,10 @@ def main():
 
     import torch
     from sdr_pmr446_amd import chain as pmr
+    from sdr_pmr446_amd import multigpu
     from sdr_pmr446_amd.synth_torch import synth_iq_torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = multigpu.env_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
@@ -77,11 +76,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    dist = multigpu.init_dist("nccl", dev)
 
     fs, M, lb = WORKLOADS[args.workload]
     lb = args.log2_block if args.log2_block is not None else lb
@@ -89,13 +84,9 @@ def main():
 
     ch = pmr.PmrChain(fs_in=fs, num_channels=M, max_block=block, device=local_rank)
     S = ch.max_frames
-    iq = synth_iq_torch(block, fs, M, dev, stream_id=rank)          # resident in HBM before timing
+    iq = synth_iq_torch(block, fs, M, dev, stream_id=multigpu.stream_id_for_rank(rank))   # resident in HBM before timing
     pcm = torch.zeros((M, S), dtype=torch.int16, device=dev)        # PCM stays in HBM
     torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
 
     def step():
         return ch.process_block_device(iq.data_ptr(), block, d_pcm=pcm.data_ptr(), stride=S)
@@ -106,26 +97,21 @@ def main():
     ch.profile_reset()
     ch.profile_enable(not args.no_kernel_events)
 
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    frames = 0
-    for _ in range(args.steps):
-        frames += step()
-    ch.synchronize()
-    torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
-    ch.profile_enable(False)
+    def run():
+        n = 0
+        for _ in range(args.steps):
+            n += step()
+        ch.synchronize()
+        return n
 
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, frames = multigpu.timed_region(run, dist, torch.cuda.synchronize, dev)
+    ch.profile_enable(False)
 
     prof = ch.profile()
     if rank == 0:
         r = M * 12500.0 / fs
         b_alg = 8.0 + 2.0 * r                                        # bytes per input sample
-        value = world * args.steps * block / dt / 1e6
+        value = multigpu.aggregate_throughput(world, args.steps, block, dt) / 1e6
         roof = None
         if prof:
             name, (ms, n) = max(prof.items(), key=lambda kv: kv[1][0])

@@ -39,7 +39,11 @@ struct pmr_chain_s {
     pmr_chain_cfg cfg;
     pmr_design d;
     int device;
-    hipStream_t stream;
+    hipStream_t stream;              /* back-end stream (channelizer, audio, outputs): what callers synchronise on */
+    hipStream_t stream_fe;           /* front-end stream: block b+1's front end overlaps block b's back end        */
+    hipEvent_t ev_fe[2], ev_be[2];   /* front end / back end of block (parity) finished                            */
+    int overlap;                     /* two-stream pipelining enabled (PMR_OVERLAP=0 disables)                     */
+    uint64_t n_calls;
     unsigned M, res_size, chan_size;
     char err[256];
 
@@ -55,8 +59,9 @@ struct pmr_chain_s {
     cfl *d_dc_state, *d_dc_agg, *d_dc_W;
     cfl *d_z[PMR_MAX_STAGES + 1];    /* z_0 .. z_h, each [keep | new]                         */
     unsigned keep[PMR_MAX_STAGES + 1];
-    cfl *d_xr; size_t xr_cap;
-    float *d_fm, *d_aux1, *d_aux2;
+    cfl *d_xr; uint64_t xr_mask;      /* resampled ring, sample a at d_xr[a & xr_mask]                 */
+    float *d_fm, *d_aux1, *d_aux2;   /* row rings, frame t at ring[(t & fm_mask) * M + k]             */
+    uint64_t fm_mask;
     void *d_scratch; size_t scratch_bytes;
     int16_t *d_pcm; float *d_audio; cfl *d_chan; float *d_rssi, *d_rssi_part;
     size_t rssi_part_cap;
@@ -68,7 +73,7 @@ struct pmr_chain_s {
     int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
     float fe_Kgain, fe_lam_wave, fe_lam_pow16[6];
     float *d_fe_taps, *d_fe_GA, *d_fe_T1, *d_fe_T2, *d_fe_lam_lane;
-    cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V;
+    cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V[2];
     uint64_t *d_fe_stamps;           /* diagnostic per-phase cycle sums (PMR_FE_STAMP)                */
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     unsigned fe_max_tiles;
@@ -76,8 +81,8 @@ struct pmr_chain_s {
     /* host-side counters (all closed form in the number of samples consumed) */
     uint64_t n_raw;                  /* raw samples consumed since reset                      */
     uint32_t arb_phase;              /* resamp_crcf phase, 2^24 per decimated sample          */
-    unsigned xr_fill;                /* valid samples in d_xr (= p*M + leftover)              */
-    uint64_t xr_base;                /* absolute resampled index of d_xr[0]                   */
+    uint64_t xr_abs;                 /* resampled samples produced since reset                */
+    uint64_t frames_done;            /* frames channelized since reset                        */
     unsigned last_ny, last_ns;
     int dbg_on; cfl *d_dbg_xr; float *d_dbg_fm;
 
@@ -133,7 +138,7 @@ static int upload_padded_taps(pmr_chain q, float **p, const float *h, unsigned n
 }
 
 /* ---- profiling helpers: HIP events on the chain's stream around every launch ---- */
-static void prof_begin(pmr_chain q, int slot, prof_pending *pp)
+static void prof_begin(pmr_chain q, int slot, prof_pending *pp, hipStream_t st)
 {
     pp->slot = -1;
     if (!q->prof_on) return;
@@ -143,13 +148,13 @@ static void prof_begin(pmr_chain q, int slot, prof_pending *pp)
         else if (hipEventCreate(&ev[i]) != hipSuccess) return;
     }
     pp->a = ev[0]; pp->b = ev[1]; pp->slot = slot;
-    hipEventRecord(pp->a, q->stream);
+    hipEventRecord(pp->a, st);
 }
 
-static void prof_end(pmr_chain q, prof_pending *pp)
+static void prof_end(pmr_chain q, prof_pending *pp, hipStream_t st)
 {
     if (pp->slot < 0) return;
-    hipEventRecord(pp->b, q->stream);
+    hipEventRecord(pp->b, st);
     if (q->npend == q->cappend) {
         unsigned nc = q->cappend ? 2 * q->cappend : 256;
         prof_pending *np = (prof_pending *)realloc(q->pend, nc * sizeof(*np));
@@ -179,20 +184,22 @@ static void prof_resolve(pmr_chain q)
     q->npend = 0;
 }
 
-#define LAUNCH(slot, expr) do { prof_pending pp_; prof_begin(q, (slot), &pp_); int rc_ = (expr); prof_end(q, &pp_); \
-        if (rc_) return fail(q, PMR_EHIP, k_names[slot], (hipError_t)rc_); } while (0)
+#define LAUNCH_ON(st, slot, expr) do { prof_pending pp_; prof_begin(q, (slot), &pp_, (st)); int rc_ = (expr); \
+        prof_end(q, &pp_, (st)); if (rc_) return fail(q, PMR_EHIP, k_names[slot], (hipError_t)rc_); } while (0)
+#define LAUNCH(slot, expr) LAUNCH_ON(q->stream, slot, expr)
+#define LAUNCH_FE(slot, expr) LAUNCH_ON(q->stream_fe, slot, expr)
 
 /* keep the last `keep` elements of a [src+keep]-element buffer at its front (history for the next call) */
-static int shift_front(pmr_chain q, void *buf, size_t elem, size_t src, size_t keep)
+static int shift_front(pmr_chain q, hipStream_t st, void *buf, size_t elem, size_t src, size_t keep)
 {
     if (src == 0 || keep == 0) return PMR_OK;
     char *b = (char *)buf;
     if (src >= keep) {
-        HIPCHK(hipMemcpyAsync(b, b + src * elem, keep * elem, hipMemcpyDeviceToDevice, q->stream), "shift");
+        HIPCHK(hipMemcpyAsync(b, b + src * elem, keep * elem, hipMemcpyDeviceToDevice, st), "shift");
     } else {
         if (keep * elem > q->scratch_bytes) return fail(q, PMR_EINVAL, "scratch too small", hipSuccess);
-        HIPCHK(hipMemcpyAsync(q->d_scratch, b + src * elem, keep * elem, hipMemcpyDeviceToDevice, q->stream), "shift");
-        HIPCHK(hipMemcpyAsync(b, q->d_scratch, keep * elem, hipMemcpyDeviceToDevice, q->stream), "shift");
+        HIPCHK(hipMemcpyAsync(q->d_scratch, b + src * elem, keep * elem, hipMemcpyDeviceToDevice, st), "shift");
+        HIPCHK(hipMemcpyAsync(b, q->d_scratch, keep * elem, hipMemcpyDeviceToDevice, st), "shift");
     }
     return PMR_OK;
 }
@@ -319,7 +326,8 @@ static int fe_init(pmr_chain q)
     }
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeA, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeB, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_fe_V, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
+    for (int i = 0; i < 2; i++)
+        if ((rc = dev_alloc(q, (void **)&q->d_fe_V[i], (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeL, sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeE, sizeof(cfl)))) return rc;
     q->fe_sel = 0;
@@ -381,17 +389,23 @@ static int chain_init(pmr_chain q)
         size_t cap = (size_t)q->keep[e] + ((size_t)mb >> e) + 2;
         if ((rc = dev_alloc(q, (void **)&q->d_z[e], cap * sizeof(cfl)))) return rc;
     }
-    q->xr_cap = (size_t)(p + 2) * M + q->res_size + 16;
-    if ((rc = dev_alloc(q, (void **)&q->d_xr, q->xr_cap * sizeof(cfl)))) return rc;
-    const size_t fm_frames = (size_t)FM_HIST_FRAMES + q->chan_size + PMR_AUDIO_R + 8;
-    if ((rc = dev_alloc(q, (void **)&q->d_fm, fm_frames * M * sizeof(float)))) return rc;
-    if (q->cfg.deemph_fir || q->cfg.lowpass) {
-        const size_t ax = (size_t)AUX_HIST_FRAMES + q->chan_size + PMR_AUDIO_R + 8;
-        if ((rc = dev_alloc(q, (void **)&q->d_aux1, ax * M * sizeof(float)))) return rc;
-        if ((rc = dev_alloc(q, (void **)&q->d_aux2, ax * M * sizeof(float)))) return rc;
+    /* rings sized for the filter history plus TWO blocks, so block b+1's front end never overwrites what block b's
+     * back end still reads */
+    {
+        uint64_t need = (uint64_t)(p + 1) * M + 2ull * q->res_size + 64, cap = 1;
+        while (cap < need) cap <<= 1;
+        q->xr_mask = cap - 1;
+        if ((rc = dev_alloc(q, (void **)&q->d_xr, (size_t)cap * sizeof(cfl)))) return rc;
+        need = (uint64_t)FM_HIST_FRAMES + 2ull * q->chan_size + 64; cap = 1;
+        while (cap < need) cap <<= 1;
+        q->fm_mask = cap - 1;
+        if ((rc = dev_alloc(q, (void **)&q->d_fm, (size_t)cap * M * sizeof(float)))) return rc;
+        if (q->cfg.deemph_fir || q->cfg.lowpass) {
+            if ((rc = dev_alloc(q, (void **)&q->d_aux1, (size_t)cap * M * sizeof(float)))) return rc;
+            if ((rc = dev_alloc(q, (void **)&q->d_aux2, (size_t)cap * M * sizeof(float)))) return rc;
+        }
     }
-    q->scratch_bytes = (size_t)FM_HIST_FRAMES * M * sizeof(float);
-    if ((size_t)(p + 1) * M * sizeof(cfl) > q->scratch_bytes) q->scratch_bytes = (size_t)(p + 1) * M * sizeof(cfl);
+    q->scratch_bytes = 4096;         /* history shifts of the staged front end only (<= 40 samples each) */
     if ((rc = dev_alloc(q, &q->d_scratch, q->scratch_bytes))) return rc;
     const size_t out_n = (size_t)M * q->chan_size;
     if ((rc = dev_alloc(q, (void **)&q->d_pcm, out_n * sizeof(int16_t)))) return rc;
@@ -407,7 +421,7 @@ static int chain_init(pmr_chain q)
         q->chan_small = !(env && !strcmp(env, "generic")) && pmr_channelize_small_supported(M, p, d->nco_period);
     }
 
-    q->n_raw = 0; q->arb_phase = 0; q->xr_fill = p * M; q->xr_base = 0;
+    q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "init sync");
     return PMR_OK;
 }
@@ -435,9 +449,17 @@ pmr_chain pmr_chain_create(const pmr_chain_cfg *cfg)
     }
     q->M = cfg->num_channels;
     pmr_design_buffer_sizes(&q->d, cfg->max_block, &q->res_size, &q->chan_size);
-    if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&q->stream_fe, hipStreamNonBlocking) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
     }
+    for (int i = 0; i < 2; i++) {
+        if (hipEventCreateWithFlags(&q->ev_fe[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q->ev_be[i], hipEventDisableTiming) != hipSuccess) {
+            pmr_design_free(&q->d); free(q); return NULL;
+        }
+    }
+    { const char *ov = getenv("PMR_OVERLAP"); q->overlap = !(ov && !strcmp(ov, "0")); }
     if (chain_init(q) != PMR_OK) {
         fprintf(stderr, "pmr_chain_create: %s\n", q->err);
         pmr_chain_destroy(q);
@@ -450,8 +472,11 @@ int pmr_chain_destroy(pmr_chain q)
 {
     if (!q) return PMR_OK;
     hipSetDevice(q->device);
+    if (q->stream_fe) hipStreamSynchronize(q->stream_fe);
     if (q->stream) hipStreamSynchronize(q->stream);
     prof_resolve(q);
+    for (int i = 0; i < 2; i++) { if (q->ev_fe[i]) hipEventDestroy(q->ev_fe[i]); if (q->ev_be[i]) hipEventDestroy(q->ev_be[i]); }
+    if (q->stream_fe) hipStreamDestroy(q->stream_fe);
     for (unsigned i = 0; i < q->npool; i++) hipEventDestroy(q->pool[i]);
     free(q->pool); free(q->pend);
     for (unsigned g = 0; g < PMR_MAX_STAGES; g++) if (q->d_hb_h1[g]) hipFree(q->d_hb_h1[g]);
@@ -461,7 +486,8 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_dc_agg, q->d_dc_W, q->d_xr, q->d_fm, q->d_aux1, q->d_aux2, q->d_scratch, q->d_pcm,
                      q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
-                     q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V };
+                     q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
+                     q->d_fe_V[1] };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     if (q->stream) hipStreamDestroy(q->stream);
     pmr_design_free(&q->d);
@@ -472,23 +498,25 @@ int pmr_chain_destroy(pmr_chain q)
 int pmr_chain_reset(pmr_chain q)
 {
     if (!q) return PMR_EINVAL;
-    const unsigned M = q->M, p = q->d.pfb_p, h = q->d.num_stages;
+    const unsigned M = q->M, h = q->d.num_stages;
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
     HIPCHK(hipMemsetAsync(q->d_dc_state, 0, sizeof(cfl), q->stream), "reset");
     for (unsigned e = 0; e <= h; e++)
         HIPCHK(hipMemsetAsync(q->d_z[e], 0, (size_t)q->keep[e] * sizeof(cfl), q->stream), "reset");
-    HIPCHK(hipMemsetAsync(q->d_xr, 0, q->xr_cap * sizeof(cfl), q->stream), "reset");
-    HIPCHK(hipMemsetAsync(q->d_fm, 0, (size_t)FM_HIST_FRAMES * M * sizeof(float), q->stream), "reset");
+    HIPCHK(hipStreamSynchronize(q->stream_fe), "reset");
+    HIPCHK(hipStreamSynchronize(q->stream), "reset");
+    HIPCHK(hipMemsetAsync(q->d_xr, 0, (size_t)(q->xr_mask + 1) * sizeof(cfl), q->stream), "reset");
+    HIPCHK(hipMemsetAsync(q->d_fm, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
     if (q->d_aux1) {
-        HIPCHK(hipMemsetAsync(q->d_aux1, 0, (size_t)AUX_HIST_FRAMES * M * sizeof(float), q->stream), "reset");
-        HIPCHK(hipMemsetAsync(q->d_aux2, 0, (size_t)AUX_HIST_FRAMES * M * sizeof(float), q->stream), "reset");
+        HIPCHK(hipMemsetAsync(q->d_aux1, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
+        HIPCHK(hipMemsetAsync(q->d_aux2, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
     }
     if (q->fe_on) for (int i = 0; i < 2; i++) {
         HIPCHK(hipMemsetAsync(q->d_fe_hist[i], 0, (size_t)q->fe_hcap * sizeof(cfl), q->stream), "reset");
         HIPCHK(hipMemsetAsync(q->d_fe_vstate[i], 0, sizeof(cfl), q->stream), "reset");
     }
     q->fe_sel = 0;
-    q->n_raw = 0; q->arb_phase = 0; q->xr_fill = p * M; q->xr_base = 0; q->last_ny = q->last_ns = 0;
+    q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
     return PMR_OK;
 }
@@ -501,6 +529,7 @@ void *pmr_chain_stream(pmr_chain q) { return q ? (void *)q->stream : NULL; }
 int pmr_chain_synchronize(pmr_chain q)
 {
     if (!q) return PMR_EINVAL;
+    HIPCHK(hipStreamSynchronize(q->stream_fe), "hipStreamSynchronize");
     HIPCHK(hipStreamSynchronize(q->stream), "hipStreamSynchronize");
     prof_resolve(q);
     return PMR_OK;
@@ -524,7 +553,8 @@ static void plan_core(unsigned num_stages, uint32_t arb_step, unsigned M, uint64
 
 static void plan_counts(const struct pmr_chain_s *q, unsigned n_in, unsigned *ny_out, unsigned *ns_out)
 {
-    plan_core(q->d.num_stages, q->d.arb_step, q->M, q->n_raw, q->arb_phase, q->xr_fill - q->d.pfb_p * q->M, n_in,
+    plan_core(q->d.num_stages, q->d.arb_step, q->M, q->n_raw, q->arb_phase,
+              (unsigned)(q->xr_abs - q->frames_done * q->M), n_in,
               ny_out, ns_out, NULL);
 }
 
@@ -542,10 +572,10 @@ static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigne
     const unsigned l_last = n_in - (ntiles - 1) * PMR_DC_TILE;
     const float lam_last = (float)pow(d->dc_lambda, (double)l_last);
     const float inv_last = (float)pow(d->dc_lambda, -(double)(PMR_DC_TILE - l_last));
-    LAUNCH(K_DC_AGG, pmr_launch_dc_agg(q->stream, d_iq, n_in, q->d_dc_agg, &q->dcc, q->d_lam_thread_pow));
-    LAUNCH(K_DC_SCAN, pmr_launch_dc_scan(q->stream, q->d_dc_agg, ntiles, q->d_dc_W, q->d_dc_state, &q->dcc,
+    LAUNCH_FE(K_DC_AGG, pmr_launch_dc_agg(q->stream_fe, d_iq, n_in, q->d_dc_agg, &q->dcc, q->d_lam_thread_pow));
+    LAUNCH_FE(K_DC_SCAN, pmr_launch_dc_scan(q->stream_fe, q->d_dc_agg, ntiles, q->d_dc_W, q->d_dc_state, &q->dcc,
                                          q->d_lam_tile_idx_pow, lam_last, inv_last));
-    LAUNCH(K_DC_APPLY, pmr_launch_dc_apply(q->stream, d_iq, n_in, q->d_dc_W, q->d_z[0] + q->keep[0], &q->dcc,
+    LAUNCH_FE(K_DC_APPLY, pmr_launch_dc_apply(q->stream_fe, d_iq, n_in, q->d_dc_W, q->d_z[0] + q->keep[0], &q->dcc,
                                            q->d_lam_thread_pow));
 
     uint64_t c_e = q->n_raw;         /* absolute count of z_e samples before this call */
@@ -554,10 +584,10 @@ static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigne
         const unsigned g = h - 1 - e;
         const unsigned n_out = (unsigned)(((c_e + n_e) >> 1) - (c_e >> 1));
         const int par = (int)(c_e & 1u);
-        LAUNCH(K_HALFBAND, pmr_launch_halfband(q->stream, q->d_z[e], q->d_z[e + 1] + q->keep[e + 1], n_out,
+        LAUNCH_FE(K_HALFBAND, pmr_launch_halfband(q->stream_fe, q->d_z[e], q->d_z[e + 1] + q->keep[e + 1], n_out,
                                                (int)q->keep[e], par, (int)d->m_stage[g], q->d_hb_h1[g],
                                                e == h - 1 ? d->zeta : 1.0f));
-        int rc = shift_front(q, q->d_z[e], sizeof(cfl), n_e, q->keep[e]);
+        int rc = shift_front(q, q->stream_fe, q->d_z[e], sizeof(cfl), n_e, q->keep[e]);
         if (rc) return rc;
         c_e >>= 1; n_e = n_out;
     }
@@ -566,11 +596,10 @@ static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigne
     unsigned ny = 0;
     if (n_e && (uint64_t)q->arb_phase < span)
         ny = (unsigned)((span - q->arb_phase + d->arb_step - 1) / d->arb_step);
-    if ((size_t)q->xr_fill + ny > q->xr_cap) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
-    LAUNCH(K_ARB, pmr_launch_arb(q->stream, q->d_z[h], q->d_xr + q->xr_fill, ny, q->arb_phase, d->arb_step,
-                                 q->d_arb_bank, (int)q->keep[h]));
+    LAUNCH_FE(K_ARB, pmr_launch_arb(q->stream_fe, q->d_z[h], q->d_xr, q->xr_abs, q->xr_mask, ny, q->arb_phase,
+                                    d->arb_step, q->d_arb_bank, (int)q->keep[h]));
     q->arb_phase = (uint32_t)((uint64_t)q->arb_phase + (uint64_t)ny * d->arb_step - span);
-    int rc = shift_front(q, q->d_z[h], sizeof(cfl), n_e, q->keep[h]);
+    int rc = shift_front(q, q->stream_fe, q->d_z[h], sizeof(cfl), n_e, q->keep[h]);
     if (rc) return rc;
     *ny_out = ny;
     return PMR_OK;
@@ -596,7 +625,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
 
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
-    p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr + q->xr_fill;
+    p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr; p.out_pos0 = q->xr_abs; p.out_mask = q->xr_mask;
     p.probeA = q->d_fe_probeA; p.probeB = q->d_fe_probeB; p.probeL = q->d_fe_probeL; p.probeE = q->d_fe_probeE;
     p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
     p.n_in = n_in; p.ny = ny; p.Q = Q; p.phi0 = q->arb_phase; p.step = d->arb_step;
@@ -610,7 +639,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
         p.stamps = q->d_fe_stamps;
     }
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
-    LAUNCH(K_FE, pmr_launch_frontend(q->stream, &p, ntiles, q->fe_nt, q->fe_spt));
+    LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles, q->fe_nt, q->fe_spt));
 
     pmr_fe_tiles_params t;
     memset(&t, 0, sizeof(t));
@@ -620,19 +649,19 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     if (kterms < 1.0) kterms = 1.0;
     if (kterms > 1e6) kterms = 1e6;
     t.probeA = q->d_fe_probeA; t.probeB = q->d_fe_probeB; t.probeL = q->d_fe_probeL; t.probeE = q->d_fe_probeE;
-    t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V;
+    t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V[q->n_calls & 1];
     t.ntiles = ntiles; t.K = (unsigned)kterms; t.c_end = c_end;
     t.rho = (float)rho; t.lamHh = (float)pow(lam, (double)q->fe_Hh); t.inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
     t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
-    LAUNCH(K_FE_TILES, pmr_launch_fe_tiles(q->stream, &t));
+    LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
 
-    if (ny) {
+    if (ny && !(q->chan_small && !q->dbg_on)) {  /* else: the small-M channelizer applies the carry while staging */
         pmr_fe_fix_params f;
         memset(&f, 0, sizeof(f));
-        f.xr = q->d_xr + q->xr_fill; f.V = q->d_fe_V; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
+        f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[q->n_calls & 1]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
         f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
         f.Kgain = q->fe_Kgain;
-        LAUNCH(K_FE_FIX, pmr_launch_fe_dcfix(q->stream, &f));
+        LAUNCH_FE(K_FE_FIX, pmr_launch_fe_dcfix(q->stream_fe, &f));
     }
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
@@ -641,6 +670,17 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
 }
 
 /* ------------------------------------------------------------------------------------------- */
+
+/* copy `n` elements starting at absolute ring index `pos` into a linear device buffer (debug capture) */
+static int ring_to_linear(pmr_chain q, void *dst, const void *ring, uint64_t mask, uint64_t pos, size_t n, size_t elem)
+{
+    const uint64_t cap = mask + 1, i0 = pos & mask;
+    const size_t first = (size_t)((cap - i0) < n ? (cap - i0) : n);
+    HIPCHK(hipMemcpyAsync(dst, (const char *)ring + i0 * elem, first * elem, hipMemcpyDeviceToDevice, q->stream), "dbg");
+    if (first < n)
+        HIPCHK(hipMemcpyAsync((char *)dst + first * elem, ring, (n - first) * elem, hipMemcpyDeviceToDevice, q->stream), "dbg");
+    return PMR_OK;
+}
 
 int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
                                    unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db)
@@ -659,80 +699,99 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
     if (n_frames) *n_frames = ns_plan;
     if (ns_plan > q->chan_size) return fail(q, PMR_ERANGE, "frame count exceeds max_frames", hipSuccess);
     if (ns_plan > pcm_stride && (d_pcm || d_audio || d_chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
-    if ((size_t)q->xr_fill + ny_plan > q->xr_cap) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
+    if (ny_plan > q->res_size) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
 
+    /* ---- front end of this block on stream_fe.  It may run while the back end of the PREVIOUS block is still
+     * busy on q->stream; it must not start before the back end of the block before that has released its part
+     * of the rings (they hold history + two blocks). ---- */
+    const unsigned par = (unsigned)(q->n_calls & 1);
+    if (q->n_calls >= 2) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
+    if (!q->overlap && q->n_calls >= 1) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par ^ 1], 0), "wait back end");
+    const uint32_t phi0 = q->arb_phase;          /* resampler phase before this block (dc carry bookkeeping) */
+    const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
     if ((rc = q->fe_on ? frontend_fused(q, d_iq, n_in, &ny) : frontend_staged(q, d_iq, n_in, &ny))) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
+    HIPCHK(hipEventRecord(q->ev_fe[par], q->stream_fe), "record");
     q->n_raw += n_in;
+    q->xr_abs += ny;
     q->last_ny = ny;
+
+    /* ---- back end on q->stream ---- */
+    HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
     if (q->dbg_on && ny)
-        HIPCHK(hipMemcpyAsync(q->d_dbg_xr, q->d_xr + q->xr_fill, (size_t)ny * sizeof(cfl), hipMemcpyDeviceToDevice,
-                              q->stream), "debug copy");
+        if ((rc = ring_to_linear(q, q->d_dbg_xr, q->d_xr, q->xr_mask, xr_abs0, ny, sizeof(cfl)))) return rc;
 
     /* ring carry (:797,:804): frames of M samples, 0..M-1 remainder stays for the next call */
-    const unsigned leftover = q->xr_fill - p * M;
-    const unsigned avail = leftover + ny;
-    const unsigned ns = avail / M;
-    const unsigned total = q->xr_fill + ny;
+    const unsigned ns = (unsigned)((q->xr_abs - q->frames_done * M) / M);
+    const int64_t frame0 = (int64_t)q->frames_done;
     q->last_ns = ns;
 
     if (ns) {
-        float *fm_new = q->d_fm + (size_t)FM_HIST_FRAMES * M;
         unsigned ntiles = 0;
-        if (q->chan_small)
-            LAUNCH(K_CHANNELIZE_SMALL,
-                   pmr_launch_channelize_small(q->stream, q->d_xr, total, ns, M, p, q->d_pfb_taps_t, q->d_fft_tw,
-                                               q->d_nco_cs, d->nco_period, (unsigned)(q->xr_base % d->nco_period),
-                                               d->fm_ref, fm_new, d_chan_out, pcm_stride,
-                                               d_rssi_db ? q->d_rssi_part : NULL, &ntiles));
-        else
-            LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, q->d_xr, ns, M, p, q->d_pfb_taps_t, q->d_fft_tw,
-                                                       q->d_nco_cs, d->nco_period,
-                                                       (unsigned)(q->xr_base % d->nco_period), d->fm_ref, fm_new,
-                                                       d_chan_out, pcm_stride, d_rssi_db ? q->d_rssi_part : NULL,
-                                                       &ntiles));
-        if (q->dbg_on)
-            HIPCHK(hipMemcpyAsync(q->d_dbg_fm, fm_new, (size_t)ns * M * sizeof(float), hipMemcpyDeviceToDevice,
-                                  q->stream), "debug copy");
+        pmr_chan_params c;
+        memset(&c, 0, sizeof(c));
+        c.xr = q->d_xr; c.xr_mask = q->xr_mask; c.frame0 = frame0; c.xr_end = q->xr_abs;
+        c.fm = q->d_fm; c.fm_mask = q->fm_mask; c.ns = ns; c.M = M; c.p = p;
+        c.taps_t = q->d_pfb_taps_t; c.fft_tw = q->d_fft_tw; c.nco_cs = q->d_nco_cs; c.nco_period = d->nco_period;
+        c.fm_ref = d->fm_ref; c.chan_out = d_chan_out; c.chan_stride = pcm_stride;
+        c.rssi_part = d_rssi_db ? q->d_rssi_part : NULL;
+        if (q->chan_small) {
+            const int fuse_fix = q->fe_on && ny && !q->dbg_on;
+            if (fuse_fix) {                      /* deferred dc carry of the fused front end, applied while staging */
+                c.V = q->d_fe_V[par]; c.GA = q->d_fe_GA; c.T1 = q->d_fe_T1; c.T2 = q->d_fe_T2;
+                c.fix_abs0 = xr_abs0; c.fix_ny = ny; c.TQ = (unsigned)q->fe_TQ; c.HhQ = (unsigned)q->fe_HhQ;
+                c.phi0 = phi0; c.step = d->arb_step; c.Kgain = q->fe_Kgain;
+            }
+            LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles));
+        } else {
+            LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles));
+        }
+        if (q->dbg_on) {
+            /* discriminator rows of this block, time-major, linearised */
+            if ((rc = ring_to_linear(q, q->d_dbg_fm, q->d_fm, q->fm_mask, (uint64_t)frame0, ns, (size_t)M * sizeof(float))))
+                return rc;
+        }
         if (d_rssi_db)
             LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->d_rssi_part, ntiles, M, ns, (float *)d_rssi_db));
 
         /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906) */
         if (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass) {
             const int more = q->cfg.deemph_fir || q->cfg.lowpass;
-            float *a1_new = q->d_aux1 ? q->d_aux1 + (size_t)AUX_HIST_FRAMES * M : NULL;
-            float *a2_new = q->d_aux2 ? q->d_aux2 + (size_t)AUX_HIST_FRAMES * M : NULL;
-            LAUNCH(K_FIR_HP, pmr_launch_fir_tm(q->stream, fm_new, ns, M, q->d_hp_pad, q->hp_len, q->cfg.audio_gain,
-                                               !q->cfg.deemph_fir, d->de_b0, d->de_b1, d->de_a1,
-                                               more ? a1_new : NULL, more ? NULL : (int16_t *)d_pcm,
+            LAUNCH(K_FIR_HP, pmr_launch_fir_tm(q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
+                                               q->cfg.audio_gain, !q->cfg.deemph_fir, d->de_b0, d->de_b1, d->de_a1,
+                                               more ? q->d_aux1 : NULL, more ? NULL : (int16_t *)d_pcm,
                                                more ? NULL : (float *)d_audio, pcm_stride));
-            float *cur = a1_new;
+            const float *cur = q->d_aux1;
             if (q->cfg.deemph_fir) {
                 const int last = !q->cfg.lowpass;
-                LAUNCH(K_FIR_DE, pmr_launch_fir_tm(q->stream, cur, ns, M, q->d_de_pad, q->de_len, 1.0f, 0, 0.f, 0.f,
-                                                   0.f, last ? NULL : a2_new, last ? (int16_t *)d_pcm : NULL,
-                                                   last ? (float *)d_audio : NULL, pcm_stride));
-                cur = a2_new;
+                LAUNCH(K_FIR_DE, pmr_launch_fir_tm(q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
+                                                   1.0f, 0, 0.f, 0.f, 0.f, last ? NULL : q->d_aux2,
+                                                   last ? (int16_t *)d_pcm : NULL, last ? (float *)d_audio : NULL,
+                                                   pcm_stride));
+                cur = q->d_aux2;
             }
             if (q->cfg.lowpass) {
-                LAUNCH(K_FIR_LP, pmr_launch_fir_tm(q->stream, cur, ns, M, q->d_lp_pad, q->lp_len, 1.0f, 0, 0.f, 0.f,
-                                                   0.f, NULL, (int16_t *)d_pcm, (float *)d_audio, pcm_stride));
-            }
-            if (more) {
-                if ((rc = shift_front(q, q->d_aux1, sizeof(float), (size_t)ns * M, (size_t)AUX_HIST_FRAMES * M))) return rc;
-                if ((rc = shift_front(q, q->d_aux2, sizeof(float), (size_t)ns * M, (size_t)AUX_HIST_FRAMES * M))) return rc;
+                LAUNCH(K_FIR_LP, pmr_launch_fir_tm(q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
+                                                   1.0f, 0, 0.f, 0.f, 0.f, NULL, (int16_t *)d_pcm, (float *)d_audio,
+                                                   pcm_stride));
             }
         }
-        if ((rc = shift_front(q, q->d_fm, sizeof(float), (size_t)ns * M, (size_t)FM_HIST_FRAMES * M))) return rc;
     }
-
-    /* keep p frames of history + the new remainder at the front of the resampled stream */
-    const unsigned keep = p * M + (avail - ns * M);
-    const unsigned src = total - keep;
-    if ((rc = shift_front(q, q->d_xr, sizeof(cfl), src, keep))) return rc;
-    q->xr_fill = keep;
-    q->xr_base += src;
+    if (q->chan_small && q->fe_on && ny && !q->dbg_on) {
+        /* The staging pass corrected its private copy only.  What later blocks will re-read as history -- the last
+         * (p+1)*M samples -- gets its dc carry in place now (after the channelizer, same stream). */
+        const unsigned keep = (p + 1) * M;
+        pmr_fe_fix_params f;
+        memset(&f, 0, sizeof(f));
+        f.xr = q->d_xr; f.pos0 = xr_abs0; f.mask = q->xr_mask; f.V = q->d_fe_V[par]; f.GA = q->d_fe_GA;
+        f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2; f.ny = ny; f.j0 = ny > keep ? ny - keep : 0;
+        f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = phi0; f.step = d->arb_step; f.Kgain = q->fe_Kgain;
+        LAUNCH(K_FE_FIX, pmr_launch_fe_dcfix(q->stream, &f));
+    }
+    q->frames_done += ns;
+    HIPCHK(hipEventRecord(q->ev_be[par], q->stream), "record");
+    q->n_calls++;
     return PMR_OK;
 }
 
@@ -742,8 +801,10 @@ int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, 
     if (!q) return PMR_EINVAL;
     if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
-    if (n_in)
-        HIPCHK(hipMemcpyAsync(q->d_in, iq, (size_t)n_in * sizeof(cfl), hipMemcpyHostToDevice, q->stream), "H2D");
+    if (n_in) {
+        /* d_in is re-used every call: the previous block's front end (same stream) has consumed it by then */
+        HIPCHK(hipMemcpyAsync(q->d_in, iq, (size_t)n_in * sizeof(cfl), hipMemcpyHostToDevice, q->stream_fe), "H2D");
+    }
     unsigned ns = 0;
     const unsigned S = q->chan_size;
     int rc = pmr_chain_process_block_device(q, q->d_in, n_in, (pcm || audio) ? q->d_pcm : NULL,

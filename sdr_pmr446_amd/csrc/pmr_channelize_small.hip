@@ -55,39 +55,61 @@ static __device__ __forceinline__ void fft_dit(cf (&x)[M], const cf *__restrict_
 #define CS_NT 256
 #define CS_FPT 2                          /* frames per thread */
 
+// deferred dc carry of the fused front end for resampled sample j of this call (pmr_frontend.hip, k_fe_dcfix):
+//   x -= V_c * K * mu^q' * GA[idx]
+static __device__ __forceinline__ void dc_fix(float &xr_, float &xi_, unsigned long long j, const pmr_chan_params &q)
+{
+    const unsigned long long ph = (unsigned long long)q.phi0 + j * q.step;
+    const unsigned qd = (unsigned)(ph >> 24);
+    const unsigned idx = (unsigned)(ph & 0xffffffu) >> 16;
+    const unsigned c = qd / q.TQ;
+    const unsigned ql = qd - c * q.TQ + q.HhQ;
+    const float g = q.Kgain * q.GA[idx] * (q.T1[ql >> 5] * q.T2[ql & 31]);
+    const cf V = ((const cf *)q.V)[c];
+    xr_ = fmaf(-V.x, g, xr_);
+    xi_ = fmaf(-V.y, g, xi_);
+}
+
 template <int M>
-__global__ __launch_bounds__(CS_NT) void k_channelize_small(const cf *__restrict__ xr, unsigned n_valid,
-                                                            unsigned ns, unsigned p,
-                                                            const float *__restrict__ taps_t,
-                                                            const cf *__restrict__ fft_tw,
-                                                            const cf *__restrict__ nco_cs, unsigned nco_mask,
-                                                            unsigned nco_idx0, float fm_ref,
-                                                            float *__restrict__ fm_out, cf *__restrict__ chan_out,
-                                                            unsigned chan_stride, float *__restrict__ rssi_part)
+__global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 {
     constexpr int L2M = log2c<M>::v;
     constexpr int FS = M + 2;                             // padded frame row in LDS (cf elements): M*8 + 16 bytes
     constexpr int NFT = CS_NT * CS_FPT;                   // frames computed per tile (local frame 0 = frame t0-1)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *xs = reinterpret_cast<cf *>(smem);                // [(NFT + p - 1)][FS]
+    const cf *__restrict__ xr = (const cf *)q.xr;
+    const cf *__restrict__ nco_cs = (const cf *)q.nco_cs;
+    const cf *__restrict__ fft_tw = (const cf *)q.fft_tw;
+    const float *__restrict__ taps_t = q.taps_t;
+    const unsigned p = q.p, ns = q.ns, nco_mask = q.nco_period - 1;
+    const float fm_ref = q.fm_ref;
+    cf *__restrict__ chan_out = (cf *)q.chan_out;
+    const unsigned chan_stride = q.chan_stride;
+    float *__restrict__ rssi_part = q.rssi_part;
 
     const int tid = threadIdx.x;
-    const long t0 = (long)blockIdx.x * (NFT - 1);         // first NEW frame of this tile
-    // local frame l <-> frame t0-1+l; it needs buffer frames (t0 + l) .. (t0 + l + p - 1)   [history = p frames]
-    const unsigned nfl = NFT + p - 1;                     // buffer frames staged
-    const size_t s_base = (size_t)t0 * M;                 // first staged sample in xr
+    const long t0 = (long)blockIdx.x * (NFT - 1);         // first NEW frame of this tile, relative to q.frame0
+    // local frame l <-> absolute frame frame0 + t0 - 1 + l; it needs absolute frames (.. - (p-1)) .. itself
+    const unsigned nfl = NFT + p - 1;                     // frames staged
+    const long long s_base = ((long long)q.frame0 + t0 - (long long)p) * M;   // absolute index of the first staged sample
 
-    // ---- stage: HBM -> NCO mix -> LDS (two samples per lane per load) ----
+    // ---- stage: HBM ring -> (dc carry) -> NCO mix -> LDS (two samples per lane per load) ----
     {
         const unsigned units = nfl * (M / 2);
         // NCO phase index of a lane's sample pair is the same for every iteration: 2*CS_NT is a multiple of the period
-        const unsigned i0 = (nco_idx0 + (unsigned)s_base + 2u * tid) & nco_mask;
+        const unsigned i0 = ((unsigned)s_base + 2u * tid) & nco_mask;
         const cf c0 = nco_cs[i0], c1 = nco_cs[(i0 + 1) & nco_mask];
+        const long long xr_end = (long long)q.xr_end, fix0 = (long long)q.fix_abs0;
         for (unsigned u = tid; u < units; u += CS_NT) {
-            const size_t s = s_base + 2 * (size_t)u;
+            const long long a = s_base + 2 * (long long)u;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s + 1 < n_valid) v = *reinterpret_cast<const float4 *>(xr + s);
-            else if (s < n_valid) { const cf a = xr[s]; v.x = a.x; v.y = a.y; }
+            if (a >= 0 && a + 1 < xr_end) v = *reinterpret_cast<const float4 *>(xr + ((unsigned long long)a & q.xr_mask));
+            else if (a >= 0 && a < xr_end) { const cf s1 = xr[(unsigned long long)a & q.xr_mask]; v.x = s1.x; v.y = s1.y; }
+            if (q.V && a + 1 >= fix0) {                   // samples produced by THIS call still miss their dc carry
+                if (a >= fix0 && a < xr_end) dc_fix(v.x, v.y, (unsigned long long)(a - fix0), q);
+                if (a + 1 < xr_end) dc_fix(v.z, v.w, (unsigned long long)(a + 1 - fix0), q);
+            }
             float4 o;
             o.x = fmaf(v.x, c0.x, v.y * c0.y);            // x * conj(e^{j theta})
             o.y = fmaf(v.y, c0.x, -(v.x * c0.y));
@@ -165,7 +187,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(const cf *__restrict
     const bool outA = tid > 0 && tA < (long)ns;
     const bool outB = tB < (long)ns;
     if (outA) {
-        float *o = fm_out + (size_t)tA * M;
+        float *o = q.fm + ((unsigned long long)(q.frame0 + tA) & q.fm_mask) * M;
 #pragma unroll
         for (int k = 0; k < M; k += 4) {
             float4 r;
@@ -179,7 +201,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(const cf *__restrict
         }
     }
     if (outB) {
-        float *o = fm_out + (size_t)tB * M;
+        float *o = q.fm + ((unsigned long long)(q.frame0 + tB) & q.fm_mask) * M;
 #pragma unroll
         for (int k = 0; k < M; k += 4) {
             float4 r;
@@ -227,25 +249,19 @@ extern "C" int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned n
     return M == 16 && p >= 2 && p <= 64 && nco_period && (2u * CS_NT) % nco_period == 0;
 }
 
-extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const void *xr, unsigned n_valid, unsigned ns, unsigned M,
-                                           unsigned p, const float *taps_t, const float *fft_tw, const float *nco_cs,
-                                           unsigned nco_period, unsigned nco_idx0, float fm_ref, float *fm_out,
-                                           void *chan_out, unsigned chan_stride, float *rssi_part,
-                                           unsigned *ntiles_out)
+extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out)
 {
-    const unsigned ntiles = pmr_channelize_small_tiles(ns);
+    const unsigned ntiles = pmr_channelize_small_tiles(p->ns);
     if (ntiles_out) *ntiles_out = ntiles;
-    if (!ns) return 0;
-    if (M != 16) return (int)hipErrorInvalidValue;
-    const size_t lds = (size_t)(CS_NT * CS_FPT + p - 1) * (M + 2) * sizeof(cf);
+    if (!p->ns) return 0;
+    if (p->M != 16) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)(CS_NT * CS_FPT + p->p - 1) * (p->M + 2) * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_small<16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_channelize_small<16>, dim3(ntiles), dim3(CS_NT), lds, (hipStream_t)s, (const cf *)xr, n_valid,
-                       ns, p, taps_t, (const cf *)fft_tw, (const cf *)nco_cs, nco_period - 1, nco_idx0, fm_ref, fm_out,
-                       (cf *)chan_out, chan_stride, rssi_part);
+    hipLaunchKernelGGL(k_channelize_small<16>, dim3(ntiles), dim3(CS_NT), lds, (hipStream_t)s, *p);
     return (int)hipGetLastError();
 }

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? FE_WAVES_512 : 4) void k_frontend(p
                 cf y = cfm(0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < 14; k++) y = cfma(bk[k], buf[lidx_rt(ql - 13 + k, g_shift)], y);
-                out[j] = y;
+                out[(p.out_pos0 + j) & p.out_mask] = y;
             }
         }
     }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_fe_tiles(pmr_fe_tiles_params p)
 // resampled-domain dc correction: xr[j] -= V_c * K * mu^q' * GA[idx_j]
 __global__ __launch_bounds__(256) void k_fe_dcfix(pmr_fe_fix_params p)
 {
-    const unsigned j = blockIdx.x * 256u + threadIdx.x;
+    const unsigned j = p.j0 + blockIdx.x * 256u + threadIdx.x;
     if (j >= p.ny) return;
     const unsigned long long ph = (unsigned long long)p.phi0 + (unsigned long long)j * p.step;
     const unsigned q = (unsigned)(ph >> 24);
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_fe_dcfix(pmr_fe_fix_params p)
     const unsigned ql = q - c * p.TQ + p.HhQ;
     const float g = p.Kgain * p.GA[idx] * (p.T1[ql >> 5] * p.T2[ql & 31]);
     const cf V = ((const cf *)p.V)[c];
-    cf *o = (cf *)p.xr + j;
+    cf *o = (cf *)p.xr + ((p.pos0 + j) & p.mask);
     cf v = *o;
     v.x = fmaf(-V.x, g, v.x);
     v.y = fmaf(-V.y, g, v.y);
@@ -397,8 +397,8 @@ extern "C" int pmr_launch_fe_tiles(pmr_stream_t s, const pmr_fe_tiles_params *p)
 
 extern "C" int pmr_launch_fe_dcfix(pmr_stream_t s, const pmr_fe_fix_params *p)
 {
-    if (!p->ny) return 0;
-    hipLaunchKernelGGL(k_fe_dcfix, dim3((p->ny + 255) / 256), dim3(256), 0, (hipStream_t)s, *p);
+    if (p->ny <= p->j0) return 0;
+    hipLaunchKernelGGL(k_fe_dcfix, dim3((p->ny - p->j0 + 255) / 256), dim3(256), 0, (hipStream_t)s, *p);
     return (int)hipGetLastError();
 }
 

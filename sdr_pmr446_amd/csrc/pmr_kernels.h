@@ -43,19 +43,30 @@ int pmr_launch_halfband(pmr_stream_t s, const void *zin, void *zout, unsigned n_
                         int m, const float *h1, float scale);
 
 /* arbitrary polyphase resampler (:796).  dec[keep + q] = q-th new decimated sample.                  */
-int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out, unsigned ny, uint32_t phase0, uint32_t step,
-                   const float *bank, int keep);
+int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out_ring, uint64_t out_pos0, uint64_t out_mask,
+                   unsigned ny, uint32_t phase0, uint32_t step, const float *bank, int keep);
 
-/* NCO shift + polyphase analysis bank + M-point FFT + discriminator (:808-821, :881).
- *  xr        resampled stream; frame f (0 = first new frame) phase c is xr[(p + f)*M + c]
- *  nco_cs    [period][2] (cos, sin); phase index of xr[0] is nco_idx0
- *  fm_out    time-major [frame][M], first new frame at fm_out
- *  chan_out  nullable, channel-major [M][chan_stride]
- *  rssi_part nullable, [ntiles][M] partial sums of |y|                                                */
-int pmr_launch_channelize(pmr_stream_t s, const void *xr, unsigned ns, unsigned M, unsigned p,
-                          const float *taps_t, const float *fft_tw, const float *nco_cs, unsigned nco_period,
-                          unsigned nco_idx0, float fm_ref, float *fm_out, void *chan_out, unsigned chan_stride,
-                          float *rssi_part, unsigned *ntiles_out);
+/* Ring buffers.  The resampled stream lives in a power-of-two ring of cf32 addressed by the ABSOLUTE resampled
+ * sample index (sample a at xr[a & xr_mask]); the discriminator output in a ring of time-major rows addressed by the
+ * absolute frame index (frame t at fm[(t & fm_mask) * M + k]).  Frame f covers samples [f*M, (f+1)*M); the NCO phase
+ * of sample a is table entry a mod period.  Negative indices (before the stream start) wrap onto still-zero memory. */
+typedef struct {
+    const void *xr; uint64_t xr_mask;   /* resampled ring                                                   */
+    int64_t frame0;                     /* absolute index of the first NEW frame of this call               */
+    uint64_t xr_end;                    /* absolute index one past the last valid resampled sample          */
+    float *fm; uint64_t fm_mask;        /* discriminator ring (rows)                                        */
+    unsigned ns, M, p;
+    const float *taps_t, *fft_tw, *nco_cs; unsigned nco_period;
+    float fm_ref;
+    void *chan_out; unsigned chan_stride;   /* nullable, channel-major [M][chan_stride], frame index relative */
+    float *rssi_part;                       /* nullable, [ntiles][M] partial sums of |y|                      */
+    /* deferred dc carry of the fused front end, applied while staging (small-M kernel only); V == NULL: none */
+    const void *V; const float *GA, *T1, *T2;
+    uint64_t fix_abs0; unsigned fix_ny, TQ, HhQ; uint32_t phi0, step; float Kgain;
+} pmr_chan_params;
+
+/* NCO shift + polyphase analysis bank + M-point FFT + discriminator (:808-821, :881), any power-of-two M */
+int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out);
 unsigned pmr_channelize_tiles(unsigned ns, unsigned M);
 int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntiles, unsigned M, unsigned ns,
                            float *rssi_db);
@@ -64,10 +75,7 @@ int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntil
  * samples in xr (zeros are read beyond).  Same outputs as pmr_launch_channelize.                       */
 int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned nco_period);
 unsigned pmr_channelize_small_tiles(unsigned ns);
-int pmr_launch_channelize_small(pmr_stream_t s, const void *xr, unsigned n_valid, unsigned ns, unsigned M,
-                                unsigned p, const float *taps_t, const float *fft_tw, const float *nco_cs,
-                                unsigned nco_period, unsigned nco_idx0, float fm_ref, float *fm_out,
-                                void *chan_out, unsigned chan_stride, float *rssi_part, unsigned *ntiles_out);
+int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out);
 
 /* time-major real FIR with optional epilogue (:882-904).
  *  in        time-major, in[(t)*M + k], t = 0 first new frame (history at negative t)
@@ -77,8 +85,10 @@ int pmr_launch_channelize_small(pmr_stream_t s, const void *xr, unsigned n_valid
  *  iir       if non-zero: y = b0*v0 + b1*v1, v0 = u - a1*v1 (:898)
  *  out_tm    nullable time-major output (same indexing as `in`)
  *  pcm/audio nullable channel-major [M][stride] final outputs                                          */
-int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, unsigned M, const float *taps_pad,
-                      unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
+/*  in / out_tm are row rings: frame t (absolute) at ring[(t & row_mask) * M + k]; row0 = absolute index of the
+ *  first new frame.  pcm / audio are the caller's channel-major buffers, frame index relative to row0.          */
+int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+                      const float *taps_pad, unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                       float *out_tm, int16_t *pcm, float *audio, unsigned stride);
 
 /* ---- fused front end (pmr_frontend.hip): dc-block + half-band cascade + arbitrary resampler in one pass ---- */
@@ -87,7 +97,8 @@ typedef struct {
     const void *x;              /* new block [n_in] cf32                                             */
     const void *hist;           /* raw history: the hcap samples before the block                    */
     void *new_hist;             /* raw history for the NEXT call (other ping-pong buffer), written by tile 0 */
-    void *out;                  /* resampled outputs of this block [ny] cf32                         */
+    void *out;                  /* resampled ring; output j of this block goes to out[(out_pos0 + j) & out_mask] */
+    uint64_t out_pos0, out_mask;
     void *probeA, *probeB;      /* [ntiles] local dc state at tile offsets Hh-1 and N0-1             */
     void *probeL, *probeE;      /* local dc state at (block start - 1) in tile 0, (block end) in tile c_end */
     const float *hb_taps;       /* branch taps of all stages, execution order, oldest-first          */
@@ -112,9 +123,10 @@ typedef struct {
 } pmr_fe_tiles_params;
 
 typedef struct {
-    void *xr; const void *V;
+    void *xr; uint64_t pos0, mask; const void *V;
     const float *GA, *T1, *T2;
-    unsigned ny, TQ, HhQ;
+    unsigned ny, TQ, HhQ;       /* ny: outputs of the block; only j in [j0, ny) are corrected */
+    unsigned j0;
     uint32_t phi0, step;
     float Kgain;
 } pmr_fe_fix_params;

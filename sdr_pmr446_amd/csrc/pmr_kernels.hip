@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void k_halfband(const cf *__restrict__ zin, cf
 // ------------------------------------------------------------------------------------------------
 // Arbitrary polyphase resampler with 24-bit phase: out[j] = sum_k bank[idx_j][k] * dec[q_j - 13 + k]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_arb(const cf *__restrict__ dec, cf *__restrict__ out, unsigned ny,
+__global__ __launch_bounds__(256) void k_arb(const cf *__restrict__ dec, cf *__restrict__ out,
+                                             unsigned long long out_pos0, unsigned long long out_mask, unsigned ny,
                                              uint32_t phase0, uint32_t step, const float *__restrict__ bank,
                                              int keep)
 {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_arb(const cf *__restrict__ dec, cf *__r
         yr = fmaf(b[k], s.x, yr);
         yi = fmaf(b[k], s.y, yi);
     }
-    out[j] = cf_make(yr, yi);
+    out[(out_pos0 + j) & out_mask] = cf_make(yr, yi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -178,38 +179,35 @@ __global__ __launch_bounds__(256) void k_arb(const cf *__restrict__ dec, cf *__r
 // ------------------------------------------------------------------------------------------------
 static __host__ __device__ inline unsigned chan_ft(unsigned M) { unsigned ft = 8192u / M; return ft < 4u ? 4u : ft; }
 
-__global__ __launch_bounds__(256) void k_channelize(const cf *__restrict__ xr, unsigned ns, unsigned M,
-                                                    unsigned log2M, unsigned p,
-                                                    const float *__restrict__ taps_t,
-                                                    const cf *__restrict__ fft_tw,
-                                                    const cf *__restrict__ nco_cs, unsigned nco_mask,
-                                                    unsigned nco_idx0, float fm_ref, float *__restrict__ fm_out,
-                                                    cf *__restrict__ chan_out, unsigned chan_stride,
-                                                    float *__restrict__ rssi_part)
+__global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned log2M)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned M = q.M, p = q.p, ns = q.ns;
     const unsigned FT = chan_ft(M), TFN = FT - 1;
     cf *Xs = reinterpret_cast<cf *>(smem);            // [FT][M]
     cf *tw = Xs + (size_t)FT * M;                     // [M/2]
+    const cf *__restrict__ xr = (const cf *)q.xr;
+    const cf *__restrict__ nco_cs = (const cf *)q.nco_cs;
+    const unsigned nco_mask = q.nco_period - 1;
     const unsigned tid = threadIdx.x;
-    const unsigned t0 = blockIdx.x * TFN;             // first NEW frame of this tile
+    const unsigned t0 = blockIdx.x * TFN;             // first NEW frame of this tile (relative to frame0)
     const unsigned nf = min(TFN, ns - t0);            // new frames in this tile
 
-    for (unsigned k = tid; k < M / 2; k += 256) tw[k] = fft_tw[k];
+    for (unsigned k = tid; k < M / 2; k += 256) tw[k] = ((const cf *)q.fft_tw)[k];
 
-    // phase 1: X[f][c] = sum_k taps_t[k][c] * xm[(t0 + f + k) * M + c],  f = 0 is frame t0-1
+    // phase 1: X[f][c] = sum_k taps_t[k][c] * xm[(F + f - p + k) * M + c],  local f = 0 is frame t0-1
+    const long long fbase = (long long)q.frame0 + t0 - (long long)p;   // absolute frame of (f = 0, k = 0)
     const unsigned items = (nf + 1) * M;
     for (unsigned w = tid; w < items; w += 256) {
         const unsigned f = w >> log2M, c = w & (M - 1);
         float ar = 0.f, ai = 0.f;
-        const size_t s0 = (size_t)(t0 + f) * M + c;
         for (unsigned k = 0; k < p; k++) {
-            const size_t s = s0 + (size_t)k * M;
-            const cf x = xr[s];
-            const cf cs = nco_cs[(nco_idx0 + (unsigned)s) & nco_mask];
+            const long long a = (fbase + f + k) * (long long)M + c;    // absolute resampled sample index
+            const cf x = xr[(unsigned long long)a & q.xr_mask];
+            const cf cs = nco_cs[(unsigned)a & nco_mask];
             const float xmr = fmaf(x.x, cs.x, x.y * cs.y);       // x * conj(e^{j theta})
             const float xmi = fmaf(x.y, cs.x, -(x.x * cs.y));
-            const float h = taps_t[k * M + c];
+            const float h = q.taps_t[k * M + c];
             ar = fmaf(h, xmr, ar);
             ai = fmaf(h, xmi, ai);
         }
@@ -237,23 +235,25 @@ __global__ __launch_bounds__(256) void k_channelize(const cf *__restrict__ xr, u
     }
 
     // phase 3: discriminator m = arg(conj(prev) * cur) / (2 pi kf), plus tap-offs
+    cf *__restrict__ chan_out = (cf *)q.chan_out;
     const unsigned oitems = nf * M;
     for (unsigned w = tid; w < oitems; w += 256) {
         const unsigned f = w >> log2M, k = w & (M - 1);
         const cf pv = Xs[f * M + k], cu = Xs[(f + 1) * M + k];
         const float re = fmaf(pv.x, cu.x, pv.y * cu.y);
         const float im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
-        fm_out[(size_t)(t0 + f) * M + k] = atan2f(im, re) * fm_ref;
-        if (chan_out) chan_out[(size_t)k * chan_stride + t0 + f] = cu;
+        const unsigned long long row = (unsigned long long)(q.frame0 + t0 + f) & q.fm_mask;
+        q.fm[row * M + k] = atan2f(im, re) * q.fm_ref;
+        if (chan_out) chan_out[(size_t)k * q.chan_stride + t0 + f] = cu;
     }
-    if (rssi_part) {
+    if (q.rssi_part) {
         for (unsigned k = tid; k < M; k += 256) {
             float a = 0.f;
             for (unsigned f = 0; f < nf; f++) {
                 const cf cu = Xs[(f + 1) * M + k];
                 a += hypotf(cu.x, cu.y);
             }
-            rssi_part[(size_t)blockIdx.x * M + k] = a;
+            q.rssi_part[(size_t)blockIdx.x * M + k] = a;
         }
     }
 }
@@ -309,7 +309,8 @@ static __device__ __forceinline__ void fir_accumulate(float (&acc)[RP], const fl
     }
 }
 
-__global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, unsigned ns, unsigned M,
+__global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, unsigned long long row_mask,
+                                                long long row0, unsigned ns, unsigned M,
                                                 unsigned log2M, const float *__restrict__ taps_q,
                                                 unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                                                 float *__restrict__ out_tm, int16_t *__restrict__ pcm,
@@ -326,8 +327,9 @@ __global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, un
     float acc[RP];
 #pragma unroll
     for (int i = 0; i < (int)RP; i++) acc[i] = 0.f;
-    const float *px = in + ((t0 - (long)PMR_AUDIO_J - (long)(ntaps - 1)) * (long)M + (long)k);
-    fir_accumulate(acc, taps_q, ntaps, [&](unsigned e) { return px[(size_t)e * M]; });
+    const long long r0 = row0 + t0 - (long long)PMR_AUDIO_J - (long long)(ntaps - 1);
+    fir_accumulate(acc, taps_q, ntaps,
+                   [&](unsigned e) { return in[((unsigned long long)(r0 + e) & row_mask) * M + k]; });
     float v1 = 0.f;
 #pragma unroll
     for (int i = 0; i < (int)RP; i++) {
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, un
         if (i >= (int)PMR_AUDIO_J) {
             const long t = t0 + (i - (int)PMR_AUDIO_J);
             if (t < (long)ns) {
-                if (out_tm) out_tm[(size_t)t * M + k] = y;
+                if (out_tm) out_tm[((unsigned long long)(row0 + t) & row_mask) * M + k] = y;
                 if (audio) audio[(size_t)k * stride + t] = y;
                 if (pcm) {
                     float s = y * 32767.0f;
@@ -367,7 +369,8 @@ __global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, un
 #define FL_SEGS 16
 #define FL_T (FL_SEGS * PMR_AUDIO_R)          /* 512 output frames per tile */
 
-__global__ __launch_bounds__(256) void k_fir_lds(const float *__restrict__ in, unsigned ns, unsigned M,
+__global__ __launch_bounds__(256) void k_fir_lds(const float *__restrict__ in, unsigned long long row_mask,
+                                                 long long row0, unsigned ns, unsigned M,
                                                  const float *__restrict__ taps_q, unsigned ntaps, float gain,
                                                  int iir, float b0, float b1, float a1, float *__restrict__ out_tm,
                                                  int16_t *__restrict__ pcm, float *__restrict__ audio,
@@ -387,7 +390,8 @@ __global__ __launch_bounds__(256) void k_fir_lds(const float *__restrict__ in, u
         const unsigned r = u >> 2, q4 = (u & 3) * 4;
         const long t = r0 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < (long)ns) v = *reinterpret_cast<const float4 *>(in + t * (long)M + g * 16 + q4);
+        if (t < (long)ns)
+            v = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + g * 16 + q4);
         *reinterpret_cast<float4 *>(tile + r * 16 + 16 * (r >> 5) + q4) = v;
     }
     __syncthreads();
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) void k_fir_lds(const float *__restrict__ in, u
         if (i >= (int)PMR_AUDIO_J) {
             const long t = t0 + (i - (int)PMR_AUDIO_J);
             if (t < (long)ns) {
-                if (out_tm) out_tm[(size_t)t * M + kk] = y;
+                if (out_tm) out_tm[((unsigned long long)(row0 + t) & row_mask) * M + kk] = y;
                 if (audio) audio[(size_t)kk * stride + t] = y;
                 if (pcm) {
                     float s = y * 32767.0f;
@@ -450,7 +454,8 @@ static __device__ __forceinline__ int16_t pcm_from_float(float y)
     return (int16_t)s;                                 // truncation toward zero (src/dsd_in.c:174)
 }
 
-__global__ __launch_bounds__(256) void k_fir_pair(const float *__restrict__ in, unsigned ns, unsigned M,
+__global__ __launch_bounds__(256) void k_fir_pair(const float *__restrict__ in, unsigned long long row_mask,
+                                                  long long row0, unsigned ns, unsigned M,
                                                   unsigned log2Mh, const float *__restrict__ taps_c,
                                                   unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                                                   float *__restrict__ out_tm, int16_t *__restrict__ pcm,
@@ -464,15 +469,17 @@ __global__ __launch_bounds__(256) void k_fir_pair(const float *__restrict__ in, 
 #pragma unroll
     for (int i = 0; i < FP_RP; i++) acc[i] = v2f{0.f, 0.f};
     // step e brings input frame s = t0 - J - (ntaps-1) + e; it meets accumulator i with tap h[ntaps-1 + i - e]
-    const float *px = in + ((t0 - (long)FP_J - (long)(ntaps - 1)) * (long)M + 2 * (long)cp);
+    const long long r0 = row0 + t0 - (long long)FP_J - (long long)(ntaps - 1);
+    const float *pc = in + 2 * cp;
+#define FP_ROW(e) (pc + ((unsigned long long)(r0 + (e)) & row_mask) * M)
     const float *tq0 = taps_c + PMR_TAP_PAD + (ntaps - 1);
     const unsigned steps = ntaps + FP_RP - 1;
     unsigned e = 0;
     for (; e + 4 <= steps; e += 4) {
-        const v2f x0 = *reinterpret_cast<const v2f *>(px + (size_t)(e + 0) * M);
-        const v2f x1 = *reinterpret_cast<const v2f *>(px + (size_t)(e + 1) * M);
-        const v2f x2 = *reinterpret_cast<const v2f *>(px + (size_t)(e + 2) * M);
-        const v2f x3 = *reinterpret_cast<const v2f *>(px + (size_t)(e + 3) * M);
+        const v2f x0 = *reinterpret_cast<const v2f *>(FP_ROW(e + 0));
+        const v2f x1 = *reinterpret_cast<const v2f *>(FP_ROW(e + 1));
+        const v2f x2 = *reinterpret_cast<const v2f *>(FP_ROW(e + 2));
+        const v2f x3 = *reinterpret_cast<const v2f *>(FP_ROW(e + 3));
         const float *tp = tq0 - (long)e - 3;           // tap(e + u, i) = tp[3 - u + i]: one window for 4 steps
 #pragma unroll
         for (int i = 0; i < FP_RP; i++) {
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(256) void k_fir_pair(const float *__restrict__ in, 
         }
     }
     for (; e < steps; e++) {
-        const v2f x = *reinterpret_cast<const v2f *>(px + (size_t)e * M);
+        const v2f x = *reinterpret_cast<const v2f *>(FP_ROW(e));
         const float *tp = tq0 - (long)e;
 #pragma unroll
         for (int i = 0; i < FP_RP; i++) acc[i] = __builtin_elementwise_fma(v2f{tp[i], tp[i]}, x, acc[i]);
@@ -512,7 +519,8 @@ __global__ __launch_bounds__(256) void k_fir_pair(const float *__restrict__ in, 
     if (out_tm) {
 #pragma unroll
         for (int i = 0; i < FP_R; i++)
-            if (t0 + i < (long)ns) *reinterpret_cast<v2f *>(out_tm + (size_t)(t0 + i) * M + ka) = v2f{ya[i], yb[i]};
+            if (t0 + i < (long)ns)
+                *reinterpret_cast<v2f *>(out_tm + ((unsigned long long)(row0 + t0 + i) & row_mask) * M + ka) = v2f{ya[i], yb[i]};
     }
     if (audio) {
         float *oa = audio + (size_t)ka * stride + t0, *ob = audio + (size_t)kb * stride + t0;
@@ -595,12 +603,12 @@ extern "C" int pmr_launch_halfband(pmr_stream_t s, const void *zin, void *zout, 
     return (int)hipGetLastError();
 }
 
-extern "C" int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out, unsigned ny, uint32_t phase0,
-                              uint32_t step, const float *bank, int keep)
+extern "C" int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out_ring, uint64_t out_pos0, uint64_t out_mask,
+                              unsigned ny, uint32_t phase0, uint32_t step, const float *bank, int keep)
 {
     if (!ny) return 0;
-    hipLaunchKernelGGL(k_arb, dim3((ny + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)dec, (cf *)out, ny,
-                       phase0, step, bank, keep);
+    hipLaunchKernelGGL(k_arb, dim3((ny + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)dec, (cf *)out_ring,
+                       (unsigned long long)out_pos0, (unsigned long long)out_mask, ny, phase0, step, bank, keep);
     return (int)hipGetLastError();
 }
 
@@ -610,24 +618,19 @@ extern "C" unsigned pmr_channelize_tiles(unsigned ns, unsigned M)
     return (ns + tfn - 1) / tfn;
 }
 
-extern "C" int pmr_launch_channelize(pmr_stream_t s, const void *xr, unsigned ns, unsigned M, unsigned p,
-                                     const float *taps_t, const float *fft_tw, const float *nco_cs,
-                                     unsigned nco_period, unsigned nco_idx0, float fm_ref, float *fm_out,
-                                     void *chan_out, unsigned chan_stride, float *rssi_part, unsigned *ntiles_out)
+extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out)
 {
-    const unsigned ntiles = pmr_channelize_tiles(ns, M);
+    const unsigned ntiles = pmr_channelize_tiles(p->ns, p->M);
     if (ntiles_out) *ntiles_out = ntiles;
-    if (!ns) return 0;
-    const size_t lds = ((size_t)chan_ft(M) * M + M / 2) * sizeof(cf);
+    if (!p->ns) return 0;
+    const size_t lds = ((size_t)chan_ft(p->M) * p->M + p->M / 2) * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_channelize, dim3(ntiles), dim3(256), lds, (hipStream_t)s, (const cf *)xr, ns, M, ilog2(M),
-                       p, taps_t, (const cf *)fft_tw, (const cf *)nco_cs, nco_period - 1, nco_idx0, fm_ref, fm_out,
-                       (cf *)chan_out, chan_stride, rssi_part);
+    hipLaunchKernelGGL(k_channelize, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p, ilog2(p->M));
     return (int)hipGetLastError();
 }
 
@@ -639,9 +642,9 @@ extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, un
     return (int)hipGetLastError();
 }
 
-extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, unsigned M, const float *taps_pad,
-                                 unsigned ntaps, float gain, int iir, float b0, float b1, float a1, float *out_tm,
-                                 int16_t *pcm, float *audio, unsigned stride)
+extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
+                                 unsigned M, const float *taps_pad, unsigned ntaps, float gain, int iir, float b0,
+                                 float b1, float a1, float *out_tm, int16_t *pcm, float *audio, unsigned stride)
 {
     if (!ns) return 0;
     static int mode = -1;                    /* 0 = pair (default), 1 = lds, 2 = global */
@@ -652,7 +655,8 @@ extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, u
     if (mode == 0 && M >= 2) {
         const unsigned segs = (ns + FP_R - 1) / FP_R;
         const size_t threads = (size_t)segs * (M >> 1);
-        hipLaunchKernelGGL(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, ns, M,
+        hipLaunchKernelGGL(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
+                           (unsigned long long)row_mask, (long long)row0, ns, M,
                            ilog2(M >> 1), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
         return (int)hipGetLastError();
     }
@@ -666,13 +670,15 @@ extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, unsigned ns, u
             attr_set = true;
         }
         const unsigned tiles = (ns + FL_T - 1) / FL_T;
-        hipLaunchKernelGGL(k_fir_lds, dim3(tiles * (M >> 4)), dim3(256), lds, (hipStream_t)s, in, ns, M, taps_pad,
+        hipLaunchKernelGGL(k_fir_lds, dim3(tiles * (M >> 4)), dim3(256), lds, (hipStream_t)s, in,
+                           (unsigned long long)row_mask, (long long)row0, ns, M, taps_pad,
                            ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
         return (int)hipGetLastError();
     }
     const unsigned segs = (ns + PMR_AUDIO_R - 1) / PMR_AUDIO_R;
     const size_t threads = (size_t)segs * M;
-    hipLaunchKernelGGL(k_fir_tm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, ns, M,
+    hipLaunchKernelGGL(k_fir_tm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
+                       (unsigned long long)row_mask, (long long)row0, ns, M,
                        ilog2(M), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
     return (int)hipGetLastError();
 }
