@@ -246,11 +246,24 @@ static int fe_init(pmr_chain q)
     const unsigned long L = D > 16 ? D : 16;
     int nt = 0;
     unsigned long T_own = 0;
-    for (int cand = 256; cand <= 1024; cand *= 4) {
-        const unsigned long N0 = (unsigned long)cand * 16;
-        if (N0 % L || H + L > N0) continue;
-        const unsigned long t = (N0 - H) / L * L;
-        if (t * 4 >= N0 * 3 || cand == 1024) { if (t * 2 >= N0) { nt = cand; T_own = t; } break; }
+    {
+        /* tile geometries (threads x 16 samples): 256 -> 4096-sample tiles; 1024 -> 16384 (deep cascades);
+         * PMR_FE_GEOM=128x16 / 192x16 / 512x8 select experimental ones */
+        const char *gm = getenv("PMR_FE_GEOM");
+        int first = 256;
+        if (gm && !strcmp(gm, "128x16")) first = 128;
+        if (gm && !strcmp(gm, "192x16")) first = 192;
+        const int cands[3] = { first, 256, 1024 };
+        for (int ci = 0; ci < 3 && !nt; ci++) {
+            const int cand = cands[ci];
+            const unsigned long N0c = (unsigned long)cand * 16;
+            if (N0c % L || H + L > N0c) continue;
+            const unsigned long t = (N0c - H) / L * L;
+            const int last = cand == 1024;
+            if ((!last && t * 4 >= N0c * 3) || (last && t * 2 >= N0c) || (cand == first && first != 256 && t * 2 >= N0c)) {
+                nt = cand; T_own = t;
+            }
+        }
     }
     if (!nt) return PMR_OK;                      /* cascade too deep for one LDS tile: staged path */
     const unsigned long N0 = (unsigned long)nt * 16;
@@ -313,10 +326,10 @@ static int fe_init(pmr_chain q)
         if ((rc = dev_upload(q, &q->d_fe_T2, t2, 32))) return rc;
     }
     {
-        float ll[64];
+        float ll[72];
         const double spt = (double)q->fe_spt;
-        for (unsigned l = 0; l < 64; l++) ll[l] = (float)pow(lam, spt * l);
-        if ((rc = dev_upload(q, &q->d_fe_lam_lane, ll, 64))) return rc;
+        for (unsigned l = 0; l < 72; l++) ll[l] = (float)pow(lam, spt * l);
+        if ((rc = dev_upload(q, &q->d_fe_lam_lane, ll, 72))) return rc;
         for (int j = 0; j < 6; j++) q->fe_lam_pow16[j] = (float)pow(lam, spt * (double)(1u << j));
         q->fe_lam_wave = (float)pow(lam, 64.0 * spt);
     }
@@ -372,7 +385,31 @@ static int chain_init(pmr_chain q)
     if (q->hp_len < 1 || q->hp_len + PMR_AUDIO_J > FM_HIST_FRAMES || q->lp_len < 1 || q->de_len < 1 ||
         q->lp_len + PMR_AUDIO_J > AUX_HIST_FRAMES || q->de_len + PMR_AUDIO_J > AUX_HIST_FRAMES)
         return fail(q, PMR_EINVAL, "audio filter length out of range", hipSuccess);
-    if ((rc = upload_padded_taps(q, &q->d_hp_pad, hp, q->hp_len))) return rc;
+    {
+        /* The audio kernels run ONE FIR: gain (:890) and, for the default IIR de-emphasis (:898), its impulse
+         * response e[0] = b0, e[k] = (b1 - a1 b0)(-a1)^(k-1) are folded into the high-pass taps in double.  The pole is
+         * 0.0146, so 7 terms reproduce the recursion to ~2e-11 (checked against scipy.lfilter); no per-thread IIR warm-up. */
+        const unsigned ke = q->cfg.deemph_fir ? 1 : 7, n = q->hp_len + ke - 1;
+        double e[8] = {0};
+        if (q->cfg.deemph_fir) e[0] = 1.0;
+        else {
+            const double b0 = d->de_b0, b1 = d->de_b1, a1 = d->de_a1;
+            e[0] = b0;
+            for (unsigned k = 1; k < ke; k++) e[k] = (b1 - a1 * b0) * pow(-a1, (double)(k - 1));
+        }
+        float *g = (float *)calloc(n, sizeof(float));
+        if (!g) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+        for (unsigned i = 0; i < n; i++) {
+            double acc = 0.0;
+            for (unsigned k = 0; k < ke && k <= i; k++)
+                if (i - k < q->hp_len) acc += e[k] * (double)hp[i - k];
+            g[i] = (float)((double)q->cfg.audio_gain * acc);
+        }
+        rc = upload_padded_taps(q, &q->d_hp_pad, g, n);
+        free(g);
+        if (rc) return rc;
+        q->hp_len = n;
+    }
     if ((rc = upload_padded_taps(q, &q->d_lp_pad, lp, q->lp_len))) return rc;
     if ((rc = upload_padded_taps(q, &q->d_de_pad, de, q->de_len))) return rc;
 
@@ -759,7 +796,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         if (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass) {
             const int more = q->cfg.deemph_fir || q->cfg.lowpass;
             LAUNCH(K_FIR_HP, pmr_launch_fir_tm(q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
-                                               q->cfg.audio_gain, !q->cfg.deemph_fir, d->de_b0, d->de_b1, d->de_a1,
+                                               1.0f, 0, 0.f, 0.f, 0.f,      /* gain + de-emphasis are in the taps */
                                                more ? q->d_aux1 : NULL, more ? NULL : (int16_t *)d_pcm,
                                                more ? NULL : (float *)d_audio, pcm_stride));
             const float *cur = q->d_aux1;

@@ -17,8 +17,11 @@
 
 #include "pmr_kernels.h"
 
-typedef float2 cf;
-static __device__ __forceinline__ cf cfm(float r, float i) { cf v; v.x = r; v.y = i; return v; }
+// complex = ext-vector pair: real-tap MACs and butterflies map onto v_pk_fma_f32 / v_pk_add_f32 (~1.8x the FLOP rate of
+// the scalar forms on gfx950, tools/ubench/valu_rate.hip)
+typedef float cf __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ cf cfm(float r, float i) { return cf{r, i}; }
+static __device__ __forceinline__ cf cfma(float h, cf x, cf acc) { return __builtin_elementwise_fma(cf{h, h}, x, acc); }
 
 template <int M> struct log2c { static constexpr int v = 1 + log2c<M / 2>::v; };
 template <> struct log2c<1> { static constexpr int v = 0; };
@@ -41,12 +44,18 @@ static __device__ __forceinline__ void fft_dit(cf (&x)[M], const cf *__restrict_
         for (int base = 0; base < M; base += len) {
 #pragma unroll
             for (int k = 0; k < half; k++) {
-                const cf w = tw[k * tstep];
                 const cf a = x[base + k], b = x[base + k + half];
-                const float tr = fmaf(b.x, w.x, -(b.y * w.y));
-                const float ti = fmaf(b.x, w.y, b.y * w.x);
-                x[base + k] = cfm(a.x + tr, a.y + ti);
-                x[base + k + half] = cfm(a.x - tr, a.y - ti);
+                cf t;
+                if (k == 0) {
+                    t = b;                                               // w = 1 (known at compile time: loops are unrolled)
+                } else if (4 * k == len) {
+                    t = cf{b.y, -b.x};                                   // w = -j
+                } else {
+                    const cf w = tw[k * tstep];                          // (cos, sin) of -2 pi k / len, wave-uniform
+                    t = __builtin_elementwise_fma(cf{b.x, b.x}, w, cf{b.y, b.y} * cf{-w.y, w.x});
+                }
+                x[base + k] = a + t;
+                x[base + k + half] = a - t;
             }
         }
     }
@@ -137,18 +146,12 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
             if (j < p) {
                 const float *ta = taps_t + j * M;
 #pragma unroll
-                for (int c = 0; c < M; c++) {
-                    XA[c].x = fmaf(ta[c], s[c].x, XA[c].x);
-                    XA[c].y = fmaf(ta[c], s[c].y, XA[c].y);
-                }
+                for (int c = 0; c < M; c++) XA[c] = cfma(ta[c], s[c], XA[c]);
             }
             if (j >= 1) {
                 const float *tb = taps_t + (j - 1) * M;
 #pragma unroll
-                for (int c = 0; c < M; c++) {
-                    XB[c].x = fmaf(tb[c], s[c].x, XB[c].x);
-                    XB[c].y = fmaf(tb[c], s[c].y, XB[c].y);
-                }
+                for (int c = 0; c < M; c++) XB[c] = cfma(tb[c], s[c], XB[c]);
             }
         }
     }

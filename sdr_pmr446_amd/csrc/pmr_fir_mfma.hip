@@ -1,0 +1,159 @@
+// pmr_fir_mfma.hip -- the audio FIR (reference src/sdr_pmr446.c:882-904: 377-tap CTCSS high-pass, gain, 50 us
+// de-emphasis, PCM hand-off) for M = 16 on the gfx950 MATRIX pipe.
+//
+// Why MFMA here although the chain is "streaming DSP": with all 16 channels demodulated this stage is the FLOP
+// hot spot at small decimation ratios (383 MACs per audio sample = 32 MACs per raw input sample at cfg2, 2/3 of all
+// arithmetic) and it is compute- not HBM-bound.  Measured on MI355X (tools/ubench/valu_rate.hip): v_fma_f32 peaks at
+// ~67 TFLOP/s, v_pk_fma_f32 at ~115 TFLOP/s, f32 MFMA at ~155 TFLOP/s -- and the matrix pipe is otherwise idle while
+// the front end and the channelizer saturate the VALU on the other stream.  The f32 MFMA is an exact, k-ordered fmaf
+// chain (MI355X_MICROARCH.md), so the accumulation order is the oracle's: oldest sample first.
+//
+// Formulation.  With gain and the (truncated, 7-term) de-emphasis response folded into the taps g[0..n) on the host,
+//   Y[t][ch] = sum_d g[d] X[t-d][ch]
+// is a banded Toeplitz matrix times the data:  D[i][j] = sum_kappa A[i][kappa] B[kappa][j] with
+//   A[i][kappa] = g[i + (n-1) - kappa]   (zero outside the band; read from the zero-padded tap table)
+//   B[kappa][j] = X[T_j - (n-1) + kappa][ch_j],      D[i][j] = Y[T_j + i][ch_j]
+// A 32x32 output tile covers 32 frames x (16 channels x 2 time blocks).  v_mfma_f32_32x32x2_f32 consumes two kappa
+// per instruction: lane l supplies A[l&31][l>>5] and B[l>>5][l&31], i.e. ONE tap and ONE sample per lane per step,
+// both from LDS (the workgroup stages its 16-channel slab of the time-major discriminator stream once).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmr_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FM_NT 256
+#define FM_TILE 256                              /* frames per workgroup: 4 waves x 2 blocks x 32 */
+
+static __device__ __forceinline__ int16_t pcm16(float y)
+{
+    const float s = y * 32767.0f;
+    if (!(s == s)) return 0;
+    if (s >= 32767.0f) return 32767;
+    if (s <= -32768.0f) return -32768;
+    return (int16_t)s;                            // truncation toward zero (src/dsd_in.c:174), saturated
+}
+
+__global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ in, unsigned long long row_mask,
+                                                      long long row0, unsigned ns, const float *__restrict__ taps_c,
+                                                      unsigned ntaps, float *__restrict__ out_tm,
+                                                      int16_t *__restrict__ pcm, float *__restrict__ audio,
+                                                      unsigned stride)
+{
+    constexpr int M = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_m[];
+    float *Qs = reinterpret_cast<float *>(smem_m);                   // [ntaps + 2*PMR_TAP_PAD] padded taps
+    const unsigned qlen = ntaps + 2 * PMR_TAP_PAD;
+    float *Xs = Qs + ((qlen + 31) & ~31u);                           // rows: r at r*16 + 16*(r>>5)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long T0 = (long)blockIdx.x * FM_TILE;                      // first frame of this workgroup (relative to row0)
+    const unsigned nrows = FM_TILE + ntaps - 1 + 18;                 // frames T0-(ntaps-1) .. T0+255 (+18: kappa padded to 16)
+
+    for (unsigned i = tid; i < qlen; i += FM_NT) Qs[i] = taps_c[i];
+    for (unsigned u = tid; u < nrows * 4; u += FM_NT) {
+        const unsigned r = u >> 2, q4 = (u & 3) * 4;
+        const long t = T0 - (long)(ntaps - 1) + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < (long)ns) v = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + q4);
+        *reinterpret_cast<float4 *>(Xs + r * 16 + 16 * (r >> 5) + q4) = v;
+    }
+    __syncthreads();
+
+    const int j = lane & 31, kk = lane >> 5, ch = j & 15, blk = j >> 4;
+    const int Tj = 64 * wave + 32 * blk;                             // frame offset of this column inside the tile
+    if (T0 + 64 * wave >= (long)ns) return;                          // whole wave beyond the block (after the only barrier)
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    const float *qa = Qs + PMR_TAP_PAD + (ntaps - 1) + (lane & 31) - kk;   // tap for kappa = 2s + kk: qa[-2s]
+    int rb = Tj + kk;                                                // tile row for kappa = 2s + kk: rb + 2s
+    // kappa runs over [0, ntaps + 31); padded up to a multiple of 16 (the extra taps are zeros of the padded table) so
+    // that 8 (tap, sample) pairs are fetched from LDS ahead of the 8 MFMAs that consume them
+    const unsigned steps = ((ntaps + 31 + 15) / 16) * 8;
+    // explicit register double-buffering: the (tap, sample) pairs of the NEXT 8 steps are in flight from LDS while the
+    // 8 MFMAs of the current ones issue back to back (64 cycles each on this SIMD's matrix pipe)
+    float a[8], b[8], an[8], bn[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        a[u] = qa[-2 * u];
+        const int r = rb + 2 * u;
+        b[u] = Xs[r * 16 + 16 * (r >> 5) + ch];
+    }
+    for (unsigned s = 0; s < steps; s += 8) {
+        const unsigned sn = s + 8 < steps ? s + 8 : s;       // last round re-reads its own operands (harmless)
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            an[u] = qa[-2 * (int)(sn + u)];
+            const int r = rb + 2 * (int)(sn + u);
+            bn[u] = Xs[r * 16 + 16 * (r >> 5) + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { a[u] = an[u]; b[u] = bn[u]; }
+    }
+
+    // D layout: lane holds column j; register g*4+q is row 8g + 4*kk + q  ->  4 consecutive frames per register group
+    const bool vec_ok = ((stride & 3) == 0);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const long t = T0 + Tj + 8 * g + 4 * kk;                     // frame of register 4g (relative to row0)
+        const float y0 = acc[4 * g], y1 = acc[4 * g + 1], y2 = acc[4 * g + 2], y3 = acc[4 * g + 3];
+        if (t + 3 < (long)ns && vec_ok) {
+            if (pcm && ((reinterpret_cast<uintptr_t>(pcm) & 7) == 0)) {
+                uint2 w;
+                w.x = (unsigned)(uint16_t)pcm16(y0) | ((unsigned)(uint16_t)pcm16(y1) << 16);
+                w.y = (unsigned)(uint16_t)pcm16(y2) | ((unsigned)(uint16_t)pcm16(y3) << 16);
+                *reinterpret_cast<uint2 *>(pcm + (size_t)ch * stride + t) = w;
+            } else if (pcm) {
+                int16_t *o = pcm + (size_t)ch * stride + t;
+                o[0] = pcm16(y0); o[1] = pcm16(y1); o[2] = pcm16(y2); o[3] = pcm16(y3);
+            }
+            if (audio && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0))
+                *reinterpret_cast<float4 *>(audio + (size_t)ch * stride + t) = make_float4(y0, y1, y2, y3);
+            else if (audio) {
+                float *o = audio + (size_t)ch * stride + t;
+                o[0] = y0; o[1] = y1; o[2] = y2; o[3] = y3;
+            }
+        } else {
+            const float yy[4] = {y0, y1, y2, y3};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (t + q < (long)ns) {
+                    if (pcm) pcm[(size_t)ch * stride + t + q] = pcm16(yy[q]);
+                    if (audio) audio[(size_t)ch * stride + t + q] = yy[q];
+                }
+            }
+        }
+        if (out_tm) {
+            const float yy[4] = {y0, y1, y2, y3};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (t + q < (long)ns) out_tm[((unsigned long long)(row0 + t + q) & row_mask) * M + ch] = yy[q];
+        }
+    }
+}
+
+extern "C" int pmr_fir_mfma_supported(unsigned M, unsigned ntaps) { return M == 16 && ntaps >= 2 && ntaps <= 1024; }
+
+extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
+                                   unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm,
+                                   float *audio, unsigned stride)
+{
+    if (!ns) return 0;
+    if (!pmr_fir_mfma_supported(M, ntaps)) return (int)hipErrorInvalidValue;
+    const unsigned qlen = ntaps + 2 * PMR_TAP_PAD, nrows = FM_TILE + ntaps - 1 + 18;
+    const size_t lds = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float) +
+                       ((size_t)nrows * 16 + 16 * ((nrows >> 5) + 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_fir_mfma16, dim3((ns + FM_TILE - 1) / FM_TILE), dim3(FM_NT), lds, (hipStream_t)s, in,
+                       (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride);
+    return (int)hipGetLastError();
+}

@@ -31,6 +31,18 @@ static __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
 static __device__ __forceinline__ cf cadd_scale(cf a, cf b, float s) { return (a + b) * cf{s, s}; }
 static __device__ __forceinline__ cf cfma(float h, cf x, cf acc) { return __builtin_elementwise_fma(cf{h, h}, x, acc); }
 
+// Cross-lane moves on the VALU (DPP), not through the LDS crossbar: the kernel is LDS-instruction-bound.
+//   row_shr:n (0x110+n) shift inside a 16-lane row; wave_shr:1 (0x138) shift across the whole wave;
+//   row_bcast:15 / row_bcast:31 (0x142 / 0x143) lane 15 / 31 of a row to every lane of the next row(s).
+// Lanes without a source (or masked rows) receive `old` = 0.
+template <int CTRL, int ROW_MASK = 0xF>
+static __device__ __forceinline__ float dpp0(float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+static __device__ __forceinline__ cf dpp0c(cf v) { return cf{dpp0<CTRL, ROW_MASK>(v.x), dpp0<CTRL, ROW_MASK>(v.y)}; }
+
 // LDS layout L(G): element e lives at e + e/G (one 8-byte pad per G elements) so that threads whose chunks
 // are G elements apart hit distinct banks with ds_read_b64 / ds_write_b64 (stride 2G+2 dwords, gcd with 64 = 2).
 template <int G> static __device__ __forceinline__ int lidx(int e) { return e + e / G; }
@@ -190,7 +202,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? FE_WAVES_512 : 4) void k_frontend(p
     __syncthreads();
     if (stamps) ts[1] = clock64();
 
-    // ---- phase B: dc blocker (:795) from zero state, in place ----
+    // ---- phase B: dc blocker (:795) from zero state.  With a 6-tap first stage (m = 3, every cascade of >= 3 stages)
+    // the first half-band stage is computed right here from registers: no write-back of yb, no window re-read. ----
+    cf *bnd = wagg + NT / 64;                                // [NT/64][10] last 10 dc-blocked samples of every wave
+    const bool fuse0 = SPT == 16 && p.h >= 1 && p.m[0] == 3 && !(p.ablate & 6);
     if (!(p.ablate & 2)) {
         const float lp = p.lam_lane_pow[lane];              // lambda^(SPT lane)
         cf xs[SPT];
@@ -199,16 +214,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? FE_WAVES_512 : 4) void k_frontend(p
         cf v = cfm(0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < SPT; j++) v = cfma(lam, v, xs[j]);             // v0 = x - a1 v1
-        // inclusive decayed scan across the wave: inc_l = sum_{s<=l} lambda^(SPT (l-s)) agg_s
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const int d = 1 << j;
-            const cf t = cfm(__shfl_up(v.x, d), __shfl_up(v.y, d));
-            if (lane >= d) v = cfma(p.lam_pow16[j], t, v);
-        }
+        // inclusive decayed scan across the wave (DPP): inc_l = sum_{s<=l} lambda^(SPT (l-s)) agg_s
+        v = cfma(p.lam_pow16[0], dpp0c<0x111>(v), v);                      // row_shr:1
+        v = cfma(p.lam_pow16[1], dpp0c<0x112>(v), v);                      // row_shr:2
+        v = cfma(p.lam_pow16[2], dpp0c<0x114>(v), v);                      // row_shr:4
+        v = cfma(p.lam_pow16[3], dpp0c<0x118>(v), v);                      // row_shr:8
+        v = cfma(p.lam_lane_pow[(lane & 15) + 1], dpp0c<0x142, 0xA>(v), v);   // row_bcast:15 -> rows 1, 3
+        v = cfma(p.lam_lane_pow[(lane & 31) + 1], dpp0c<0x143, 0xC>(v), v);   // row_bcast:31 -> rows 2, 3
         if (lane == 63) wagg[wave] = v;
-        cf ex = cfm(__shfl_up(v.x, 1), __shfl_up(v.y, 1));
-        if (lane == 0) ex = cfm(0.f, 0.f);
+        const cf ex = dpp0c<0x138>(v);                                     // wave_shr:1 (lane 0 <- 0)
         __syncthreads();
         cf cw = cfm(0.f, 0.f);                                             // v (local) at the end of the previous wave
         for (int w = 0; w < wave; w++) cw = cfma(p.lam_wave, cw, wagg[w]);
@@ -217,10 +231,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? FE_WAVES_512 : 4) void k_frontend(p
         const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
         const int pE = (c == p.c_end) ? p.off_end : -1;
         const bool stray = (pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid);
+        cf yb[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             const cf v0 = cfma(lam, v1, xs[j]);
-            buf[(SPT + 1) * tid + j] = csub(v0, v1);                       // y = v0 - v1
+            yb[j] = csub(v0, v1);                                          // y = v0 - v1
             v1 = v0;
             if (stray) {
                 if (SPT * tid + j == pL) ((cf *)p.probeL)[0] = v0;
@@ -229,6 +244,42 @@ __global__ __launch_bounds__(NT, NT == 512 ? FE_WAVES_512 : 4) void k_frontend(p
         }
         if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;               // local v at tile offset Hh-1
         if (tid == NT - 1) ((cf *)p.probeB)[c] = v1;                       // local v at tile offset N0-1
+        if constexpr (SPT == 16) {
+            if (fuse0) {
+                // halo of stage 0: the previous thread's yb[6..15] (lane 0: previous wave's lane 63, through LDS)
+                cf W[26];
+#pragma unroll
+                for (int i = 0; i < 10; i++) W[i] = dpp0c<0x138>(yb[6 + i]);
+#pragma unroll
+                for (int i = 0; i < 16; i++) W[10 + i] = yb[i];
+                if (lane == 63) {
+#pragma unroll
+                    for (int i = 0; i < 10; i++) bnd[wave * 10 + i] = yb[6 + i];
+                }
+                __syncthreads();                                           // also: every thread is done with the raw tile
+                if (lane == 0 && wave > 0) {
+#pragma unroll
+                    for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * 10 + i];
+                }
+                // z1[8 tid + q] = W[2q + 5] + sum_j h1[j] W[2q + 2j]   (window offset 0 <-> sample 16 tid - 10)
+                const float *__restrict__ h1 = p.hb_taps + p.tap_off[0];
+                const float scale0 = p.h == 1 ? p.zeta : 1.0f;
+                cf *o = buf + tid * 9;                                     // layout L(8)
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    cf a = cfm(0.f, 0.f);
+#pragma unroll
+                    for (int j = 0; j < 6; j++) a = cfma(h1[j], W[2 * q + 2 * j], a);
+                    o[q] = cadd_scale(W[2 * q + 5], a, scale0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SPT; j++) buf[(SPT + 1) * tid + j] = yb[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) buf[(SPT + 1) * tid + j] = yb[j];
+        }
     }
     __syncthreads();
     if (stamps) ts[2] = clock64();
@@ -238,7 +289,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? FE_WAVES_512 : 4) void k_frontend(p
     if (!(p.ablate & 4)) {
         const float *__restrict__ taps = p.hb_taps;
         int n_out = N0 >> 1;
-        for (int e = 0; e < p.h; e++) {
+        int e0 = 0;
+        if (fuse0) { e0 = 1; n_out >>= 1; g_shift = 3; }     // stage 0 already done, its output sits in L(8)
+        for (int e = e0; e < p.h; e++) {
             const int mm = p.m[e];
             const float *h1 = taps + p.tap_off[e];
             const float scale = (e == p.h - 1) ? p.zeta : 1.0f;
@@ -365,7 +418,7 @@ template <int NT, int SPT>
 static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
 {
     const size_t n0 = (size_t)NT * SPT;
-    const size_t lds = (FE_PAD + n0 + n0 / SPT + 32) * sizeof(cf);   /* pad + tile + scan scratch */
+    const size_t lds = (FE_PAD + n0 + n0 / SPT + 32 + 10 * (NT / 64 + 1)) * sizeof(cf);   /* pad + tile + scan scratch + halo exchange */
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend<NT, SPT>),
@@ -383,6 +436,8 @@ extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsig
 {
     if (!ntiles) return 0;
     if (nt == 512 && spt == 8) return launch_frontend_t<512, 8>((hipStream_t)s, p, ntiles);
+    if (nt == 128 && spt == 16) return launch_frontend_t<128, 16>((hipStream_t)s, p, ntiles);
+    if (nt == 192 && spt == 16) return launch_frontend_t<192, 16>((hipStream_t)s, p, ntiles);
     if (nt == 256 && spt == 16) return launch_frontend_t<256, 16>((hipStream_t)s, p, ntiles);
     if (nt == 1024 && spt == 16) return launch_frontend_t<1024, 16>((hipStream_t)s, p, ntiles);
     return (int)hipErrorInvalidValue;

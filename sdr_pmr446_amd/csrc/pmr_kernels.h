@@ -91,6 +91,12 @@ int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_mask, int64_
                       const float *taps_pad, unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                       float *out_tm, int16_t *pcm, float *audio, unsigned stride);
 
+/* M = 16 audio FIR on the matrix pipe (pmr_fir_mfma.hip): banded-Toeplitz x data with v_mfma_f32_32x32x2_f32 */
+int pmr_fir_mfma_supported(unsigned M, unsigned ntaps);
+int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+                        const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio,
+                        unsigned stride);
+
 /* ---- fused front end (pmr_frontend.hip): dc-block + half-band cascade + arbitrary resampler in one pass ---- */
 #define PMR_FE_MAX_STAGES 16
 typedef struct {

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_fir_lds(const float *__restrict__ in, u
 // v_fma_f32 on gfx950 (tools/ubench/valu_rate.hip).  taps_c is h zero-padded by PMR_TAP_PAD on both sides.
 // ------------------------------------------------------------------------------------------------
 #define FP_R 16
-#define FP_J 4                                 /* de-emphasis pole^4 = 4.5e-8: below float32 resolution */
+#define FP_J 0                                 /* no IIR warm-up: the host folds gain + de-emphasis into the taps */
 #define FP_RP (FP_R + FP_J)
 
 static __device__ __forceinline__ int16_t pcm_from_float(float y)
@@ -647,12 +647,14 @@ extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_m
                                  float b1, float a1, float *out_tm, int16_t *pcm, float *audio, unsigned stride)
 {
     if (!ns) return 0;
-    static int mode = -1;                    /* 0 = pair (default), 1 = lds, 2 = global */
+    static int mode = -1;                    /* 3 = mfma (default where supported), 0 = pair, 1 = lds, 2 = global */
     if (mode < 0) {
         const char *e = getenv("PMR_FIR");
-        mode = (e && !strcmp(e, "lds")) ? 1 : (e && !strcmp(e, "global")) ? 2 : 0;
+        mode = (e && !strcmp(e, "lds")) ? 1 : (e && !strcmp(e, "global")) ? 2 : (e && !strcmp(e, "pair")) ? 0 : 3;
     }
-    if (mode == 0 && M >= 2) {
+    if (mode == 3 && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
+        return pmr_launch_fir_mfma(s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride);
+    if ((mode == 0 || mode == 3) && M >= 2) {
         const unsigned segs = (ns + FP_R - 1) / FP_R;
         const size_t threads = (size_t)segs * (M >> 1);
         hipLaunchKernelGGL(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
