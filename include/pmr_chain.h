@@ -94,7 +94,7 @@ int   pmr_chain_synchronize(pmr_chain q);
 void *pmr_chain_stream(pmr_chain q);                       /* hipStream_t the kernels are launched on   */
 
 /* ---- measurement hooks (bench.py): HIP-event time of every kernel launched by this handle ---- */
-int         pmr_chain_profile_enable(pmr_chain q, int on);
+int         pmr_chain_profile_enable(pmr_chain q, int mode);   /* 0 off, 1 every kernel, 2 only the front-end kernel */
 int         pmr_chain_profile_reset(pmr_chain q);
 unsigned    pmr_chain_profile_count(pmr_chain q);                          /* number of distinct kernels   */
 const char *pmr_chain_profile_name(pmr_chain q, unsigned i);
@@ -110,6 +110,15 @@ enum { PMR_DEBUG_RESAMPLED = 0,   /* cf32 [ny]  resampler output of the last blo
        PMR_DEBUG_FM = 1 };        /* f32 [ns][M] discriminator output of the last block, time-major     */
 int pmr_chain_debug_enable(pmr_chain q, int on);   /* capture the intermediates of subsequent blocks */
 int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes, size_t *n_bytes);
+
+/* ---- channel select + squelch hysteresis on rssi_db (host logic; mirrors find_max_rssi_channel,
+ * src/sdr_pmr446.c:668-700, and the proc_scanning / proc_tuned state machine, :828-874) ---- */
+enum { PMR_SCANNING = 0, PMR_TUNED = 1 };
+typedef struct { int state; int active_chan; float rssi; } pmr_squelch;
+void pmr_squelch_init(pmr_squelch *s);
+int  pmr_find_max_rssi_channel(const float *rssi_db, unsigned M, uint64_t channel_mask, float *max_rssi);
+int  pmr_squelch_update(pmr_squelch *s, const float *rssi_db, unsigned M, uint64_t channel_mask,
+                        float squelch_level /* :34 default 18 dB */, int lock_mode_max);
 
 /* ---- host-only helpers: pure arithmetic, need no HIP device (used by the CPU test tier) ---- */
 unsigned pmr_cfg_info(const pmr_chain_cfg *cfg, int what, unsigned idx);

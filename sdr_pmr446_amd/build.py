@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpmr446_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
-C_SOURCES = ["pmr_chain.c", "pmr_design.c"]
+C_SOURCES = ["pmr_chain.c", "pmr_design.c", "pmr_squelch.c"]
 HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_channelize_small.hip", "pmr_fir_mfma.hip"]
 EXTRA_HIP_FLAGS = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
 HEADERS = ["pmr_design.h", "pmr_kernels.h", os.path.join("..", "..", "include", "pmr_chain.h"),

@@ -24,7 +24,13 @@ ABI_SYMBOLS = [
     "pmr_chain_profile_reset", "pmr_chain_profile_count", "pmr_chain_profile_name", "pmr_chain_profile_get",
     "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read",
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
+    "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
 ]
+
+
+class Squelch(C.Structure):
+    """pmr_squelch: state (0 scanning / 1 tuned), active_chan, rssi -- SURVEY s8 row f1."""
+    _fields_ = [("state", C.c_int), ("active_chan", C.c_int), ("rssi", C.c_float)]
 
 
 class PlanState(C.Structure):
@@ -105,6 +111,12 @@ def load(build_if_missing=True):
     L.pmr_chain_debug_enable.restype = i
     L.pmr_chain_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pmr_chain_debug_read.restype = i
+    L.pmr_squelch_init.argtypes = [C.POINTER(Squelch)]
+    L.pmr_squelch_init.restype = None
+    L.pmr_find_max_rssi_channel.argtypes = [vp, u, C.c_uint64, C.POINTER(C.c_float)]
+    L.pmr_find_max_rssi_channel.restype = i
+    L.pmr_squelch_update.argtypes = [C.POINTER(Squelch), vp, u, C.c_uint64, C.c_float, i]
+    L.pmr_squelch_update.restype = i
     L.pmr_cfg_info.argtypes = [C.POINTER(PmrCfg), i, u]
     L.pmr_cfg_info.restype = u
     L.pmr_cfg_design.argtypes = [C.POINTER(PmrCfg), i, u, vp, u]
@@ -256,8 +268,9 @@ class PmrChain:
         return ns.value
 
     # -- measurement / introspection -------------------------------------------------------------
-    def profile_enable(self, on=True):
-        self._check(self._L.pmr_chain_profile_enable(self.h, int(on)))
+    def profile_enable(self, mode=1):
+        """0 off, 1 every kernel, 2 only the front-end (roofline) kernel."""
+        self._check(self._L.pmr_chain_profile_enable(self.h, int(mode)))
 
     def profile_reset(self):
         self._check(self._L.pmr_chain_profile_reset(self.h))

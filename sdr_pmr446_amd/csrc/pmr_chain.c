@@ -142,6 +142,7 @@ static void prof_begin(pmr_chain q, int slot, prof_pending *pp, hipStream_t st)
 {
     pp->slot = -1;
     if (!q->prof_on) return;
+    if (q->prof_on == 2 && slot != K_FE) return;          /* mode 2: only the front-end (roofline) kernel */
     hipEvent_t ev[2];
     for (int i = 0; i < 2; i++) {
         if (q->npool) ev[i] = q->pool[--q->npool];
@@ -253,14 +254,17 @@ static int fe_init(pmr_chain q)
         int first = 256;
         if (gm && !strcmp(gm, "128x16")) first = 128;
         if (gm && !strcmp(gm, "192x16")) first = 192;
-        const int cands[3] = { first, 256, 1024 };
-        for (int ci = 0; ci < 3 && !nt; ci++) {
+        const int cands[4] = { first, 256, 512, 1024 };
+        for (int ci = 0; ci < 4 && !nt; ci++) {
             const int cand = cands[ci];
             const unsigned long N0c = (unsigned long)cand * 16;
             if (N0c % L || H + L > N0c) continue;
             const unsigned long t = (N0c - H) / L * L;
             const int last = cand == 1024;
-            if ((!last && t * 4 >= N0c * 3) || (last && t * 2 >= N0c) || (cand == first && first != 256 && t * 2 >= N0c)) {
+            const int mid = cand == 512 && gm && !strcmp(gm, "512x16");       /* 8192-sample tiles, 2 WGs per CU */
+            if (cand == 512 && !mid) continue;
+            if ((!last && !mid && t * 4 >= N0c * 3) || ((last || mid) && t * 2 >= N0c) ||
+                (cand == first && first != 256 && t * 2 >= N0c)) {
                 nt = cand; T_own = t;
             }
         }
@@ -449,7 +453,7 @@ static int chain_init(pmr_chain q)
     if ((rc = dev_alloc(q, (void **)&q->d_audio, out_n * sizeof(float)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_chan, out_n * sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_rssi, (size_t)M * sizeof(float)))) return rc;
-    q->rssi_part_cap = (size_t)pmr_channelize_tiles(q->chan_size, M) * M;
+    q->rssi_part_cap = ((size_t)q->chan_size + 2) * M;   /* worst case: one new frame per channelizer tile */
     if ((rc = dev_alloc(q, (void **)&q->d_rssi_part, q->rssi_part_cap * sizeof(float)))) return rc;
 
     if ((rc = fe_init(q))) return rc;

@@ -154,7 +154,7 @@ static __device__ __forceinline__ unsigned long long ceil_div_u64(unsigned long 
 
 // NT threads own a tile of N0 = NT * SPT raw samples (SPT consecutive samples per thread in the dc scan).
 template <int NT, int SPT>
-__global__ __launch_bounds__(NT, NT == 512 ? FE_WAVES_512 : 4) void k_frontend(pmr_fe_params p)
+__global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) void k_frontend(pmr_fe_params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int N0 = NT * SPT;
@@ -440,6 +440,7 @@ extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsig
     if (nt == 192 && spt == 16) return launch_frontend_t<192, 16>((hipStream_t)s, p, ntiles);
     if (nt == 256 && spt == 16) return launch_frontend_t<256, 16>((hipStream_t)s, p, ntiles);
     if (nt == 1024 && spt == 16) return launch_frontend_t<1024, 16>((hipStream_t)s, p, ntiles);
+    if (nt == 512 && spt == 16) return launch_frontend_t<512, 16>((hipStream_t)s, p, ntiles);
     return (int)hipErrorInvalidValue;
 }
 

@@ -177,13 +177,20 @@ __global__ __launch_bounds__(256) void k_arb(const cf *__restrict__ dec, cf *__r
 // One workgroup owns FT frames in LDS (the first one is the frame BEFORE its range, recomputed so the
 // discriminator has conj(prev) without a cross-workgroup dependency).
 // ------------------------------------------------------------------------------------------------
-static __host__ __device__ inline unsigned chan_ft(unsigned M) { unsigned ft = 8192u / M; return ft < 4u ? 4u : ft; }
+// frames held in LDS per workgroup (one of them is the recomputed previous frame): at most 64 KB worth, and few enough
+// that a block still yields ~1000 workgroups (the work per frame is small; parallelism is what matters)
+static __host__ __device__ inline unsigned chan_ft(unsigned M, unsigned ns)
+{
+    unsigned cap = 8192u / M; if (cap < 4u) cap = 4u;
+    unsigned want = ns / 1024u + 2u;
+    return want < cap ? want : cap;
+}
 
 __global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned log2M)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned M = q.M, p = q.p, ns = q.ns;
-    const unsigned FT = chan_ft(M), TFN = FT - 1;
+    const unsigned FT = chan_ft(M, ns), TFN = FT - 1;
     cf *Xs = reinterpret_cast<cf *>(smem);            // [FT][M]
     cf *tw = Xs + (size_t)FT * M;                     // [M/2]
     const cf *__restrict__ xr = (const cf *)q.xr;
@@ -614,7 +621,7 @@ extern "C" int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out_ring, u
 
 extern "C" unsigned pmr_channelize_tiles(unsigned ns, unsigned M)
 {
-    const unsigned tfn = chan_ft(M) - 1;
+    const unsigned tfn = chan_ft(M, ns) - 1;
     return (ns + tfn - 1) / tfn;
 }
 
@@ -623,7 +630,7 @@ extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, u
     const unsigned ntiles = pmr_channelize_tiles(p->ns, p->M);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
-    const size_t lds = ((size_t)chan_ft(p->M) * p->M + p->M / 2) * sizeof(cf);
+    const size_t lds = ((size_t)chan_ft(p->M, p->ns) * p->M + p->M / 2) * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize),
