@@ -52,6 +52,19 @@ def cpu_baseline(fs, M, block_host, seconds_target=12.0):
                       (n_blocks, n_probe, M, dt)}
 
 
+def load_measured_traffic(kernel, workload, block):
+    """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE), if they were taken for this workload/block."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t.get("%s/%s/%d" % (workload, kernel, block))
+        return e["hbm_bytes_per_launch"] if e else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,7 +123,9 @@ def main():
     ch.profile_enable(0)
     prof_roof = ch.profile()
     breakdown_steps = 0
-    if not args.no_kernel_events:                 # separate pass, outside the timed region: every kernel
+    if not args.no_kernel_events:
+        # separate pass, outside the timed region: every kernel, blocks NOT pipelined (uncontended kernel times)
+        ch.set_overlap(False)
         ch.profile_reset()
         ch.profile_enable(1)
         breakdown_steps = min(args.steps, 5)
@@ -118,6 +133,7 @@ def main():
             step()
         ch.synchronize()
         ch.profile_enable(0)
+        ch.set_overlap(True)
 
     prof = ch.profile()
     if rank == 0:
@@ -134,8 +150,15 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": ms / n,
                     "launches_per_step": launches_per_step,
                     "algorithmic_bytes_per_sample": b_alg,
-                    "kernels_ms_per_step_separate_pass": {k: v[0] / max(1, breakdown_steps)
-                                                          for k, v in sorted(prof.items())}}
+                    "kernels_ms_per_step_isolated": {k: v[0] / max(1, breakdown_steps)
+                                                     for k, v in sorted(prof.items())}}
+            iso = prof.get(name)
+            if iso and iso[1]:
+                iso_s = iso[0] / iso[1] * 1e-3
+                roof["isolated"] = {"avg_kernel_ms": iso[0] / iso[1], "achieved": b_alg * block / iso_s / 1e9,
+                                    "frac": b_alg * block / iso_s / 1e9 / HBM_PEAK_GBPS,
+                                    "note": "same kernel with block pipelining off (no other kernel sharing the GPU)"}
+            roof["traffic"] = load_measured_traffic(name, args.workload, block)
         out = {
             "metric": "complex-IQ Msamples/s through full channelize+demod chain", "value": value,
             "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -91,6 +91,9 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
                                    void *d_pcm, void *d_audio, unsigned pcm_stride, unsigned *n_frames,
                                    void *d_chan_out, void *d_rssi_db);
 int   pmr_chain_synchronize(pmr_chain q);
+/* Consecutive blocks pipeline on two HIP streams (front end of block b+1 under the back end of block b); 0 runs
+ * every block start-to-finish before the next one (kernel timings then are uncontended).  Default: on.          */
+int   pmr_chain_set_overlap(pmr_chain q, int on);
 void *pmr_chain_stream(pmr_chain q);                       /* hipStream_t the kernels are launched on   */
 
 /* ---- measurement hooks (bench.py): HIP-event time of every kernel launched by this handle ---- */

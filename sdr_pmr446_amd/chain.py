@@ -20,7 +20,7 @@ DEBUG_RESAMPLED, DEBUG_FM = range(2)
 ABI_SYMBOLS = [
     "pmr_chain_default_cfg", "pmr_chain_create", "pmr_chain_reset", "pmr_chain_destroy", "pmr_chain_max_frames",
     "pmr_chain_num_channels", "pmr_chain_last_error", "pmr_chain_process_block", "pmr_chain_process_block_f32",
-    "pmr_chain_process_block_device", "pmr_chain_synchronize", "pmr_chain_stream", "pmr_chain_profile_enable",
+    "pmr_chain_process_block_device", "pmr_chain_synchronize", "pmr_chain_set_overlap", "pmr_chain_stream", "pmr_chain_profile_enable",
     "pmr_chain_profile_reset", "pmr_chain_profile_count", "pmr_chain_profile_name", "pmr_chain_profile_get",
     "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read",
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
@@ -97,6 +97,8 @@ def load(build_if_missing=True):
     L.pmr_chain_process_block_f32.restype = i
     L.pmr_chain_process_block_device.argtypes = [vp, vp, u, vp, vp, u, C.POINTER(u), vp, vp]
     L.pmr_chain_process_block_device.restype = i
+    L.pmr_chain_set_overlap.argtypes = [vp, i]
+    L.pmr_chain_set_overlap.restype = i
     L.pmr_chain_profile_enable.argtypes = [vp, i]
     L.pmr_chain_profile_enable.restype = i
     L.pmr_chain_profile_name.argtypes = [vp, u]
@@ -219,6 +221,9 @@ class PmrChain:
 
     def synchronize(self):
         self._check(self._L.pmr_chain_synchronize(self.h))
+
+    def set_overlap(self, on=True):
+        self._check(self._L.pmr_chain_set_overlap(self.h, int(on)))
 
     @property
     def stream(self):

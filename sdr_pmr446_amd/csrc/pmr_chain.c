@@ -881,6 +881,14 @@ int pmr_chain_process_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, int1
 
 int pmr_chain_profile_enable(pmr_chain q, int on) { if (!q) return PMR_EINVAL; q->prof_on = on; return PMR_OK; }
 
+int pmr_chain_set_overlap(pmr_chain q, int on)
+{
+    if (!q) return PMR_EINVAL;
+    int rc = pmr_chain_synchronize(q);
+    q->overlap = on ? 1 : 0;
+    return rc;
+}
+
 int pmr_chain_profile_reset(pmr_chain q)
 {
     if (!q) return PMR_EINVAL;

@@ -152,8 +152,14 @@ static __device__ __forceinline__ unsigned long long ceil_div_u64(unsigned long 
     return q;
 }
 
-// NT threads own a tile of N0 = NT * SPT raw samples (SPT consecutive samples per thread in the dc scan).
-template <int NT, int SPT>
+// NT threads own a tile of N0 = NT * SPT input samples (SPT consecutive samples per thread in the dc scan).
+// MODE 0: whole front end (raw in -> dc-block -> all stages -> resampler).
+// Deep cascades (tile halo would eat the tile) run as two launches of the same code:
+// MODE 1: level 1 = raw in -> dc-block -> the first few (6-tap) stages -> decimated stream stored to a ring;
+// MODE 2: level 2 = ring in (dc carry of level 1 applied at load) -> remaining stages -> resampler.
+enum { FE_FULL = 0, FE_L1 = 1, FE_L2 = 2 };
+
+template <int NT, int SPT, int MODE>
 __global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) void k_frontend(pmr_fe_params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,15 +172,67 @@ __global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) voi
     const cf *__restrict__ x = (const cf *)p.x;
     const cf *__restrict__ hist = (const cf *)p.hist;
     const float lam = -p.dc_a1;
-    const int c = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so give every XCD
+    // a CONTIGUOUS range of tiles -- a tile's halo is its left neighbour's tail and can then be an L2 hit instead of a
+    // second HBM read (PMC: 8 % extra fetch without it).  Placement only affects speed, never results.
+    int c = blockIdx.x;
+    {
+        const int nt_all = gridDim.x, per = nt_all >> 3, main = per << 3;
+        if (c < main) c = (c & 7) * per + (c >> 3);
+    }
     const long b0 = (long)c * p.T_own - p.Hh - p.pend;      // block-relative index of tile sample 0
     unsigned long long *stamps = (unsigned long long *)p.stamps;   // diagnostic build only (PMR_FE_STAMP)
     long long ts[5] = {0, 0, 0, 0, 0};
     if (stamps) ts[0] = clock64();
 
+    // ---- resampler bookkeeping first: which outputs this tile owns, and the polyphase taps of this thread's first
+    // output (a dependent global load: issued now, it lands while the raw tile streams in) ----
+    const unsigned long long qa = (unsigned long long)c * p.TQ;
+    unsigned long long ja = 0, jb = 0;
+    {
+        unsigned long long qb = qa + p.TQ;
+        if (qb > p.Q) qb = p.Q;
+        if (MODE != FE_L1 && qa < qb && !(p.ablate & 8)) {
+            const unsigned long long sa = qa << 24, sb = qb << 24;
+            ja = sa <= p.phi0 ? 0ull : ceil_div_u64(sa - p.phi0, p.step);
+            jb = sb <= p.phi0 ? 0ull : ceil_div_u64(sb - p.phi0, p.step);
+            if (jb > p.ny) jb = p.ny;
+        }
+    }
+    float bk0[14];
+    {
+        const unsigned long long j = ja + tid;
+        const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
+        const unsigned idx = j < jb ? (unsigned)(ph & 0xffffffu) >> 16 : 0u;
+        const float *b = p.arb_bank + idx * 14u;
+#pragma unroll
+        for (int k = 0; k < 14; k++) bk0[k] = b[k];
+    }
+
     // ---- phase A: raw samples -> LDS (layout L(SPT)); history for b < 0, zeros beyond the block ----
     if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
-    if (!(p.ablate & 1)) {
+    if (MODE == FE_L2) {
+        // level-2 input: the decimated ring written by level 1; sample r of the tile has absolute index in_abs0 + b0 + r.
+        // Samples produced by THIS call (abs >= in_abs0) still miss their dc carry: V_c1 * K1 * mu^i' (see k_fe_dcfix).
+        const cf *__restrict__ ring = (const cf *)p.in_ring;
+        const cf *__restrict__ V1 = (const cf *)p.fixV;
+        for (int i = tid; i < N0; i += NT) {
+            const long long a = (long long)p.in_abs0 + b0 + i;
+            const long long jn = b0 + i;                              // index among this call's new samples
+            cf v = cfm(0.f, 0.f);
+            if (a >= 0 && jn < (long long)p.n_in) {
+                v = ring[(unsigned long long)a & p.in_mask];
+                if (V1 && jn >= 0) {
+                    const unsigned c1 = (unsigned)jn / p.fix_TQ;
+                    const unsigned ql = (unsigned)jn - c1 * p.fix_TQ + p.fix_HhQ;
+                    const float g = p.fix_K * (p.fix_T1[ql >> 5] * p.fix_T2[ql & 31]);
+                    const cf Vc = V1[c1];
+                    v = cf{fmaf(-Vc.x, g, v.x), fmaf(-Vc.y, g, v.y)};
+                }
+            }
+            buf[lidx<SPT>(i)] = v;
+        }
+    } else if (!(p.ablate & 1)) {
         // interior tile, 16-byte aligned: all loads of the thread are issued before the first LDS write
         const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
         if (fast) {
@@ -211,6 +269,12 @@ __global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) voi
         cf xs[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; j++) xs[j] = buf[(SPT + 1) * tid + j];
+        cf yb[SPT];
+        if constexpr (MODE == FE_L2) {
+            (void)lp;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) yb[j] = xs[j];                   // level 2: the input is already dc-blocked
+        } else {
         cf v = cfm(0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < SPT; j++) v = cfma(lam, v, xs[j]);             // v0 = x - a1 v1
@@ -231,7 +295,6 @@ __global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) voi
         const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
         const int pE = (c == p.c_end) ? p.off_end : -1;
         const bool stray = (pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid);
-        cf yb[SPT];
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             const cf v0 = cfma(lam, v1, xs[j]);
@@ -244,6 +307,7 @@ __global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) voi
         }
         if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;               // local v at tile offset Hh-1
         if (tid == NT - 1) ((cf *)p.probeB)[c] = v1;                       // local v at tile offset N0-1
+        }
         if constexpr (SPT == 16) {
             if (fuse0) {
                 // halo of stage 0: the previous thread's yb[6..15] (lane 0: previous wave's lane 63, through LDS)
@@ -307,35 +371,42 @@ __global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) voi
     }
     if (stamps) ts[3] = clock64();
 
+    // ---- level 1: store the owned part of the last stage's output to the decimated ring; no resampler ----
+    if constexpr (MODE == FE_L1) {
+        (void)bk0; (void)ja; (void)jb;
+        cf *__restrict__ out = (cf *)p.out;
+        const unsigned long long q0 = qa;                               // first decimated sample this tile owns
+        for (int i = tid; i < p.TQ; i += NT) {
+            const unsigned long long q1 = q0 + i;
+            if (q1 < p.Q) out[(p.out_pos0 + q1) & p.out_mask] = buf[lidx_rt(p.HhQ + i, g_shift)];
+        }
+    }
     // ---- phase D: arbitrary resampler (24-bit phase) for the outputs whose input sample is owned here ----
-    if (!(p.ablate & 8)) {
-        const unsigned long long qa = (unsigned long long)c * p.TQ;
-        unsigned long long qb = qa + p.TQ;
-        if (qb > p.Q) qb = p.Q;
-        if (qa < qb) {
-            const unsigned long long sa = qa << 24, sb = qb << 24;
-            const unsigned long long ja = sa <= p.phi0 ? 0ull : ceil_div_u64(sa - p.phi0, p.step);
-            unsigned long long jb = sb <= p.phi0 ? 0ull : ceil_div_u64(sb - p.phi0, p.step);
-            if (jb > p.ny) jb = p.ny;
-            const float *__restrict__ bank = p.arb_bank;
-            cf *__restrict__ out = (cf *)p.out;
-            for (unsigned long long j = ja + tid; j < jb; j += NT) {
-                const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
-                const int ql = (int)((ph >> 24) - qa) + p.HhQ;          // tile-local decimated index
+    if (MODE != FE_L1 && !(p.ablate & 8)) {
+        cf *__restrict__ out = (cf *)p.out;
+        bool first = true;
+        for (unsigned long long j = ja + tid; j < jb; j += NT) {
+            const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
+            const int ql = (int)((ph >> 24) - qa) + p.HhQ;              // tile-local decimated index
+            float bk[14];
+            if (first) {
+#pragma unroll
+                for (int k = 0; k < 14; k++) bk[k] = bk0[k];
+            } else {
                 const unsigned idx = (unsigned)(ph & 0xffffffu) >> 16;
-                const float *b = bank + idx * 14u;
-                float bk[14];
+                const float *b = p.arb_bank + idx * 14u;
 #pragma unroll
                 for (int k = 0; k < 14; k++) bk[k] = b[k];
-                cf y = cfm(0.f, 0.f);
-#pragma unroll
-                for (int k = 0; k < 14; k++) y = cfma(bk[k], buf[lidx_rt(ql - 13 + k, g_shift)], y);
-                out[(p.out_pos0 + j) & p.out_mask] = y;
             }
+            first = false;
+            cf y = cfm(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 14; k++) y = cfma(bk[k], buf[lidx_rt(ql - 13 + k, g_shift)], y);
+            out[(p.out_pos0 + j) & p.out_mask] = y;
         }
     }
     // ---- raw history for the next call (last hcap samples of old history || block), by workgroup 0 ----
-    if (c == 0 && p.new_hist) {
+    if (MODE != FE_L2 && c == 0 && p.new_hist) {
         cf *__restrict__ nh = (cf *)p.new_hist;
         for (int i = tid; i < p.hcap; i += NT) {
             const long sb = (long)i + (long)p.n_in - (long)p.hcap;      // block-relative index
@@ -389,12 +460,14 @@ __global__ __launch_bounds__(256) void k_fe_dcfix(pmr_fe_fix_params p)
 {
     const unsigned j = p.j0 + blockIdx.x * 256u + threadIdx.x;
     if (j >= p.ny) return;
+    // step != 0: j indexes resampler outputs (decimated index and polyphase gain from the 24-bit phase);
+    // step == 0: j indexes decimated samples directly (the level-1 ring of a two-level front end)
     const unsigned long long ph = (unsigned long long)p.phi0 + (unsigned long long)j * p.step;
-    const unsigned q = (unsigned)(ph >> 24);
+    const unsigned q = p.step ? (unsigned)(ph >> 24) : j;
     const unsigned idx = (unsigned)(ph & 0xffffffu) >> 16;
     const unsigned c = q / p.TQ;
     const unsigned ql = q - c * p.TQ + p.HhQ;
-    const float g = p.Kgain * p.GA[idx] * (p.T1[ql >> 5] * p.T2[ql & 31]);
+    const float g = p.Kgain * (p.step ? p.GA[idx] : 1.0f) * (p.T1[ql >> 5] * p.T2[ql & 31]);
     const cf V = ((const cf *)p.V)[c];
     cf *o = (cf *)p.xr + ((p.pos0 + j) & p.mask);
     cf v = *o;
@@ -414,18 +487,18 @@ __global__ __launch_bounds__(256) void k_fe_hist(const cf *__restrict__ old_hist
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int NT, int SPT>
+template <int NT, int SPT, int MODE>
 static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
 {
     const size_t n0 = (size_t)NT * SPT;
     const size_t lds = (FE_PAD + n0 + n0 / SPT + 32 + 10 * (NT / 64 + 1)) * sizeof(cf);   /* pad + tile + scan scratch + halo exchange */
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend<NT, SPT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend<NT, SPT, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    auto kern = k_frontend<NT, SPT>;
+    auto kern = k_frontend<NT, SPT, MODE>;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), lds, st, *p);
     return (int)hipGetLastError();
 }
@@ -435,12 +508,16 @@ static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned nt
 extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt)
 {
     if (!ntiles) return 0;
-    if (nt == 512 && spt == 8) return launch_frontend_t<512, 8>((hipStream_t)s, p, ntiles);
-    if (nt == 128 && spt == 16) return launch_frontend_t<128, 16>((hipStream_t)s, p, ntiles);
-    if (nt == 192 && spt == 16) return launch_frontend_t<192, 16>((hipStream_t)s, p, ntiles);
-    if (nt == 256 && spt == 16) return launch_frontend_t<256, 16>((hipStream_t)s, p, ntiles);
-    if (nt == 1024 && spt == 16) return launch_frontend_t<1024, 16>((hipStream_t)s, p, ntiles);
-    if (nt == 512 && spt == 16) return launch_frontend_t<512, 16>((hipStream_t)s, p, ntiles);
+    hipStream_t st = (hipStream_t)s;
+    if (p->mode == FE_L1 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L1>(st, p, ntiles);
+    if (p->mode == FE_L2 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L2>(st, p, ntiles);
+    if (p->mode != FE_FULL) return (int)hipErrorInvalidValue;
+    if (nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_FULL>(st, p, ntiles);
+    if (nt == 1024 && spt == 16) return launch_frontend_t<1024, 16, FE_FULL>(st, p, ntiles);
+    if (nt == 512 && spt == 16) return launch_frontend_t<512, 16, FE_FULL>(st, p, ntiles);
+    if (nt == 512 && spt == 8) return launch_frontend_t<512, 8, FE_FULL>(st, p, ntiles);
+    if (nt == 128 && spt == 16) return launch_frontend_t<128, 16, FE_FULL>(st, p, ntiles);
+    if (nt == 192 && spt == 16) return launch_frontend_t<192, 16, FE_FULL>(st, p, ntiles);
     return (int)hipErrorInvalidValue;
 }
 

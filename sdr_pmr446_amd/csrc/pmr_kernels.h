@@ -114,6 +114,11 @@ typedef struct {
     uint32_t phi0, step;        /* resamp_crcf phase before the block's first decimated sample, step */
     int h, T_own, Hh, HhQ, TQ;  /* stages; owned raw samples per tile, halo (raw / decimated), owned decimated */
     int pend, hcap, c_end, off_end;
+    int mode;                   /* 0 whole front end; 1 level 1 (store decimated stream); 2 level 2 (ring input) */
+    /* level 2 input: decimated ring of level 1; in_abs0 = absolute index of this call's first new sample; the dc carry
+     * of level-1 tile c1 = j / fix_TQ is subtracted at load: V[c1] * fix_K * mu^(j - c1 fix_TQ + fix_HhQ)       */
+    const void *in_ring; uint64_t in_mask; int64_t in_abs0;
+    const void *fixV; const float *fix_T1, *fix_T2; unsigned fix_TQ, fix_HhQ; float fix_K;
     void *stamps;               /* diagnostic: 8 x u64 per-phase cycle sums (PMR_FE_STAMP), else NULL  */
     int ablate;                 /* timing experiments only (PMR_FE_ABLATE): bit0 skip load, 1 dc, 2 cascade, 3 resampler */
     int m[PMR_FE_MAX_STAGES], tap_off[PMR_FE_MAX_STAGES];
