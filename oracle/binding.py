@@ -25,7 +25,7 @@ class OrcCfg(C.Structure):
         ("fs_in", C.c_double), ("num_channels", C.c_uint), ("channel_width_hz", C.c_double),
         ("dcblock_alpha", C.c_float), ("resamp_As", C.c_float), ("pfb_m", C.c_uint), ("pfb_As", C.c_float),
         ("fm_kf", C.c_float), ("audio_gain", C.c_float), ("lowpass", C.c_int), ("deemph_fir", C.c_int),
-        ("max_block", C.c_uint), ("only_channel", C.c_int),
+        ("max_block", C.c_uint), ("only_channel", C.c_int), ("ctcss_block", C.c_uint),
         ("hp_taps", C.POINTER(C.c_float)), ("hp_len", C.c_uint),
         ("lp_taps", C.POINTER(C.c_float)), ("lp_len", C.c_uint),
         ("deemph_taps", C.POINTER(C.c_float)), ("deemph_len", C.c_uint),
@@ -36,7 +36,11 @@ class OrcTaps(C.Structure):
     _fields_ = [
         ("resampled", C.c_void_p), ("resampled_cap", C.c_uint), ("n_resampled", C.c_uint),
         ("fm", C.c_void_p), ("ctcss_lp", C.c_void_p), ("audio", C.c_void_p), ("stride", C.c_uint),
+        ("ctcss_events", C.c_void_p), ("ctcss_cap", C.c_uint), ("ctcss_n", C.c_uint),
     ]
+
+
+CTCSS_EVENT = np.dtype([("index", np.int32), ("detected", np.int32), ("max_power", np.float32), ("avg_power", np.float32)])
 
 
 _lib = None
@@ -181,6 +185,12 @@ class OracleChain:
                 bufs[name] = np.zeros((M, S), dtype=np.float32)
                 setattr(taps, name, bufs[name].ctypes.data)
         taps.stride = S
+        ev = None
+        if "ctcss" in want:
+            cap = S // 2441 + 2
+            ev = np.zeros((M, cap), dtype=CTCSS_EVENT)
+            taps.ctcss_events = ev.ctypes.data
+            taps.ctcss_cap = cap
         ns = C.c_uint(0)
         rc = lib().orc_chain_process_block(
             self.h, iq.ctypes.data, len(iq), pcm.ctypes.data, S, C.byref(ns),
@@ -199,4 +209,6 @@ class OracleChain:
         for name in ("fm", "ctcss_lp", "audio"):
             if name in bufs:
                 out[name] = bufs[name][:, :n].copy()
+        if ev is not None:
+            out["ctcss"] = ev[:, :taps.ctcss_n].copy()
         return out

@@ -22,6 +22,7 @@ void orc_chain_default_cfg(orc_chain_cfg *c)
     c->deemph_fir = 0;             /* :457 */
     c->max_block = 100000;         /* :30 */
     c->only_channel = -1;
+    c->ctcss_block = 2441;         /* :37,:46 */
 }
 
 /* PCM hand-off: reference src/dsd_in.c:172-175 `buf_out_s[i] = out_buf[i] * INT16_MAX` (C float->int16
@@ -33,6 +34,58 @@ int16_t orc_pcm_from_float(float x)
     if (s >= 32767.0f) return 32767;
     if (s <= -32768.0f) return -32768;
     return (int16_t)s;
+}
+
+/* reference src/sdr_pmr446.c:338-347 */
+static void ctcss_detector_reset(orc_ctcss_detector *c)
+{
+    c->samp_processed = 0; c->max_power = 0.0f; c->max_power_index = 0; c->tone_detected = 0;
+    for (int j = 0; j < ORC_CTCSS_NUM_FREQS; ++j) c->power[j] = c->u0[j] = c->u1[j] = 0.0f;
+}
+
+/* :349-364 */
+static void ctcss_detector_init(orc_ctcss_detector *c, double audio_rate)
+{
+    ctcss_detector_reset(c);
+    for (int j = 0; j < ORC_CTCSS_NUM_FREQS; ++j)
+        c->coef[j] = 2.0f * cosf((2.0 * M_PI * pmr446_ctcss_freqs[j]) / audio_rate);
+}
+
+/* :366-409; returns the number of Goertzel blocks completed, appending one event per block */
+static unsigned ctcss_detector_analyze(orc_ctcss_detector *c, const float *xs, unsigned nx, unsigned block,
+                                       orc_ctcss_event *ev, unsigned cap)
+{
+    unsigned nev = 0;
+    for (unsigned i = 0; i < nx; i++) {
+        const float in = xs[i];
+        for (int j = 0; j < ORC_CTCSS_NUM_FREQS; ++j) {
+            float t = c->u0[j];
+            c->u0[j] = in + (c->coef[j] * c->u0[j]) - c->u1[j];
+            c->u1[j] = t;
+        }
+        c->samp_processed += 1;
+        if (c->samp_processed == block) {
+            for (int j = 0; j < ORC_CTCSS_NUM_FREQS; ++j) {
+                c->power[j] = (c->u0[j] * c->u0[j]) + (c->u1[j] * c->u1[j]) - (c->coef[j] * c->u0[j] * c->u1[j]);
+                c->u0[j] = c->u1[j] = 0.0;
+            }
+            float avg_power = 0.0f;
+            c->max_power = 0.0f;
+            for (int j = 0; j < ORC_CTCSS_NUM_FREQS; ++j) {
+                avg_power += c->power[j];
+                if (c->power[j] > c->max_power) { c->max_power = c->power[j]; c->max_power_index = j; }
+            }
+            avg_power /= ORC_CTCSS_NUM_FREQS;
+            c->tone_detected = (avg_power > 120.0f) && ((c->max_power / avg_power) > 10.0f);
+            c->samp_processed = 0;
+            if (ev && nev < cap) {
+                ev[nev].index = c->max_power_index; ev[nev].detected = c->tone_detected;
+                ev[nev].max_power = c->max_power; ev[nev].avg_power = avg_power;
+            }
+            nev++;
+        }
+    }
+    return nev;
 }
 
 /* reference src/sdr_pmr446.c:330-336 */
@@ -78,6 +131,8 @@ orc_chain *orc_chain_create(const orc_chain_cfg *cfg)
         c->ctcss_filt = orc_firfilt_rrrf_create(q->cfg.hp_taps, q->cfg.hp_len);                   /* :443 */
         c->ctcss_lp_delay = orc_wdelayf_create((q->cfg.hp_len - 1) / 2);                          /* :447 */
         c->audio_filt = orc_firfilt_rrrf_create(q->cfg.lp_taps, q->cfg.lp_len);                   /* :453 */
+        c->ctcss_dcblock = orc_iirfilt_rrrf_create_dc_blocker(0.0005f);                           /* :450 */
+        ctcss_detector_init(&c->ctcss, cfg->channel_width_hz);                                    /* :777 (AUDIO_SAMPLERATE == CHANNEL_WIDTH_HZ, :24) */
         if (cfg->deemph_fir) {
             c->deemph_fir = orc_firfilt_rrrf_create(q->cfg.deemph_taps, q->cfg.deemph_len);       /* :458 */
         } else {
@@ -108,6 +163,8 @@ int orc_chain_reset(orc_chain *q)
         orc_firfilt_rrrf_reset(c->ctcss_filt);
         orc_wdelayf_reset(c->ctcss_lp_delay);
         orc_firfilt_rrrf_reset(c->audio_filt);
+        orc_iirfilt_rrrf_reset(c->ctcss_dcblock);
+        ctcss_detector_reset(&c->ctcss);
         if (c->deemph_iir) orc_iirfilt_rrrf_reset(c->deemph_iir);
         if (c->deemph_fir) orc_firfilt_rrrf_reset(c->deemph_fir);
     }
@@ -126,6 +183,7 @@ int orc_chain_destroy(orc_chain *q)
         orc_firfilt_rrrf_destroy(c->ctcss_filt);
         orc_wdelayf_destroy(c->ctcss_lp_delay);
         orc_firfilt_rrrf_destroy(c->audio_filt);
+        orc_iirfilt_rrrf_destroy(c->ctcss_dcblock);
         orc_iirfilt_rrrf_destroy(c->deemph_iir);
         orc_firfilt_rrrf_destroy(c->deemph_fir);
     }
@@ -195,6 +253,13 @@ int orc_chain_process_block(orc_chain *q, const cf32 *iq, unsigned n_in,
             t2[k] *= q->cfg.audio_gain;
         }
         if (taps && taps->ctcss_lp) memcpy(taps->ctcss_lp + (size_t)i * taps->stride, t1, ns * sizeof(float));
+        {   /* ctcss_execute(), :605-628: dc-block the low-pass branch in place, then the Goertzel bank */
+            orc_iirfilt_rrrf_execute_block(c->ctcss_dcblock, t1, ns, t1);                 /* :606 */
+            unsigned nev = ctcss_detector_analyze(&c->ctcss, t1, ns, q->cfg.ctcss_block ? q->cfg.ctcss_block : 2441,
+                                                  taps && taps->ctcss_events ? taps->ctcss_events + (size_t)i * taps->ctcss_cap : NULL,
+                                                  taps ? taps->ctcss_cap : 0);             /* :610 */
+            if (taps) taps->ctcss_n = nev;
+        }
         if (c->deemph_fir) orc_firfilt_rrrf_execute_block(c->deemph_fir, t2, ns, t2);  /* :896 */
         else               orc_iirfilt_rrrf_execute_block(c->deemph_iir, t2, ns, t2);  /* :898 */
         if (q->cfg.lowpass) orc_firfilt_rrrf_execute_block(c->audio_filt, t2, ns, t2); /* :901 */

@@ -25,10 +25,19 @@ typedef struct {
     int      deemph_fir;         /* :457  APP_FIR_DEEMPH     0 = IIR                        */
     unsigned max_block;          /* :30   SDR_INPUT_CHUNK    100000                         */
     int      only_channel;       /* -1 = demodulate all channels; k = reference semantics   */
+    unsigned ctcss_block;        /* :46   CTCSS_BLOCK_SIZE   2441 (Goertzel length)         */
     const float *hp_taps; unsigned hp_len;          /* :56-104, 377  */
     const float *lp_taps; unsigned lp_len;          /* :106-119, 103 */
     const float *deemph_taps; unsigned deemph_len;  /* :121-136, 101 */
 } orc_chain_cfg;
+
+/* CTCSS tone detector (reference src/sdr_pmr446.c:338-418, struct include/sdr_pmr446.h:42-52) */
+#define ORC_CTCSS_NUM_FREQS 38
+typedef struct {
+    float coef[ORC_CTCSS_NUM_FREQS], u0[ORC_CTCSS_NUM_FREQS], u1[ORC_CTCSS_NUM_FREQS], power[ORC_CTCSS_NUM_FREQS];
+    float max_power; int max_power_index; unsigned samp_processed; int tone_detected;
+} orc_ctcss_detector;
+typedef struct { int index; int detected; float max_power; float avg_power; } orc_ctcss_event;
 
 typedef struct {
     orc_freqdem        fm_demod;
@@ -37,6 +46,8 @@ typedef struct {
     orc_firfilt_rrrf  *audio_filt;
     orc_iirfilt_rrrf  *deemph_iir;
     orc_firfilt_rrrf  *deemph_fir;
+    orc_iirfilt_rrrf  *ctcss_dcblock;    /* :450, run :606 */
+    orc_ctcss_detector ctcss;            /* :777 */
 } orc_chan_state;
 
 typedef struct orc_chain_s {
@@ -59,6 +70,8 @@ typedef struct {
     float   *ctcss_lp;    /* [M][stride] delayed - highpassed branch (:889), pre ctcss_execute      */
     float   *audio;       /* [M][stride] float audio handed to the sink (:904)                       */
     unsigned stride;
+    /* CTCSS decisions of every Goertzel block completed in this call (:381-406): [M][ctcss_cap] */
+    orc_ctcss_event *ctcss_events; unsigned ctcss_cap; unsigned ctcss_n;
 } orc_taps;
 
 void       orc_chain_default_cfg(orc_chain_cfg *cfg);

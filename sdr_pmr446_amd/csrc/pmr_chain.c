@@ -27,11 +27,11 @@
 typedef struct { float re, im; } cfl;
 
 enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
-       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_CHANNELIZE_SMALL, K_COUNT };
+       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_CHANNELIZE_SMALL, K_FE_L2, K_COUNT };
 static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
                                         "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
                                         "k_fir_tm<lp>", "k_frontend", "k_fe_tiles", "k_fe_dcfix", "k_fe_hist",
-                                        "k_channelize_small" };
+                                        "k_channelize_small", "k_frontend<level2>" };
 
 typedef struct { hipEvent_t a, b; int slot; } prof_pending;
 
@@ -75,6 +75,12 @@ struct pmr_chain_s {
     float *d_fe_taps, *d_fe_GA, *d_fe_T1, *d_fe_T2, *d_fe_lam_lane;
     cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V[2];
     uint64_t *d_fe_stamps;           /* diagnostic per-phase cycle sums (PMR_FE_STAMP)                */
+    /* two-level front end for deep cascades: level 1 = dc-block + first fe_s1 stages -> decimated ring, level 2 = rest */
+    int fe_two;                      /* 1: two launches of k_frontend (modes 1 and 2)                 */
+    int fe_s1;                       /* stages in level 1 (all 6-tap)                                  */
+    int fe2_T_own, fe2_Hh, fe2_HhQ, fe2_TQ;   /* level-2 tile geometry, in level-1 output samples      */
+    float fe1_K;                     /* alpha * prod G_e (e < s1): dc-carry gain at the level-1 output */
+    cfl *d_fe_ring1; uint64_t ring1_mask;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     unsigned fe_max_tiles;
 
@@ -243,8 +249,28 @@ static int fe_init(pmr_chain q)
         q->fe_m[e] = (int)d->m_stage[h - 1 - e];
         S += (unsigned long)(4 * q->fe_m[e] - 2) << e;
     }
-    const unsigned long H = S + 13ul * D;
-    const unsigned long L = D > 16 ? D : 16;
+    unsigned long H = S + 13ul * D;
+    unsigned long L = D > 16 ? D : 16;
+    /* Deep cascades: with 4096-sample tiles the halo H would eat the tile.  Split: level 1 = all but the last three
+     * stages (6-tap filters, halo 10*(2^s1 - 1) raw samples), level 2 = the last three stages + resampler on the
+     * 2^s1-times decimated stream.  Costs 16/2^s1 B per raw sample of extra HBM traffic, keeps 4 workgroups per CU. */
+    q->fe_two = 0; q->fe_s1 = 0;
+    {
+        const char *lv = getenv("PMR_FE_LEVELS");
+        const int want_two = lv ? atoi(lv) == 2 : (h >= 5 && (4096ul - (H < 4096ul ? H : 4096ul)) * 4 < 4096ul * 3);
+        if (want_two && h >= 4) {
+            int ok = 1;
+            for (unsigned e = 0; e + 3 < h; e++) if (q->fe_m[e] != 3) ok = 0;
+            if (ok) { q->fe_two = 1; q->fe_s1 = (int)h - 3; }
+        }
+    }
+    const unsigned s1 = (unsigned)q->fe_s1, D1 = 1u << s1;
+    if (q->fe_two) {                              /* level-1 geometry replaces the single-level one below */
+        S = 0;
+        for (unsigned e = 0; e < s1; e++) S += (unsigned long)(4 * q->fe_m[e] - 2) << e;
+        H = S;
+        L = D1 > 16 ? D1 : 16;
+    }
     int nt = 0;
     unsigned long T_own = 0;
     {
@@ -277,11 +303,26 @@ static int fe_init(pmr_chain q)
         if (g && !strcmp(g, "512x8")) { q->fe_nt = 512; q->fe_spt = 8; }   /* measured slower than 256 x 16 */
     }
     q->fe_T_own = (int)T_own;
+    const unsigned Dl = q->fe_two ? D1 : D;       /* decimation of the (first) level */
     q->fe_Hh = (int)(N0 - T_own);
-    q->fe_HhQ = q->fe_Hh / (int)D;
-    q->fe_TQ = (int)(T_own / D);
-    q->fe_hcap = (int)((q->fe_Hh + D + 15) / 16 * 16);
-    q->fe_max_tiles = (unsigned)((q->cfg.max_block + D) / T_own + 2);
+    q->fe_HhQ = q->fe_Hh / (int)Dl;
+    q->fe_TQ = (int)(T_own / Dl);
+    q->fe_hcap = (int)((q->fe_Hh + Dl + 15) / 16 * 16);
+    q->fe_max_tiles = (unsigned)((q->cfg.max_block + Dl) / T_own + 2);
+    if (q->fe_two) {
+        if (nt != 256) return PMR_OK;             /* level kernels exist for 256 x 16 tiles only */
+        const unsigned D2 = 1u << (h - s1);
+        unsigned long S2 = 0;
+        for (unsigned e = s1; e < h; e++) S2 += (unsigned long)(4 * q->fe_m[e] - 2) << (e - s1);
+        const unsigned long H2 = S2 + 13ul * D2, L2 = D2 > 16 ? D2 : 16;
+        if (H2 + L2 > 4096) return PMR_OK;
+        const unsigned long t2 = (4096 - H2) / L2 * L2;
+        q->fe2_T_own = (int)t2; q->fe2_Hh = (int)(4096 - t2); q->fe2_HhQ = q->fe2_Hh / (int)D2; q->fe2_TQ = (int)(t2 / D2);
+        uint64_t need = (uint64_t)q->fe2_Hh + D2 + 2ull * ((q->cfg.max_block >> s1) + 2) + 64, cap = 1;
+        while (cap < need) cap <<= 1;
+        q->ring1_mask = cap - 1;
+        if ((rc = dev_alloc(q, (void **)&q->d_fe_ring1, (size_t)cap * sizeof(cfl)))) return rc;
+    }
 
     /* branch taps of all stages, execution order */
     {
@@ -301,15 +342,18 @@ static int fe_init(pmr_chain q)
      * G_e = mu * sum_k hb_e[k] mu^-k;  after the cascade dec_err[q'] = alpha zeta prod(G_e) V mu_h^q';
      * the arbitrary resampler adds GA[idx] = sum_n hA[idx + 256 n] mu_h^-n.  All in double.          */
     const double lam = d->dc_lambda, alpha = 1.0 - lam;
-    double mu = lam, G = 1.0;
+    double mu = lam, G = 1.0, mu1 = lam;
+    q->fe1_K = (float)alpha;
     for (unsigned e = 0; e < h; e++) {
         const unsigned g = h - 1 - e, n = 4 * d->m_stage[g] + 1;
         double acc = 0.0;
         for (unsigned k = 0; k < n; k++) acc += (double)d->hb_proto[g][k] * pow(mu, -(double)k);
         G *= mu * acc;
         mu *= mu;
+        if (q->fe_two && e + 1 == s1) { q->fe1_K = (float)(alpha * G); mu1 = mu; }
     }
     q->fe_Kgain = (float)(alpha * (double)d->zeta * G);
+    if (q->fe_two) mu = mu1;                      /* the carry is removed at the level-1 output: tables for mu_s1 */
     {
         float ga[PMR_ARB_NPFB];
         for (unsigned idx = 0; idx < PMR_ARB_NPFB; idx++) {
@@ -319,7 +363,7 @@ static int fe_init(pmr_chain q)
             ga[idx] = (float)acc;
         }
         if ((rc = dev_upload(q, &q->d_fe_GA, ga, PMR_ARB_NPFB))) return rc;
-        const unsigned nq = (unsigned)(N0 / D), n1 = nq / 32 + 2;
+        const unsigned nq = (unsigned)(N0 / (q->fe_two ? D1 : D)), n1 = nq / 32 + 2;
         float *t1 = (float *)calloc(n1, sizeof(float)), t2[32];
         if (!t1) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
         for (unsigned i = 0; i < n1; i++) t1[i] = (float)pow(mu, 32.0 * i);
@@ -528,7 +572,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1] };
+                     q->d_fe_V[1], q->d_fe_ring1 };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     if (q->stream) hipStreamDestroy(q->stream);
     pmr_design_free(&q->d);
@@ -552,6 +596,7 @@ int pmr_chain_reset(pmr_chain q)
         HIPCHK(hipMemsetAsync(q->d_aux1, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
         HIPCHK(hipMemsetAsync(q->d_aux2, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
     }
+    if (q->d_fe_ring1) HIPCHK(hipMemsetAsync(q->d_fe_ring1, 0, (size_t)(q->ring1_mask + 1) * sizeof(cfl), q->stream), "reset");
     if (q->fe_on) for (int i = 0; i < 2; i++) {
         HIPCHK(hipMemsetAsync(q->d_fe_hist[i], 0, (size_t)q->fe_hcap * sizeof(cfl), q->stream), "reset");
         HIPCHK(hipMemsetAsync(q->d_fe_vstate[i], 0, sizeof(cfl), q->stream), "reset");
@@ -710,6 +755,95 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     return PMR_OK;
 }
 
+/* front end, two levels (deep cascades): level 1 = dc-block + first s1 stages -> d_fe_ring1; level 2 = remaining
+ * stages + resampler reading that ring (pmr_frontend.hip modes 1 and 2) */
+static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny_out)
+{
+    const pmr_design *d = &q->d;
+    const unsigned h = d->num_stages, s1 = (unsigned)q->fe_s1, h2 = h - s1, D1 = 1u << s1, D2 = 1u << h2;
+    *ny_out = 0;
+    if (n_in == 0) return PMR_OK;
+    const unsigned pend1 = (unsigned)(q->n_raw & (D1 - 1));
+    const uint64_t A = q->n_raw >> s1;                                   /* level-1 output samples before this call */
+    const unsigned Q1 = (unsigned)(((q->n_raw + n_in) >> s1) - A);       /* ... produced by this call               */
+    const unsigned Q = (unsigned)(((q->n_raw + n_in) >> h) - (q->n_raw >> h));
+    unsigned ny = 0, ns_unused = 0; uint32_t new_phase = 0;
+    plan_core(h, d->arb_step, q->M, q->n_raw, q->arb_phase, 0, n_in, &ny, &ns_unused, &new_phase);
+    const int cur = q->fe_sel, nxt = cur ^ 1;
+    const unsigned par = (unsigned)(q->n_calls & 1);
+
+    /* ---- level 1 ---- */
+    const unsigned long total1 = (unsigned long)pend1 + n_in;
+    const unsigned ntiles1 = (unsigned)((total1 + q->fe_T_own - 1) / q->fe_T_own);
+    const unsigned c_end = (unsigned)((total1 - 1) / q->fe_T_own);
+    const int off_end = (int)((total1 - 1) - (unsigned long)c_end * q->fe_T_own) + q->fe_Hh;
+    if (ntiles1 > q->fe_max_tiles) return fail(q, PMR_ERANGE, "tile count", hipSuccess);
+    pmr_fe_params p;
+    memset(&p, 0, sizeof(p));
+    p.mode = 1;
+    p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt];
+    p.out = q->d_fe_ring1; p.out_pos0 = A; p.out_mask = q->ring1_mask;
+    p.probeA = q->d_fe_probeA; p.probeB = q->d_fe_probeB; p.probeL = q->d_fe_probeL; p.probeE = q->d_fe_probeE;
+    p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
+    p.n_in = n_in; p.ny = 0; p.Q = Q1; p.phi0 = 0; p.step = 1;
+    p.h = (int)s1; p.T_own = q->fe_T_own; p.Hh = q->fe_Hh; p.HhQ = q->fe_HhQ; p.TQ = q->fe_TQ;
+    p.pend = (int)pend1; p.hcap = q->fe_hcap; p.c_end = (int)c_end; p.off_end = off_end;
+    memcpy(p.m, q->fe_m, sizeof(p.m)); memcpy(p.tap_off, q->fe_tap_off, sizeof(p.tap_off));
+    p.dc_a1 = d->dc_a1; p.zeta = 1.0f; p.lam_wave = q->fe_lam_wave;
+    memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
+    LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles1, 256, 16));
+
+    pmr_fe_tiles_params t;
+    memset(&t, 0, sizeof(t));
+    const double lam = d->dc_lambda;
+    const double rho = pow(lam, (double)q->fe_T_own);
+    double kterms = rho > 0.0 && rho < 1.0 ? ceil(log(1e-12) / log(rho)) : 1.0;
+    if (kterms < 1.0) kterms = 1.0;
+    if (kterms > 1e6) kterms = 1e6;
+    t.probeA = q->d_fe_probeA; t.probeB = q->d_fe_probeB; t.probeL = q->d_fe_probeL; t.probeE = q->d_fe_probeE;
+    t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V[par];
+    t.ntiles = ntiles1; t.K = (unsigned)kterms; t.c_end = c_end;
+    t.rho = (float)rho; t.lamHh = (float)pow(lam, (double)q->fe_Hh); t.inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
+    t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend1)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
+    LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
+
+    /* ---- level 2: Q1 new samples of the decimated ring -> last h2 stages -> resampler ---- */
+    if (Q1) {
+        const unsigned pend2 = (unsigned)(A & (D2 - 1));
+        const unsigned long total2 = (unsigned long)pend2 + Q1;
+        const unsigned ntiles2 = (unsigned)((total2 + q->fe2_T_own - 1) / q->fe2_T_own);
+        pmr_fe_params p2;
+        memset(&p2, 0, sizeof(p2));
+        p2.mode = 2;
+        p2.in_ring = q->d_fe_ring1; p2.in_mask = q->ring1_mask; p2.in_abs0 = (int64_t)A;
+        p2.fixV = q->d_fe_V[par]; p2.fix_T1 = q->d_fe_T1; p2.fix_T2 = q->d_fe_T2;
+        p2.fix_TQ = (unsigned)q->fe_TQ; p2.fix_HhQ = (unsigned)q->fe_HhQ; p2.fix_K = q->fe1_K;
+        p2.out = q->d_xr; p2.out_pos0 = q->xr_abs; p2.out_mask = q->xr_mask;
+        p2.hb_taps = q->d_fe_taps; p2.arb_bank = q->d_arb_bank; p2.lam_lane_pow = q->d_fe_lam_lane;
+        p2.n_in = Q1; p2.ny = ny; p2.Q = Q; p2.phi0 = q->arb_phase; p2.step = d->arb_step;
+        p2.h = (int)h2; p2.T_own = q->fe2_T_own; p2.Hh = q->fe2_Hh; p2.HhQ = q->fe2_HhQ; p2.TQ = q->fe2_TQ;
+        p2.pend = (int)pend2; p2.hcap = 0; p2.c_end = (int)ntiles2 - 1; p2.off_end = 0;
+        for (unsigned e = 0; e < h2; e++) { p2.m[e] = q->fe_m[s1 + e]; p2.tap_off[e] = q->fe_tap_off[s1 + e]; }
+        p2.dc_a1 = d->dc_a1; p2.zeta = d->zeta; p2.lam_wave = q->fe_lam_wave;
+        memcpy(p2.lam_pow16, q->fe_lam_pow16, sizeof(p2.lam_pow16));
+        (void)D2;
+        LAUNCH_FE(K_FE_L2, pmr_launch_frontend(q->stream_fe, &p2, ntiles2, 256, 16));
+
+        /* level 2 corrected its private copy; what the next call re-reads as history gets its dc carry in place */
+        const unsigned keep = (unsigned)q->fe2_Hh + D2 + 16;
+        pmr_fe_fix_params f;
+        memset(&f, 0, sizeof(f));
+        f.xr = q->d_fe_ring1; f.pos0 = A; f.mask = q->ring1_mask; f.V = q->d_fe_V[par]; f.GA = q->d_fe_GA;
+        f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2; f.ny = Q1; f.j0 = Q1 > keep ? Q1 - keep : 0;
+        f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = 0; f.step = 0; f.Kgain = q->fe1_K;
+        LAUNCH_FE(K_FE_FIX, pmr_launch_fe_dcfix(q->stream_fe, &f));
+    }
+    q->fe_sel = nxt;
+    q->arb_phase = new_phase;
+    *ny_out = ny;
+    return PMR_OK;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 
 /* copy `n` elements starting at absolute ring index `pos` into a linear device buffer (debug capture) */
@@ -751,7 +885,8 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
     const uint32_t phi0 = q->arb_phase;          /* resampler phase before this block (dc carry bookkeeping) */
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
-    if ((rc = q->fe_on ? frontend_fused(q, d_iq, n_in, &ny) : frontend_staged(q, d_iq, n_in, &ny))) return rc;
+    if ((rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
+                        : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny))) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
     HIPCHK(hipEventRecord(q->ev_fe[par], q->stream_fe), "record");
     q->n_raw += n_in;
@@ -778,7 +913,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         c.fm_ref = d->fm_ref; c.chan_out = d_chan_out; c.chan_stride = pcm_stride;
         c.rssi_part = d_rssi_db ? q->d_rssi_part : NULL;
         if (q->chan_small) {
-            const int fuse_fix = q->fe_on && ny && !q->dbg_on;
+            const int fuse_fix = q->fe_on && !q->fe_two && ny && !q->dbg_on;
             if (fuse_fix) {                      /* deferred dc carry of the fused front end, applied while staging */
                 c.V = q->d_fe_V[par]; c.GA = q->d_fe_GA; c.T1 = q->d_fe_T1; c.T2 = q->d_fe_T2;
                 c.fix_abs0 = xr_abs0; c.fix_ny = ny; c.TQ = (unsigned)q->fe_TQ; c.HhQ = (unsigned)q->fe_HhQ;
@@ -819,7 +954,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
             }
         }
     }
-    if (q->chan_small && q->fe_on && ny && !q->dbg_on) {
+    if (q->chan_small && q->fe_on && !q->fe_two && ny && !q->dbg_on) {
         /* The staging pass corrected its private copy only.  What later blocks will re-read as history -- the last
          * (p+1)*M samples -- gets its dc carry in place now (after the channelizer, same stream). */
         const unsigned keep = (p + 1) * M;
