@@ -114,6 +114,17 @@ enum { PMR_DEBUG_RESAMPLED = 0,   /* cf32 [ny]  resampler output of the last blo
 int pmr_chain_debug_enable(pmr_chain q, int on);   /* capture the intermediates of subsequent blocks */
 int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes, size_t *n_bytes);
 
+/* ---- CTCSS tone detection for every channel (complementary low-pass branch src/sdr_pmr446.c:884-889,
+ * ctcss_execute :605-628, 38-tone Goertzel bank over 2441-sample blocks :366-409).  When enabled, every
+ * process_block call also runs the detector; each Goertzel block completed by the call yields one event per channel. ---- */
+typedef struct { int index;        /* strongest of the 38 tones (ctcss_freqs[index], :138-141)          */
+                 int detected;     /* avg power > 120 && max/avg > 10 (:403-404)                         */
+                 float max_power, avg_power; } pmr_ctcss_event;
+int pmr_chain_ctcss_enable(pmr_chain q, int on);
+/* events of the LAST process_block call: events[k * cap + e], e < *n_events (same count for every channel).
+ * Synchronises the chain's streams.                                                                       */
+int pmr_chain_ctcss_read(pmr_chain q, pmr_ctcss_event *events, unsigned cap, unsigned *n_events);
+
 /* ---- channel select + squelch hysteresis on rssi_db (host logic; mirrors find_max_rssi_channel,
  * src/sdr_pmr446.c:668-700, and the proc_scanning / proc_tuned state machine, :828-874) ---- */
 enum { PMR_SCANNING = 0, PMR_TUNED = 1 };

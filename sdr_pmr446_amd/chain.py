@@ -25,7 +25,11 @@ ABI_SYMBOLS = [
     "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read",
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
+    "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read",
 ]
+
+CTCSS_EVENT = np.dtype([("index", np.int32), ("detected", np.int32), ("max_power", np.float32),
+                        ("avg_power", np.float32)])
 
 
 class Squelch(C.Structure):
@@ -113,6 +117,10 @@ def load(build_if_missing=True):
     L.pmr_chain_debug_enable.restype = i
     L.pmr_chain_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pmr_chain_debug_read.restype = i
+    L.pmr_chain_ctcss_enable.argtypes = [vp, i]
+    L.pmr_chain_ctcss_enable.restype = i
+    L.pmr_chain_ctcss_read.argtypes = [vp, vp, u, C.POINTER(u)]
+    L.pmr_chain_ctcss_read.restype = i
     L.pmr_squelch_init.argtypes = [C.POINTER(Squelch)]
     L.pmr_squelch_init.restype = None
     L.pmr_find_max_rssi_channel.argtypes = [vp, u, C.c_uint64, C.POINTER(C.c_float)]
@@ -239,6 +247,8 @@ class PmrChain:
         audio = np.zeros((M, S), dtype=np.float32) if "audio" in want else None
         chan = np.zeros((M, S), dtype=np.complex64) if "chan" in want else None
         rssi = np.zeros(M, dtype=np.float32) if "rssi" in want else None
+        if "ctcss" in want:
+            self._check(self._L.pmr_chain_ctcss_enable(self.h, 1))
         dbg = bool(want & {"resampled", "fm"})
         if dbg:
             self._check(self._L.pmr_chain_debug_enable(self.h, 1))
@@ -256,6 +266,8 @@ class PmrChain:
             out["chan"] = chan[:, :n].copy()
         if rssi is not None:
             out["rssi"] = rssi
+        if "ctcss" in want:
+            out["ctcss"] = self.ctcss_read()
         if "resampled" in want:
             out["resampled"] = self.debug_read(DEBUG_RESAMPLED, np.complex64)
         if "fm" in want:
@@ -271,6 +283,14 @@ class PmrChain:
                                                            stride if stride is not None else self.max_frames,
                                                            C.byref(ns), d_chan, d_rssi))
         return ns.value
+
+    def ctcss_read(self):
+        """CTCSS decisions of the Goertzel blocks completed by the last block: structured array [M][n_events]."""
+        cap = self.max_frames // 2441 + 2
+        ev = np.zeros((self.M, cap), dtype=CTCSS_EVENT)
+        n = C.c_uint(0)
+        self._check(self._L.pmr_chain_ctcss_read(self.h, ev.ctypes.data, cap, C.byref(n)))
+        return ev[:, :n.value].copy()
 
     # -- measurement / introspection -------------------------------------------------------------
     def profile_enable(self, mode=1):

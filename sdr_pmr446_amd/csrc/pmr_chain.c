@@ -27,11 +27,12 @@
 typedef struct { float re, im; } cfl;
 
 enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
-       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_CHANNELIZE_SMALL, K_FE_L2, K_COUNT };
+       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_CHANNELIZE_SMALL, K_FE_L2, K_CT_FIR, K_CT_DC, K_CT_GOERTZEL, K_COUNT };
 static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
                                         "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
                                         "k_fir_tm<lp>", "k_frontend", "k_fe_tiles", "k_fe_dcfix", "k_fe_hist",
-                                        "k_channelize_small", "k_frontend<level2>" };
+                                        "k_channelize_small", "k_frontend<level2>", "k_fir_tm<ctcss_lp>",
+                                        "k_ct_dc_*", "k_ct_goertzel+final" };
 
 typedef struct { hipEvent_t a, b; int slot; } prof_pending;
 
@@ -65,6 +66,12 @@ struct pmr_chain_s {
     void *d_scratch; size_t scratch_bytes;
     int16_t *d_pcm; float *d_audio; cfl *d_chan; float *d_rssi, *d_rssi_part;
     size_t rssi_part_cap;
+
+    /* CTCSS branch (pmr_ctcss.hip), allocated by pmr_chain_ctcss_enable */
+    int ct_on; unsigned ct_max_ev, ct_nev_last; int ct_sel;
+    float *d_ctlp, *d_ct_taps, *d_ct_agg, *d_ct_W, *d_ct_dcstate, *d_ct_U, *d_ct_coef, *d_ct_part, *d_ct_carry[2];
+    pmr_ctcss_event *d_ct_events;
+    unsigned hp_len_raw;             /* length of the un-folded high-pass table (377)                 */
 
     /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
     int chan_small;                  /* small-M channelizer (pmr_channelize_small.hip) selected       */
@@ -456,6 +463,7 @@ static int chain_init(pmr_chain q)
         rc = upload_padded_taps(q, &q->d_hp_pad, g, n);
         free(g);
         if (rc) return rc;
+        q->hp_len_raw = q->hp_len;
         q->hp_len = n;
     }
     if ((rc = upload_padded_taps(q, &q->d_lp_pad, lp, q->lp_len))) return rc;
@@ -572,7 +580,8 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_ring1 };
+                     q->d_fe_V[1], q->d_fe_ring1, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     if (q->stream) hipStreamDestroy(q->stream);
     pmr_design_free(&q->d);
@@ -595,6 +604,12 @@ int pmr_chain_reset(pmr_chain q)
     if (q->d_aux1) {
         HIPCHK(hipMemsetAsync(q->d_aux1, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
         HIPCHK(hipMemsetAsync(q->d_aux2, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
+    }
+    if (q->d_ctlp) {
+        HIPCHK(hipMemsetAsync(q->d_ctlp, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
+        HIPCHK(hipMemsetAsync(q->d_ct_dcstate, 0, (size_t)M * sizeof(float), q->stream), "reset");
+        for (int i = 0; i < 2; i++)
+            HIPCHK(hipMemsetAsync(q->d_ct_carry[i], 0, (size_t)M * PMR_CT_TONES * 2 * sizeof(float), q->stream), "reset");
     }
     if (q->d_fe_ring1) HIPCHK(hipMemsetAsync(q->d_fe_ring1, 0, (size_t)(q->ring1_mask + 1) * sizeof(cfl), q->stream), "reset");
     if (q->fe_on) for (int i = 0; i < 2; i++) {
@@ -846,6 +861,95 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
 
 /* ------------------------------------------------------------------------------------------- */
 
+/* ---- CTCSS branch: low-pass branch FIR -> dc-block scan -> Goertzel bank, all channels ---- */
+static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns)
+{
+    const unsigned M = q->M, N = PMR_CT_BLOCK;
+    /* tmp1 = delay188(fm) - hp(fm) (:884-889) as one FIR with taps delta_188 - h */
+    LAUNCH(K_CT_FIR, pmr_launch_fir_tm(q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
+                                       0.f, 0.f, 0.f, q->d_ctlp, NULL, NULL, 0));
+    const float a1 = -1.0f + 0.0005f;                              /* iirfilt_rrrf_create_dc_blocker(0.0005f), :450 */
+    const double lam = -(double)a1;
+    const unsigned nchunks = (ns + 255) / 256, len_last = ns - (nchunks - 1) * 256;
+    LAUNCH(K_CT_DC, pmr_launch_ct_dc(q->stream, q->d_ctlp, q->fm_mask, frame0, ns, M, a1, (float)pow(lam, 256.0),
+                                     (float)pow(lam, (double)len_last), q->d_ct_dcstate, q->d_ct_agg, q->d_ct_W));
+    const uint64_t f0 = (uint64_t)frame0, f1 = f0 + ns;
+    const unsigned nblk = (unsigned)((f1 - 1) / N - f0 / N + 1), ncomplete = (unsigned)(f1 / N - f0 / N);
+    if (ncomplete > q->ct_max_ev) return fail(q, PMR_ERANGE, "ctcss events", hipSuccess);
+    const int cur = q->ct_sel, nxt = cur ^ 1;
+    HIPCHK(hipMemsetAsync(q->d_ct_carry[nxt], 0, (size_t)M * PMR_CT_TONES * 2 * sizeof(float), q->stream), "ctcss");
+    LAUNCH(K_CT_GOERTZEL, pmr_launch_ct_goertzel(q->stream, q->d_ctlp, q->fm_mask, frame0, ns, M, N, q->d_ct_U, q->d_ct_coef,
+                                                 q->d_ct_part, q->d_ct_carry[cur], q->d_ct_carry[nxt], q->d_ct_events,
+                                                 nblk, ncomplete));
+    q->ct_sel = nxt;
+    q->ct_nev_last = ncomplete;
+    return PMR_OK;
+}
+
+int pmr_chain_ctcss_enable(pmr_chain q, int on)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    int rc = pmr_chain_synchronize(q);
+    if (rc) return rc;
+    if (on && !q->d_ctlp) {
+        const unsigned M = q->M, N = PMR_CT_BLOCK, n = q->hp_len_raw;
+        if ((n & 1) == 0) return fail(q, PMR_EINVAL, "ctcss needs an odd-length high-pass", hipSuccess);
+        const float *hp = q->cfg.hp_taps ? q->cfg.hp_taps : pmr446_hp_audio_taps;
+        float *tc = (float *)calloc(n, sizeof(float));
+        if (!tc) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+        for (unsigned i = 0; i < n; i++) tc[i] = -hp[i];
+        tc[(n - 1) / 2] += 1.0f;                                   /* wdelayf((n-1)/2), :447 */
+        rc = upload_padded_taps(q, &q->d_ct_taps, tc, n);
+        free(tc);
+        if (rc) return rc;
+        /* Goertzel weights U_m = sin((m+1)w)/sin(w), coef = 2cos(w) as the reference computes it (:360-361) */
+        float coef[PMR_CT_TONES];
+        float *U = (float *)calloc((size_t)PMR_CT_TONES * (N + 1), sizeof(float));
+        if (!U) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+        for (unsigned j = 0; j < PMR_CT_TONES; j++) {
+            coef[j] = 2.0f * cosf((float)((2.0 * M_PI * pmr446_ctcss_freqs[j]) / q->cfg.channel_width_hz));
+            const double w = acos((double)coef[j] / 2.0);
+            for (unsigned i = 0; i <= N; i++) U[(size_t)j * (N + 1) + i] = (float)(sin((double)i * w) / sin(w));
+        }
+        rc = dev_upload(q, &q->d_ct_U, U, (size_t)PMR_CT_TONES * (N + 1));
+        free(U);
+        if (rc) return rc;
+        if ((rc = dev_upload(q, &q->d_ct_coef, coef, PMR_CT_TONES))) return rc;
+        const size_t rows = (size_t)(q->fm_mask + 1), nch = q->chan_size / 256 + 2;
+        q->ct_max_ev = q->chan_size / N + 2;
+        if ((rc = dev_alloc(q, (void **)&q->d_ctlp, rows * M * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_ct_agg, nch * M * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_ct_W, nch * M * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_ct_dcstate, (size_t)M * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_ct_part, (size_t)(q->ct_max_ev + 1) * PMR_CT_SEG * M * PMR_CT_TONES * 2 * sizeof(float)))) return rc;
+        for (int i = 0; i < 2; i++)
+            if ((rc = dev_alloc(q, (void **)&q->d_ct_carry[i], (size_t)M * PMR_CT_TONES * 2 * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(q, (void **)&q->d_ct_events, (size_t)(q->ct_max_ev + 1) * M * sizeof(pmr_ctcss_event)))) return rc;
+        HIPCHK(hipStreamSynchronize(q->stream), "ctcss init");
+    }
+    q->ct_on = on ? 1 : 0;
+    return PMR_OK;
+}
+
+int pmr_chain_ctcss_read(pmr_chain q, pmr_ctcss_event *events, unsigned cap, unsigned *n_events)
+{
+    if (!q || !q->d_ct_events) return PMR_EINVAL;
+    int rc = pmr_chain_synchronize(q);
+    if (rc) return rc;
+    const unsigned n = q->ct_nev_last, M = q->M;
+    if (n_events) *n_events = n;
+    if (!events || !n) return PMR_OK;
+    if (cap < n) return fail(q, PMR_ERANGE, "ctcss event capacity", hipSuccess);
+    pmr_ctcss_event *tmp = (pmr_ctcss_event *)malloc((size_t)n * M * sizeof(*tmp));
+    if (!tmp) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
+    hipError_t e = hipMemcpy(tmp, q->d_ct_events, (size_t)n * M * sizeof(*tmp), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        for (unsigned b = 0; b < n; b++) for (unsigned k = 0; k < M; k++) events[(size_t)k * cap + b] = tmp[(size_t)b * M + k];
+    free(tmp);
+    return e == hipSuccess ? PMR_OK : fail(q, PMR_EHIP, "ctcss D2H", e);
+}
+
 /* copy `n` elements starting at absolute ring index `pos` into a linear device buffer (debug capture) */
 static int ring_to_linear(pmr_chain q, void *dst, const void *ring, uint64_t mask, uint64_t pos, size_t n, size_t elem)
 {
@@ -902,6 +1006,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
     const unsigned ns = (unsigned)((q->xr_abs - q->frames_done * M) / M);
     const int64_t frame0 = (int64_t)q->frames_done;
     q->last_ns = ns;
+    q->ct_nev_last = 0;
 
     if (ns) {
         unsigned ntiles = 0;
@@ -930,6 +1035,8 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         }
         if (d_rssi_db)
             LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->d_rssi_part, ntiles, M, ns, (float *)d_rssi_db));
+
+        if (q->ct_on && (rc = ctcss_run(q, frame0, ns))) return rc;
 
         /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906) */
         if (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass) {

@@ -6,6 +6,8 @@
 
 #include <stdint.h>
 
+#include "../../include/pmr_chain.h"     /* pmr_ctcss_event */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -96,6 +98,16 @@ int pmr_fir_mfma_supported(unsigned M, unsigned ntaps);
 int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                         const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio,
                         unsigned stride);
+
+/* ---- CTCSS branch (pmr_ctcss.hip) ---- */
+#define PMR_CT_TONES 38u
+#define PMR_CT_SEG 8u           /* time segments a Goertzel block is split into */
+#define PMR_CT_BLOCK 2441u      /* CTCSS_BLOCK_SIZE, src/sdr_pmr446.c:37,:46 */
+int pmr_launch_ct_dc(pmr_stream_t s, float *lp, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M, float a1,
+                     float lam_chunk, float lam_last, float *state, float *agg, float *W);
+int pmr_launch_ct_goertzel(pmr_stream_t s, const float *lp, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+                           unsigned N, const float *U, const float *coef, float *part, const float *carry_in,
+                           float *carry_out, pmr_ctcss_event *events, unsigned nblk, unsigned ncomplete);
 
 /* ---- fused front end (pmr_frontend.hip): dc-block + half-band cascade + arbitrary resampler in one pass ---- */
 #define PMR_FE_MAX_STAGES 16

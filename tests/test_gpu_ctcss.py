@@ -1,0 +1,45 @@
+"""SURVEY s8 row f2 on the GPU: CTCSS tone detection for all channels vs the oracle restatement of
+src/sdr_pmr446.c:338-418, :605-628 -- tone index and decision exact where the decision is clear, powers within 0.5 %
+(the reference's float32 Goertzel recurrence itself wobbles by ~1e-5), Goertzel blocks that straddle calls included."""
+import numpy as np
+import pytest
+
+import oracle
+from parity_util import CFG2, CFG3, active_channels
+from sdr_pmr446_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(chain_obj, x, splits):
+    evs, pos = [], 0
+    for n in splits:
+        o = chain_obj.process_block(x[pos:pos + n], want=("pcm", "ctcss"))
+        pos += n
+        evs.append(o["ctcss"])
+    return np.concatenate(evs, axis=1)
+
+
+@pytest.mark.parametrize("fs,M,N,splits,ks", [
+    CFG2 + (1300000, [1300000], None),
+    CFG2 + (1300000, [400000, 1, 500000, 399999], None),          # 2441-frame Goertzel blocks straddle the calls
+    CFG3 + (1 << 25, [1 << 24, 1 << 24], list(range(0, 256, 9))),
+])
+def test_ctcss_matches_oracle(fs, M, N, splits, ks):
+    from sdr_pmr446_amd import chain
+    x = synth.synth_iq(N, fs, M, channels=ks, dev_hz=1500.0, ctcss_dev_hz=700.0)
+    mb = max(splits)
+    eo = _run(oracle.OracleChain(fs_in=fs, num_channels=M, max_block=mb), x, splits)
+    eg = _run(chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb), x, splits)
+    assert eo.shape == eg.shape and eo.shape[1] >= 2
+    fm_ch = [k for k in active_channels(M, ks) if synth.channel_kind(k) == "fm"]
+    for k in fm_ch:
+        assert np.all(eo["detected"][k] == 1)                                   # the test signal is a clear tone
+        assert np.array_equal(eg["index"][k], eo["index"][k])
+        assert np.all(eo["index"][k] == k % 38)                                 # ... and it is the right tone
+        assert np.array_equal(eg["detected"][k], eo["detected"][k])
+        assert np.allclose(eg["max_power"][k], eo["max_power"][k], rtol=5e-3)
+        assert np.allclose(eg["avg_power"][k], eo["avg_power"][k], rtol=5e-3)
+    carriers = [k for k in active_channels(M, ks) if synth.channel_kind(k) == "carrier"]
+    for k in carriers:                                                          # bare carrier: no tone, in both
+        assert not eo["detected"][k].any() and not eg["detected"][k].any()
