@@ -13,7 +13,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle_pmr.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orc_dsp.c", "orc_chain.c", "orc_dsp.h", "orc_chain.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_dsp.c", "orc_chain.c", "orc_dsd.c", "orc_dsp.h", "orc_chain.h", "orc_dsd.h")]
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -38,6 +38,11 @@ class OrcTaps(C.Structure):
         ("fm", C.c_void_p), ("ctcss_lp", C.c_void_p), ("audio", C.c_void_p), ("stride", C.c_uint),
         ("ctcss_events", C.c_void_p), ("ctcss_cap", C.c_uint), ("ctcss_n", C.c_uint),
     ]
+
+
+class OrcDsdCfg(C.Structure):
+    _fields_ = [("fs_in", C.c_double), ("sig_rate", C.c_double), ("audio_rate", C.c_double),
+                ("dcblock_alpha", C.c_float), ("resamp_As", C.c_float), ("fm_kf", C.c_float), ("max_block", C.c_uint)]
 
 
 CTCSS_EVENT = np.dtype([("index", np.int32), ("detected", np.int32), ("max_power", np.float32), ("avg_power", np.float32)])
@@ -92,6 +97,25 @@ def lib():
         L.orc_fft_create.restype = C.c_void_p
         L.orc_fft_destroy.argtypes = [C.c_void_p]
         L.orc_fft_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_dsd_default_cfg.argtypes = [C.POINTER(OrcDsdCfg)]
+        L.orc_dsd_create.argtypes = [C.POINTER(OrcDsdCfg)]
+        L.orc_dsd_create.restype = C.c_void_p
+        L.orc_dsd_reset.argtypes = [C.c_void_p]
+        L.orc_dsd_destroy.argtypes = [C.c_void_p]
+        L.orc_dsd_max_out.argtypes = [C.c_void_p]
+        L.orc_dsd_max_out.restype = C.c_uint
+        L.orc_dsd_max_resampled.argtypes = [C.c_void_p]
+        L.orc_dsd_max_resampled.restype = C.c_uint
+        L.orc_dsd_info.argtypes = [C.c_void_p, C.c_int]
+        L.orc_dsd_info.restype = C.c_uint
+        L.orc_dsd_design.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint]
+        L.orc_dsd_design.restype = C.c_uint
+        L.orc_dsd_process_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint,
+                                            C.POINTER(C.c_uint), C.c_void_p, C.c_void_p, C.POINTER(C.c_uint)]
+        L.orc_msresamp_rrrf_create.argtypes = [C.c_float, C.c_float]
+        L.orc_msresamp_rrrf_create.restype = C.c_void_p
+        L.orc_msresamp_rrrf_destroy.argtypes = [C.c_void_p]
+        L.orc_msresamp_rrrf_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.POINTER(C.c_uint)]
         _lib = L
     return _lib
 
@@ -211,4 +235,65 @@ class OracleChain:
                 out[name] = bufs[name][:, :n].copy()
         if ev is not None:
             out["ctcss"] = ev[:, :taps.ctcss_n].copy()
+        return out
+
+
+class OracleDsd:
+    """Mirror of the `dsd_in` loop body (reference src/dsd_in.c:160-178); see oracle/orc_dsd.h."""
+
+    def __init__(self, fs_in=1024000.0, sig_rate=12500.0, audio_rate=48000.0, max_block=200000):
+        L = lib()
+        cfg = OrcDsdCfg()
+        L.orc_dsd_default_cfg(C.byref(cfg))
+        cfg.fs_in, cfg.sig_rate, cfg.audio_rate, cfg.max_block = fs_in, sig_rate, audio_rate, max_block
+        self.cfg = cfg
+        self.h = L.orc_dsd_create(C.byref(cfg))
+        if not self.h:
+            raise RuntimeError("orc_dsd_create failed")
+        self.max_out = L.orc_dsd_max_out(self.h)
+        self.max_resampled = L.orc_dsd_max_resampled(self.h)
+
+    def info(self, what):
+        return lib().orc_dsd_info(self.h, what)
+
+    def design(self, what):
+        n = lib().orc_dsd_design(self.h, what, None, 0)
+        out = np.zeros(n, dtype=np.float32)
+        lib().orc_dsd_design(self.h, what, out.ctypes.data, n)
+        return out
+
+    def reset(self):
+        lib().orc_dsd_reset(self.h)
+
+    def close(self):
+        if self.h:
+            lib().orc_dsd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_block(self, iq, want=("pcm",)):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        want = set(want)
+        cap = self.max_out
+        pcm = np.zeros(cap, dtype=np.int16)
+        audio = np.zeros(cap, dtype=np.float32)
+        res = np.zeros(self.max_resampled, dtype=np.complex64)
+        fm = np.zeros(self.max_resampled, dtype=np.float32)
+        nz, ny = C.c_uint(0), C.c_uint(0)
+        rc = lib().orc_dsd_process_block(self.h, iq.ctypes.data, len(iq), pcm.ctypes.data, audio.ctypes.data, cap,
+                                         C.byref(nz), res.ctypes.data, fm.ctypes.data, C.byref(ny))
+        if rc != 0:
+            raise RuntimeError("orc_dsd_process_block rc=%d" % rc)
+        out = {"n_out": nz.value, "n_resampled": ny.value, "pcm": pcm[:nz.value].copy()}
+        if "audio" in want:
+            out["audio"] = audio[:nz.value].copy()
+        if "resampled" in want:
+            out["resampled"] = res[:ny.value].copy()
+        if "fm" in want:
+            out["fm"] = fm[:ny.value].copy()
         return out

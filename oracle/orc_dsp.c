@@ -408,6 +408,153 @@ void orc_msresamp_crcf_execute(orc_msresamp_crcf *q, const cf32 *x, unsigned nx,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* msresamp_rrrf, interpolation branch: liquid msresamp.proto.c / msresamp2.proto.c / resamp2.proto.c /
+ * resamp.fixed.proto.c with T = float.  ref create src/dsd_in.c:104 (rate = (float)48000/12500, As 60),
+ * run :170.  Structure (restated from the library, same confidence as SURVEY A.3):
+ *   create : while (rate_arbitrary > 2) { stages++; rate_arbitrary *= 0.5; }            3.84 -> 1 stage, 1.92
+ *   execute: per input sample  resamp_execute -> nw outputs;  each through the half-band interpolators, stage 0
+ *            (lowest rate) first, 2^stages outputs per arbitrary-resampler output; no output scaling (unity DC gain:
+ *            the delay branch passes x, the filter branch taps sum to ~1).
+ *   resamp2 interp_execute(x): push x into w0, y[0] = w0[m-1]; push x into w1, y[1] = dot(h1, w1).               */
+
+orc_resamp2_rrrf *orc_resamp2_rrrf_create(unsigned m, float f0, float As)
+{
+    orc_resamp2_rrrf *q = (orc_resamp2_rrrf *)calloc(1, sizeof(*q));
+    orc_resamp2_crcf *c = orc_resamp2_crcf_create(m, f0, As);      /* same prototype, same branch taps */
+    q->m = m; q->h_len = c->h_len; q->h1_len = c->h1_len;
+    q->h = (float *)calloc(q->h_len, sizeof(float));
+    q->h1 = (float *)calloc(q->h1_len, sizeof(float));
+    memcpy(q->h, c->h, q->h_len * sizeof(float));
+    memcpy(q->h1, c->h1, q->h1_len * sizeof(float));
+    orc_resamp2_crcf_destroy(c);
+    orc_windowf_init(&q->w0, 2 * m);
+    orc_windowf_init(&q->w1, 2 * m);
+    return q;
+}
+
+void orc_resamp2_rrrf_reset(orc_resamp2_rrrf *q) { orc_windowf_reset(&q->w0); orc_windowf_reset(&q->w1); }
+
+void orc_resamp2_rrrf_destroy(orc_resamp2_rrrf *q)
+{
+    if (!q) return;
+    orc_windowf_free(&q->w0); orc_windowf_free(&q->w1);
+    free(q->h); free(q->h1); free(q);
+}
+
+void orc_resamp2_rrrf_interp_execute(orc_resamp2_rrrf *q, float x, float *y)
+{
+    orc_windowf_push(&q->w0, x);                                    /* delay branch */
+    y[0] = orc_windowf_read(&q->w0)[q->m - 1];
+    orc_windowf_push(&q->w1, x);                                    /* filter branch */
+    y[1] = orc_dotprod_rrrf(q->h1, orc_windowf_read(&q->w1), q->h1_len);
+}
+
+orc_resamp_rrrf *orc_resamp_rrrf_create(float rate, unsigned m, float fc, float As, unsigned npfb)
+{
+    orc_resamp_rrrf *q = (orc_resamp_rrrf *)calloc(1, sizeof(*q));
+    orc_resamp_crcf *c = orc_resamp_crcf_create(rate, m, fc, As, npfb);   /* same bank design */
+    q->m = c->m; q->npfb = c->npfb; q->bits_index = c->bits_index; q->sub_len = c->sub_len;
+    q->rate = c->rate; q->fc = c->fc; q->As = c->As; q->step = c->step; q->phase = 0;
+    const unsigned n = 2 * q->m * q->npfb + 1;
+    q->proto = (float *)calloc(n, sizeof(float));
+    q->bank = (float *)calloc((size_t)q->npfb * q->sub_len, sizeof(float));
+    memcpy(q->proto, c->proto, n * sizeof(float));
+    memcpy(q->bank, c->bank, (size_t)q->npfb * q->sub_len * sizeof(float));
+    orc_resamp_crcf_destroy(c);
+    orc_windowf_init(&q->w, q->sub_len);
+    return q;
+}
+
+void orc_resamp_rrrf_reset(orc_resamp_rrrf *q) { orc_windowf_reset(&q->w); q->phase = 0; }
+
+void orc_resamp_rrrf_destroy(orc_resamp_rrrf *q)
+{
+    if (!q) return;
+    orc_windowf_free(&q->w); free(q->bank); free(q->proto); free(q);
+}
+
+void orc_resamp_rrrf_execute(orc_resamp_rrrf *q, float x, float *y, unsigned *nw)
+{
+    orc_windowf_push(&q->w, x);
+    unsigned n = 0;
+    while (q->phase <= 0x00ffffffu) {
+        unsigned index = q->phase >> (24 - q->bits_index);
+        y[n++] = orc_dotprod_rrrf(q->bank + (size_t)index * q->sub_len, orc_windowf_read(&q->w), q->sub_len);
+        q->phase += q->step;
+    }
+    q->phase -= (1u << 24);
+    *nw = n;
+}
+
+orc_msresamp_rrrf *orc_msresamp_rrrf_create(float rate, float As)
+{
+    if (!(rate >= 1.0f) || rate > 1024.0f) return NULL;   /* decimation of real streams is not on any reference path */
+    orc_msresamp_rrrf *q = (orc_msresamp_rrrf *)calloc(1, sizeof(*q));
+    q->rate = rate; q->As = As;
+    q->rate_arbitrary = rate; q->rate_halfband = 1.0f; q->num_halfband_stages = 0;
+    while (q->rate_arbitrary > 2.0f) {
+        q->num_halfband_stages++;
+        q->rate_halfband *= 2.0f;
+        q->rate_arbitrary *= 0.5f;
+    }
+    const unsigned ns = q->num_halfband_stages;
+    q->m_stage = (unsigned *)calloc(ns + 1, sizeof(unsigned));
+    q->stage = (orc_resamp2_rrrf **)calloc(ns + 1, sizeof(*q->stage));
+    {
+        /* msresamp2_create(INTERP, ns, fc = 0.4, f0 = 0, As): same stage design loop as the decimator */
+        orc_msresamp2_crcf *d = orc_msresamp2_crcf_create_decim(ns, 0.4f, 0.0f, As);
+        for (unsigned i = 0; i < ns; i++) {
+            q->m_stage[i] = d->m_stage[i];
+            q->stage[i] = orc_resamp2_rrrf_create(d->m_stage[i], d->f0_stage[i], d->As_stage[i]);
+        }
+        orc_msresamp2_crcf_destroy(d);
+    }
+    float fc = 0.515f * q->rate_arbitrary;
+    if (fc > 0.49f) fc = 0.49f;
+    q->arbitrary = orc_resamp_rrrf_create(q->rate_arbitrary, 7, fc, q->As, 256);
+    q->buffer0 = (float *)calloc((1u << ns) + 4, sizeof(float));
+    q->buffer1 = (float *)calloc((1u << ns) + 4, sizeof(float));
+    return q;
+}
+
+void orc_msresamp_rrrf_reset(orc_msresamp_rrrf *q)
+{
+    for (unsigned i = 0; i < q->num_halfband_stages; i++) orc_resamp2_rrrf_reset(q->stage[i]);
+    orc_resamp_rrrf_reset(q->arbitrary);
+}
+
+void orc_msresamp_rrrf_destroy(orc_msresamp_rrrf *q)
+{
+    if (!q) return;
+    for (unsigned i = 0; i < q->num_halfband_stages; i++) orc_resamp2_rrrf_destroy(q->stage[i]);
+    orc_resamp_rrrf_destroy(q->arbitrary);
+    free(q->stage); free(q->m_stage); free(q->buffer0); free(q->buffer1); free(q);
+}
+
+void orc_msresamp_rrrf_execute(orc_msresamp_rrrf *q, const float *x, unsigned nx, float *y, unsigned *ny_out)
+{
+    const unsigned ns = q->num_halfband_stages;
+    unsigned ny = 0, nw;
+    float arb[8];
+    for (unsigned i = 0; i < nx; i++) {
+        orc_resamp_rrrf_execute(q->arbitrary, x[i], arb, &nw);
+        for (unsigned j = 0; j < nw; j++) {
+            if (ns == 0) { y[ny++] = arb[j]; continue; }
+            float *b0 = q->buffer0, *b1 = q->buffer1;
+            b0[0] = arb[j];
+            for (unsigned s = 0; s < ns; s++) {
+                const unsigned k = 1u << s;
+                float *dst = (s + 1 == ns) ? &y[ny] : b1;
+                for (unsigned u = 0; u < k; u++) orc_resamp2_rrrf_interp_execute(q->stage[s], b0[u], &dst[2 * u]);
+                float *t = b0; b0 = b1; b1 = t;
+            }
+            ny += 1u << ns;
+        }
+    }
+    *ny_out = ny;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* nco_crcf (LIQUID_VCO): liquid nco.proto.c.  ref create/set src/sdr_pmr446.c:430-434, run
  * :810-811.  SURVEY A.4: 32-bit phase; VCO flavour evaluates sinf/cosf of the float phase.       */
 

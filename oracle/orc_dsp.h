@@ -107,6 +107,43 @@ void orc_msresamp_crcf_reset(orc_msresamp_crcf *q);
 void orc_msresamp_crcf_destroy(orc_msresamp_crcf *q);
 void orc_msresamp_crcf_execute(orc_msresamp_crcf *q, const cf32 *x, unsigned nx, cf32 *y, unsigned *ny);
 
+/* ---- msresamp_rrrf, interpolation branch (reference src/dsd_in.c:104 creates it with rate 48000/12500, :170 runs it):
+ *      resamp_rrrf (arbitrary, runs first) -> msresamp2_rrrf half-band interpolators (stage 0 first) ---- */
+typedef struct {
+    unsigned m, h_len, h1_len;
+    float *h, *h1;
+    orc_windowf w0, w1;
+} orc_resamp2_rrrf;
+orc_resamp2_rrrf *orc_resamp2_rrrf_create(unsigned m, float f0, float As);
+void orc_resamp2_rrrf_reset(orc_resamp2_rrrf *q);
+void orc_resamp2_rrrf_destroy(orc_resamp2_rrrf *q);
+void orc_resamp2_rrrf_interp_execute(orc_resamp2_rrrf *q, float x, float *y /*[2]*/);
+
+typedef struct {
+    unsigned m, npfb, bits_index, sub_len;
+    float rate, fc, As;
+    uint32_t step, phase;
+    float *bank, *proto;
+    orc_windowf w;
+} orc_resamp_rrrf;
+orc_resamp_rrrf *orc_resamp_rrrf_create(float rate, unsigned m, float fc, float As, unsigned npfb);
+void orc_resamp_rrrf_reset(orc_resamp_rrrf *q);
+void orc_resamp_rrrf_destroy(orc_resamp_rrrf *q);
+void orc_resamp_rrrf_execute(orc_resamp_rrrf *q, float x, float *y, unsigned *nw);
+
+typedef struct {
+    float rate, As, rate_arbitrary, rate_halfband;
+    unsigned num_halfband_stages;
+    unsigned *m_stage;
+    orc_resamp2_rrrf **stage;     /* [num_halfband_stages], stage 0 = lowest rate, runs first when interpolating */
+    orc_resamp_rrrf *arbitrary;
+    float *buffer0, *buffer1;
+} orc_msresamp_rrrf;
+orc_msresamp_rrrf *orc_msresamp_rrrf_create(float rate, float As);   /* rate >= 1 only */
+void orc_msresamp_rrrf_reset(orc_msresamp_rrrf *q);
+void orc_msresamp_rrrf_destroy(orc_msresamp_rrrf *q);
+void orc_msresamp_rrrf_execute(orc_msresamp_rrrf *q, const float *x, unsigned nx, float *y, unsigned *ny);
+
 /* ---- nco_crcf, LIQUID_VCO flavour : SURVEY A.4 ---- */
 typedef struct { uint32_t theta, d_theta; } orc_nco_crcf;
 uint32_t orc_nco_constrain(float theta);

@@ -26,6 +26,10 @@ ABI_SYMBOLS = [
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
     "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read",
+    # include/pmr_dsd.h
+    "pmr_dsd_default_cfg", "pmr_dsd_create", "pmr_dsd_reset", "pmr_dsd_destroy", "pmr_dsd_max_out",
+    "pmr_dsd_last_error", "pmr_dsd_process_block", "pmr_dsd_process_block_device", "pmr_dsd_synchronize",
+    "pmr_dsd_debug_read", "pmr_dsd_plan_block", "pmr_dsd_cfg_info",
 ]
 
 CTCSS_EVENT = np.dtype([("index", np.int32), ("detected", np.int32), ("max_power", np.float32),
@@ -39,6 +43,17 @@ class Squelch(C.Structure):
 
 class PlanState(C.Structure):
     _fields_ = [("n_raw", C.c_uint64), ("arb_phase", C.c_uint32), ("leftover", C.c_uint)]
+
+
+class DsdCfg(C.Structure):
+    """pmr_dsd_cfg (include/pmr_dsd.h)."""
+    _fields_ = [("fs_in", C.c_double), ("sig_rate", C.c_double), ("audio_rate", C.c_double),
+                ("dcblock_alpha", C.c_float), ("resamp_As", C.c_float), ("fm_kf", C.c_float),
+                ("max_block", C.c_uint), ("device", C.c_int)]
+
+
+class DsdPlanState(C.Structure):
+    _fields_ = [("n_raw", C.c_uint64), ("n_resampled", C.c_uint64), ("down_phase", C.c_uint32)]
 
 
 class PmrCfg(C.Structure):
@@ -135,6 +150,27 @@ def load(build_if_missing=True):
     L.pmr_cfg_max_frames.restype = u
     L.pmr_cfg_plan_block.argtypes = [C.POINTER(PmrCfg), C.POINTER(PlanState), u, C.POINTER(u), C.POINTER(u)]
     L.pmr_cfg_plan_block.restype = i
+    L.pmr_dsd_default_cfg.argtypes = [C.POINTER(DsdCfg)]
+    L.pmr_dsd_default_cfg.restype = None
+    L.pmr_dsd_create.argtypes = [C.POINTER(DsdCfg)]
+    L.pmr_dsd_create.restype = vp
+    for name in ("pmr_dsd_reset", "pmr_dsd_destroy", "pmr_dsd_synchronize"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = i
+    L.pmr_dsd_max_out.argtypes = [vp]
+    L.pmr_dsd_max_out.restype = u
+    L.pmr_dsd_last_error.argtypes = [vp]
+    L.pmr_dsd_last_error.restype = C.c_char_p
+    L.pmr_dsd_process_block.argtypes = [vp, vp, u, vp, vp, u, C.POINTER(u)]
+    L.pmr_dsd_process_block.restype = i
+    L.pmr_dsd_process_block_device.argtypes = [vp, vp, u, vp, vp, u, C.POINTER(u)]
+    L.pmr_dsd_process_block_device.restype = i
+    L.pmr_dsd_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.pmr_dsd_debug_read.restype = i
+    L.pmr_dsd_plan_block.argtypes = [C.POINTER(DsdCfg), C.POINTER(DsdPlanState), u, C.POINTER(u), C.POINTER(u)]
+    L.pmr_dsd_plan_block.restype = i
+    L.pmr_dsd_cfg_info.argtypes = [C.POINTER(DsdCfg), i]
+    L.pmr_dsd_cfg_info.restype = u
     _lib = L
     return L
 
@@ -325,4 +361,75 @@ class PmrChain:
         buf = np.zeros(nb.value // np.dtype(dtype).itemsize, dtype=dtype)
         if nb.value:
             self._check(self._L.pmr_chain_debug_read(self.h, what, buf.ctypes.data, nb.value, C.byref(nb)))
+        return buf
+
+
+def make_dsd_cfg(fs_in=1024000.0, sig_rate=12500.0, audio_rate=48000.0, max_block=200000, device=-1):
+    cfg = DsdCfg()
+    load().pmr_dsd_default_cfg(C.byref(cfg))
+    cfg.fs_in, cfg.sig_rate, cfg.audio_rate, cfg.max_block, cfg.device = fs_in, sig_rate, audio_rate, max_block, device
+    return cfg
+
+
+class PmrDsd:
+    """The `dsd_in` loop body on the GPU (include/pmr_dsd.h; reference src/dsd_in.c:160-178)."""
+
+    def __init__(self, fs_in=1024000.0, sig_rate=12500.0, audio_rate=48000.0, max_block=200000, device=-1):
+        self._L = load()
+        self.cfg = make_dsd_cfg(fs_in, sig_rate, audio_rate, max_block, device)
+        self.h = self._L.pmr_dsd_create(C.byref(self.cfg))
+        if not self.h:
+            raise PmrError("pmr_dsd_create failed (no HIP device, or invalid configuration)")
+        self.max_out = self._L.pmr_dsd_max_out(self.h)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PmrError("pmr_dsd rc=%d: %s" % (rc, self._L.pmr_dsd_last_error(self.h).decode()))
+
+    def reset(self):
+        self._check(self._L.pmr_dsd_reset(self.h))
+
+    def synchronize(self):
+        self._check(self._L.pmr_dsd_synchronize(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.pmr_dsd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def process_block(self, iq, want=("pcm",)):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        want = set(want)
+        cap = self.max_out
+        pcm = np.zeros(cap, dtype=np.int16)
+        audio = np.zeros(cap, dtype=np.float32) if "audio" in want else None
+        nz = C.c_uint(0)
+        self._check(self._L.pmr_dsd_process_block(self.h, iq.ctypes.data, len(iq), pcm.ctypes.data,
+                                                  audio.ctypes.data if audio is not None else None, cap, C.byref(nz)))
+        out = {"n_out": nz.value, "pcm": pcm[:nz.value].copy()}
+        if audio is not None:
+            out["audio"] = audio[:nz.value].copy()
+        if "resampled" in want:
+            out["resampled"] = self.debug_read(0, np.complex64)
+        if "fm" in want:
+            out["fm"] = self.debug_read(1, np.float32)
+        return out
+
+    def process_block_device(self, d_iq, n_in, d_pcm=None, d_audio=None, cap=0):
+        nz = C.c_uint(0)
+        self._check(self._L.pmr_dsd_process_block_device(self.h, d_iq, n_in, d_pcm, d_audio, cap, C.byref(nz)))
+        return nz.value
+
+    def debug_read(self, what, dtype):
+        nb = C.c_size_t(0)
+        self._check(self._L.pmr_dsd_debug_read(self.h, what, None, 0, C.byref(nb)))
+        buf = np.zeros(nb.value // np.dtype(dtype).itemsize, dtype=dtype)
+        if nb.value:
+            self._check(self._L.pmr_dsd_debug_read(self.h, what, buf.ctypes.data, nb.value, C.byref(nb)))
         return buf

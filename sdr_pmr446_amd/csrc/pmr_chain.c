@@ -18,6 +18,7 @@
 #include "../data/pmr446_taps.h"
 #include "pmr_design.h"
 #include "pmr_kernels.h"
+#include "pmr_internal.h"
 
 #define FM_HIST_FRAMES 512u     /* >= 376 (HP) + IIR warm-up; also covers 102/100-tap follow-on FIRs */
 #define AUX_HIST_FRAMES 128u    /* history of the time-major intermediates behind the HP stage        */
@@ -519,9 +520,17 @@ static int chain_init(pmr_chain q)
     return PMR_OK;
 }
 
-pmr_chain pmr_chain_create(const pmr_chain_cfg *cfg)
+static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only);
+pmr_chain pmr_chain_create(const pmr_chain_cfg *cfg) { return chain_create(cfg, 0); }
+pmr_chain pmr_chain_create_frontend(const pmr_chain_cfg *cfg) { return chain_create(cfg, 1); }
+
+static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
 {
     if (!cfg) return NULL;
+    if (cfg->num_channels < 2 && !frontend_only) {
+        fprintf(stderr, "pmr_chain_create: invalid configuration\n");
+        return NULL;
+    }
     pmr_chain q = (pmr_chain)calloc(1, sizeof(*q));
     if (!q) return NULL;
     q->cfg = *cfg;
@@ -857,6 +866,38 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     q->arb_phase = new_phase;
     *ny_out = ny;
     return PMR_OK;
+}
+
+/* front end only, for pmr_dsd.c (pmr_internal.h): everything on stream_fe, dc carry applied in place */
+int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny_out, uint64_t *xr_abs0)
+{
+    if (!q) return PMR_EINVAL;
+    if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
+    if (n_in && !d_iq) return fail(q, PMR_EINVAL, "null input", hipSuccess);
+    unsigned ny_plan = 0, ns_plan = 0, ny = 0;
+    plan_counts(q, n_in, &ny_plan, &ns_plan);
+    if (ny_plan > q->res_size) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
+    *xr_abs0 = q->xr_abs;
+    const int keep_dbg = q->dbg_on;
+    q->dbg_on = 1;                                /* forces the in-place dc fix even if a fused consumer exists */
+    int rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
+                       : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny);
+    q->dbg_on = keep_dbg;
+    if (rc) return rc;
+    if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
+    q->n_raw += n_in;
+    q->xr_abs += ny;
+    q->frames_done = q->xr_abs / q->M;
+    q->last_ny = ny;
+    q->n_calls++;
+    *ny_out = ny;
+    return PMR_OK;
+}
+
+void pmr_chain_frontend_view(pmr_chain q, pmr_fe_view *v)
+{
+    v->d_xr = q->d_xr; v->xr_mask = q->xr_mask; v->stream_fe = (void *)q->stream_fe; v->d_in = q->d_in;
+    v->res_size = q->res_size; v->device = q->device;
 }
 
 /* ------------------------------------------------------------------------------------------- */

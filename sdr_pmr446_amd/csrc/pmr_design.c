@@ -90,7 +90,7 @@ int pmr_design_build(pmr_design *d, double fs_in, unsigned M, double channel_wid
                      float resamp_As, unsigned pfb_m, float pfb_As, float fm_kf)
 {
     memset(d, 0, sizeof(*d));
-    if (M < 2 || (M & (M - 1)) != 0 || M > 4096 || pfb_m < 1 || pfb_m > 32 || !(fs_in > 0) ||
+    if (M < 1 || (M & (M - 1)) != 0 || M > 4096 || pfb_m < 1 || pfb_m > 32 || !(fs_in > 0) ||
         !(channel_width_hz > 0) || !(fm_kf > 0))
         return 1;
 
@@ -199,6 +199,56 @@ int pmr_design_build(pmr_design *d, double fs_in, unsigned M, double channel_wid
         d->de_b0 = b[0] / a[0]; d->de_b1 = b[1] / a[0]; d->de_a1 = a[1] / a[0];
     }
     return 0;
+}
+
+/* msresamp_rrrf_create(rate, As), interpolation (reference src/dsd_in.c:104): the same constructors as above */
+int pmr_up_design_build(pmr_up_design *u, float rate, float As)
+{
+    memset(u, 0, sizeof(*u));
+    if (!(rate >= 1.0f) || rate > 256.0f) return 1;
+    u->rate = rate; u->rate_arb = rate; u->num_stages = 0;
+    while (u->rate_arb > 2.0f) { u->num_stages++; u->rate_arb *= 0.5f; }
+    if (u->num_stages > PMR_UP_MAX_STAGES) return 1;
+    {
+        float fc = 0.4f, as = As + 5.0f;
+        for (unsigned g = 0; g < u->num_stages; g++) {
+            fc = (g == 1) ? (0.5f - fc) / 2.0f : 0.5f * fc;
+            float ft = 2.0f * (0.25f - fc);
+            unsigned h_len = (unsigned)((as - 7.95f) / (14.26f * ft));
+            unsigned m = (unsigned)ceilf((float)(h_len - 1) / 4.0f);
+            if (m < 3) m = 3;
+            u->m_stage[g] = m;
+            float *proto = (float *)calloc(4 * m + 1, sizeof(float));
+            u->hb_h1[g] = (float *)calloc(2 * m, sizeof(float));
+            design_halfband(m, as, proto);
+            for (unsigned j = 0; j < 2 * m; j++) u->hb_h1[g][j] = proto[4 * m - 1 - 2 * j];
+            free(proto);
+        }
+    }
+    {
+        float fc = 0.515f * u->rate_arb;
+        if (fc > 0.49f) fc = 0.49f;
+        u->arb_step = (uint32_t)roundf((float)(1 << 24) / u->rate_arb);
+        unsigned n = 2 * PMR_ARB_M * PMR_ARB_NPFB + 1, L = 2 * PMR_ARB_M;
+        float *hf = (float *)calloc(n, sizeof(float));
+        design_kaiser_lowpass(n, fc / (float)PMR_ARB_NPFB, As, hf);
+        float gain = 0.0f;
+        for (unsigned i = 0; i < n; i++) gain += hf[i];
+        gain = (float)PMR_ARB_NPFB / gain;
+        u->arb_bank = (float *)calloc((size_t)PMR_ARB_NPFB * L, sizeof(float));
+        for (unsigned i = 0; i < PMR_ARB_NPFB; i++)
+            for (unsigned k = 0; k < L; k++)
+                u->arb_bank[(size_t)i * L + k] = (hf[i + (L - 1 - k) * PMR_ARB_NPFB] * gain);
+        free(hf);
+    }
+    return 0;
+}
+
+void pmr_up_design_free(pmr_up_design *u)
+{
+    for (unsigned g = 0; g < PMR_UP_MAX_STAGES; g++) free(u->hb_h1[g]);
+    free(u->arb_bank);
+    memset(u, 0, sizeof(*u));
 }
 
 void pmr_design_buffer_sizes(const pmr_design *d, unsigned max_block, unsigned *res_size, unsigned *chan_size)

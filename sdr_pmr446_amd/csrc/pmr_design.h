@@ -50,6 +50,20 @@ int  pmr_design_build(pmr_design *d, double fs_in, unsigned M, double channel_wi
                       float resamp_As, unsigned pfb_m, float pfb_As, float fm_kf);
 void pmr_design_free(pmr_design *d);
 
+/* msresamp_rrrf interpolator of `dsd_in` (reference src/dsd_in.c:104): arbitrary resampler first, then half-band
+ * interpolators, design stage 0 (lowest rate) first */
+#define PMR_UP_MAX_STAGES 8
+typedef struct {
+    float    rate, rate_arb;    /* requested rate; rate / 2^num_stages in (1, 2]               */
+    unsigned num_stages;
+    unsigned m_stage[PMR_UP_MAX_STAGES];
+    float   *hb_h1[PMR_UP_MAX_STAGES];   /* 2m branch taps, oldest-sample-first                 */
+    uint32_t arb_step;          /* round(2^24 / rate_arb)                                       */
+    float   *arb_bank;          /* [npfb][2m] oldest-sample-first                               */
+} pmr_up_design;
+int  pmr_up_design_build(pmr_up_design *u, float rate, float As);
+void pmr_up_design_free(pmr_up_design *u);
+
 /* sizing rule of src/sdr_pmr446.c:730-736 */
 void pmr_design_buffer_sizes(const pmr_design *d, unsigned max_block, unsigned *res_size, unsigned *chan_size);
 

@@ -109,6 +109,14 @@ int pmr_launch_ct_goertzel(pmr_stream_t s, const float *lp, uint64_t row_mask, i
                            unsigned N, const float *U, const float *coef, float *part, const float *carry_in,
                            float *carry_out, pmr_ctcss_event *events, unsigned nblk, unsigned ncomplete);
 
+/* ---- `dsd_in` back end (pmr_dsd_kernels.hip): discriminator + msresamp_rrrf interpolator on absolute-indexed rings ---- */
+int pmr_launch_dsd_fm(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t a0, unsigned ny, float *fm,
+                      uint64_t fm_mask, float ref);
+int pmr_launch_dsd_arb(pmr_stream_t s, const float *fm, uint64_t fm_mask, uint64_t j0, unsigned nu, uint32_t step,
+                       const float *bank, float *u, uint64_t u_mask, int16_t *pcm, float *audio);
+int pmr_launch_dsd_hb(pmr_stream_t s, const float *in, uint64_t in_mask, uint64_t i0, unsigned n, int m,
+                      const float *h1, float *out, uint64_t out_mask, int16_t *pcm, float *audio);
+
 /* ---- fused front end (pmr_frontend.hip): dc-block + half-band cascade + arbitrary resampler in one pass ---- */
 #define PMR_FE_MAX_STAGES 16
 typedef struct {

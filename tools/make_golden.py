@@ -46,5 +46,21 @@ def main():
         print(path, pcm.shape, os.path.getsize(path))
 
 
+def main_dsd():
+    """dsd_in chain: one FM channel at band centre, reference operating point, ragged block split."""
+    fs, n, splits, dev = 1.024e6, 260000, [200000, 1, 59999], 2500.0
+    x = synth.synth_iq(n, fs, 1, dev_hz=dev)
+    o = oracle.OracleDsd(fs_in=fs, max_block=max(splits))
+    pcm, pos = [], 0
+    for k in splits:
+        pcm.append(o.process_block(x[pos:pos + k])["pcm"]); pos += k
+    pcm = np.concatenate(pcm)
+    path = os.path.join(ROOT, "tests", "golden", "dsd_ref_point.npz")
+    np.savez_compressed(path, pcm=pcm, input_sha256=hashlib.sha256(x.tobytes()).hexdigest(), fs=fs, n=n,
+                        splits=np.array(splits), dev_hz=dev)
+    print(path, pcm.shape, os.path.getsize(path))
+
+
 if __name__ == "__main__":
     main()
+    main_dsd()
