@@ -1,0 +1,89 @@
+/* pmr446_file -- headless stand-in for the reference's main() loops on a RECORDED cf32 stream:
+ *
+ *   pmr446_file chan <in.cf32|-> <out.wav> [fs_in] [num_channels] [channel|-1]
+ *       the block loop of src/sdr_pmr446.c:788-908: read a chunk (:789) -> pmr_chain_process_block_f32 -> squelch state
+ *       machine on the GPU's RSSI (:828-874) -> float32 WAV at 12.5 kHz.  channel >= 0 writes that channel (mono, like
+ *       the RtAudio sink :585); -1 writes all channels (multi-channel WAV).
+ *   pmr446_file dsd <in.cf32|-> <out.s16|-> [fs_in]
+ *       the loop of src/dsd_in.c:159-179: s16le mono 48 kHz, ready for `dsd -i -`.
+ *
+ * Everything numerical happens in libpmr446_hip.so; this file is plumbing. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pmr_chain.h"
+#include "pmr_dsd.h"
+#include "pmr_io.h"
+
+static int run_chan(const char *in, const char *out, double fs, unsigned M, int only)
+{
+    pmr_chain_cfg cfg;
+    pmr_chain_default_cfg(&cfg);
+    cfg.fs_in = fs; cfg.num_channels = M;
+    pmr_chain q = pmr_chain_create(&cfg);
+    if (!q) return 2;
+    const unsigned S = pmr_chain_max_frames(q), C = only >= 0 ? 1 : M;
+    pmr_iq_reader r = pmr_iq_reader_open(in, PMR_IQ_CF32);
+    pmr_wav_writer w = pmr_wav_writer_open(out, PMR_WAV_F32, (unsigned)cfg.channel_width_hz, C);
+    pmr_cf32 *iq = (pmr_cf32 *)malloc((size_t)cfg.max_block * sizeof(pmr_cf32));
+    float *audio = (float *)malloc((size_t)M * S * sizeof(float)), *rssi = (float *)malloc(M * sizeof(float));
+    int16_t *pcm = (int16_t *)malloc((size_t)M * S * sizeof(int16_t));
+    if (!r || !w || !iq || !audio || !rssi || !pcm) { fprintf(stderr, "pmr446_file: cannot open / allocate\n"); return 3; }
+    pmr_squelch sq;
+    pmr_squelch_init(&sq);
+    int n, rc = 0;
+    unsigned long blocks = 0, frames = 0;
+    while ((n = pmr_iq_reader_read(r, iq, cfg.max_block)) > 0) {                      /* :789 */
+        unsigned ns = 0;
+        rc = pmr_chain_process_block_f32(q, iq, (unsigned)n, pcm, audio, S, &ns, NULL, rssi);
+        if (rc) { fprintf(stderr, "pmr446_file: %s\n", pmr_chain_last_error(q)); break; }
+        const int ev = pmr_squelch_update(&sq, rssi, M, ~0ull, 18.0f, 0);               /* :828-874 */
+        if (ev) fprintf(stderr, "block %lu: %s channel %d (%.1f dB)\n", blocks, sq.state == PMR_TUNED ? "tuned to" : "left",
+                        sq.active_chan + 1, sq.rssi);
+        rc = pmr_wav_writer_write_f32(w, only >= 0 ? audio + (size_t)only * S : audio, ns, S);
+        if (rc) break;
+        blocks++; frames += ns;
+    }
+    fprintf(stderr, "pmr446_file: %lu blocks, %lu frames per channel\n", blocks, frames);
+    pmr_wav_writer_close(w); pmr_iq_reader_close(r); pmr_chain_destroy(q);
+    free(iq); free(audio); free(rssi); free(pcm);
+    return rc || n < 0 ? 1 : 0;
+}
+
+static int run_dsd(const char *in, const char *out, double fs)
+{
+    pmr_dsd_cfg cfg;
+    pmr_dsd_default_cfg(&cfg);
+    cfg.fs_in = fs;
+    pmr_dsd q = pmr_dsd_create(&cfg);
+    if (!q) return 2;
+    const unsigned cap = pmr_dsd_max_out(q);
+    pmr_iq_reader r = pmr_iq_reader_open(in, PMR_IQ_CF32);
+    pmr_wav_writer w = pmr_wav_writer_open(out, PMR_RAW_S16, (unsigned)cfg.audio_rate, 1);
+    pmr_cf32 *iq = (pmr_cf32 *)malloc((size_t)cfg.max_block * sizeof(pmr_cf32));
+    int16_t *pcm = (int16_t *)malloc((size_t)cap * sizeof(int16_t));
+    if (!r || !w || !iq || !pcm) { fprintf(stderr, "pmr446_file: cannot open / allocate\n"); return 3; }
+    int n, rc = 0;
+    while ((n = pmr_iq_reader_read(r, iq, cfg.max_block)) > 0) {                      /* src/dsd_in.c:161 */
+        unsigned nz = 0;
+        rc = pmr_dsd_process_block(q, iq, (unsigned)n, pcm, NULL, cap, &nz);           /* :167-175 */
+        if (rc) { fprintf(stderr, "pmr446_file: %s\n", pmr_dsd_last_error(q)); break; }
+        if ((rc = pmr_wav_writer_write_s16(w, pcm, nz, cap))) break;                    /* :177-178 */
+    }
+    pmr_wav_writer_close(w); pmr_iq_reader_close(r); pmr_dsd_destroy(q);
+    free(iq); free(pcm);
+    return rc || n < 0 ? 1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc >= 4 && !strcmp(argv[1], "chan"))
+        return run_chan(argv[2], argv[3], argc > 4 ? atof(argv[4]) : 1024000.0, argc > 5 ? (unsigned)atoi(argv[5]) : 16,
+                        argc > 6 ? atoi(argv[6]) : -1);
+    if (argc >= 4 && !strcmp(argv[1], "dsd"))
+        return run_dsd(argv[2], argv[3], argc > 4 ? atof(argv[4]) : 1024000.0);
+    fprintf(stderr, "usage: %s chan <in.cf32|-> <out.wav> [fs_in] [num_channels] [channel|-1]\n"
+                    "       %s dsd  <in.cf32|-> <out.s16|-> [fs_in]\n", argv[0], argv[0]);
+    return 64;
+}

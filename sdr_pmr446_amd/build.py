@@ -8,12 +8,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpmr446_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
-C_SOURCES = ["pmr_chain.c", "pmr_design.c", "pmr_squelch.c", "pmr_dsd.c"]
+C_SOURCES = ["pmr_chain.c", "pmr_design.c", "pmr_squelch.c", "pmr_dsd.c", "pmr_io.c"]
 HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_channelize_small.hip", "pmr_fir_mfma.hip", "pmr_ctcss.hip",
                "pmr_dsd_kernels.hip"]
 EXTRA_HIP_FLAGS = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
 HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_internal.h", os.path.join("..", "..", "include", "pmr_chain.h"),
-           os.path.join("..", "..", "include", "pmr_dsd.h"),
+           os.path.join("..", "..", "include", "pmr_dsd.h"), os.path.join("..", "..", "include", "pmr_io.h"),
            os.path.join("..", "data", "pmr446_taps.h")]
 
 
@@ -56,7 +56,23 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_example(verbose)
     return LIB
+
+
+EXAMPLE = os.path.join(HERE, "pmr446_file")
+
+
+def build_example(verbose=False):
+    """examples/pmr446_file.c: headless file -> WAV / s16 harness, linked against the in-tree library."""
+    root = os.path.dirname(HERE)
+    cmd = ["gcc", "-std=gnu11", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "pmr446_file.c"), "-o", EXAMPLE, "-L" + HERE, "-lpmr446_hip",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return EXAMPLE
 
 
 if __name__ == "__main__":

@@ -30,6 +30,9 @@ ABI_SYMBOLS = [
     "pmr_dsd_default_cfg", "pmr_dsd_create", "pmr_dsd_reset", "pmr_dsd_destroy", "pmr_dsd_max_out",
     "pmr_dsd_last_error", "pmr_dsd_process_block", "pmr_dsd_process_block_device", "pmr_dsd_synchronize",
     "pmr_dsd_debug_read", "pmr_dsd_plan_block", "pmr_dsd_cfg_info",
+    # include/pmr_io.h
+    "pmr_iq_reader_open", "pmr_iq_reader_read", "pmr_iq_reader_close",
+    "pmr_wav_writer_open", "pmr_wav_writer_write_f32", "pmr_wav_writer_write_s16", "pmr_wav_writer_close",
 ]
 
 CTCSS_EVENT = np.dtype([("index", np.int32), ("detected", np.int32), ("max_power", np.float32),
@@ -150,6 +153,20 @@ def load(build_if_missing=True):
     L.pmr_cfg_max_frames.restype = u
     L.pmr_cfg_plan_block.argtypes = [C.POINTER(PmrCfg), C.POINTER(PlanState), u, C.POINTER(u), C.POINTER(u)]
     L.pmr_cfg_plan_block.restype = i
+    L.pmr_iq_reader_open.argtypes = [C.c_char_p, i]
+    L.pmr_iq_reader_open.restype = vp
+    L.pmr_iq_reader_read.argtypes = [vp, vp, u]
+    L.pmr_iq_reader_read.restype = i
+    L.pmr_iq_reader_close.argtypes = [vp]
+    L.pmr_iq_reader_close.restype = i
+    L.pmr_wav_writer_open.argtypes = [C.c_char_p, i, u, u]
+    L.pmr_wav_writer_open.restype = vp
+    L.pmr_wav_writer_write_f32.argtypes = [vp, vp, u, u]
+    L.pmr_wav_writer_write_f32.restype = i
+    L.pmr_wav_writer_write_s16.argtypes = [vp, vp, u, u]
+    L.pmr_wav_writer_write_s16.restype = i
+    L.pmr_wav_writer_close.argtypes = [vp]
+    L.pmr_wav_writer_close.restype = i
     L.pmr_dsd_default_cfg.argtypes = [C.POINTER(DsdCfg)]
     L.pmr_dsd_default_cfg.restype = None
     L.pmr_dsd_create.argtypes = [C.POINTER(DsdCfg)]
@@ -433,3 +450,59 @@ class PmrDsd:
         if nb.value:
             self._check(self._L.pmr_dsd_debug_read(self.h, what, buf.ctypes.data, nb.value, C.byref(nb)))
         return buf
+
+
+IQ_CF32, IQ_CS16, IQ_CU8 = 0, 1, 2
+WAV_F32, WAV_S16, RAW_S16 = 0, 1, 2
+
+
+class IqReader:
+    """pmr_iq_reader (include/pmr_io.h): recorded IQ as cf32 blocks, the stand-in for readStream."""
+
+    def __init__(self, path, fmt=IQ_CF32):
+        self._L = load()
+        self.h = self._L.pmr_iq_reader_open(os.fsencode(path), fmt)
+        if not self.h:
+            raise PmrError("pmr_iq_reader_open failed: %s" % path)
+
+    def read(self, max_samples):
+        buf = np.zeros(max_samples, dtype=np.complex64)
+        n = self._L.pmr_iq_reader_read(self.h, buf.ctypes.data, max_samples)
+        if n < 0:
+            raise PmrError("pmr_iq_reader_read rc=%d" % n)
+        return buf[:n]
+
+    def close(self):
+        if self.h:
+            self._L.pmr_iq_reader_close(self.h)
+            self.h = None
+
+
+class WavWriter:
+    """pmr_wav_writer (include/pmr_io.h): planar [channels][stride] in, interleaved WAV / raw s16 out."""
+
+    def __init__(self, path, fmt, sample_rate, channels=1):
+        self._L = load()
+        self.fmt, self.channels = fmt, channels
+        self.h = self._L.pmr_wav_writer_open(os.fsencode(path), fmt, sample_rate, channels)
+        if not self.h:
+            raise PmrError("pmr_wav_writer_open failed: %s" % path)
+
+    def write(self, data):
+        data = np.atleast_2d(data)
+        assert data.shape[0] == self.channels
+        if self.fmt == WAV_F32:
+            d = np.ascontiguousarray(data, dtype=np.float32)
+            rc = self._L.pmr_wav_writer_write_f32(self.h, d.ctypes.data, d.shape[1], d.shape[1])
+        else:
+            d = np.ascontiguousarray(data, dtype=np.int16)
+            rc = self._L.pmr_wav_writer_write_s16(self.h, d.ctypes.data, d.shape[1], d.shape[1])
+        if rc != 0:
+            raise PmrError("pmr_wav_writer_write rc=%d" % rc)
+
+    def close(self):
+        if self.h:
+            rc = self._L.pmr_wav_writer_close(self.h)
+            self.h = None
+            if rc != 0:
+                raise PmrError("pmr_wav_writer_close rc=%d" % rc)
