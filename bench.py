@@ -27,14 +27,11 @@ WORKLOADS = {
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
-def cpu_baseline(fs, M, block_host, seconds_target=12.0):
-    """Time the CPU oracle (kind 'port': the reference itself needs liquid-dsp and cannot be built here) on a
-    bounded sample of the same workload, single thread like the reference's DSP thread (src/sdr_pmr446.c:788)."""
-    import numpy as np
+def _oracle_loop(fs, M, block_host, seconds_target, only_channel=-1):
     import oracle
     n_probe = min(len(block_host), 1 << 20)
     n_avail = max(1, len(block_host) // n_probe)
-    ch = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n_probe)
+    ch = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n_probe, only_channel=only_channel)
     ch.process_block(block_host[:n_probe], want=("pcm",))               # warm-up (page-in, caches)
     n_blocks = 0
     t0 = time.perf_counter()
@@ -46,10 +43,51 @@ def cpu_baseline(fs, M, block_host, seconds_target=12.0):
         if dt >= seconds_target:
             break
     ch.close()
+    return n_blocks, n_probe, dt
+
+
+_WORKER = """
+import sys, time, numpy as np
+sys.path.insert(0, %r)
+import bench
+fs, M, n, secs = float(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
+from sdr_pmr446_amd import synth
+x = synth.synth_iq(n, fs, M, stream_id=int(sys.argv[5]), channels=list(range(0, M, max(1, M // 16))))
+nb, npr, dt = bench._oracle_loop(fs, M, x, secs)
+print(nb * npr, dt)
+"""
+
+
+def cpu_baseline(fs, M, block_host, seconds_target=8.0):
+    """Time the CPU oracle (kind 'port': the reference itself needs liquid-dsp and cannot be built here) on a
+    bounded sample of the same workload: (i) single thread like the reference's DSP thread (src/sdr_pmr446.c:788) --
+    the headline `value`; (ii) N independent streams on N cores, the CPU analogue of one stream per GPU (SURVEY s8d);
+    (iii) the reference's own semantics, one squelch-selected channel demodulated (:876-877)."""
+    import subprocess
+    import sys
+    n_blocks, n_probe, dt = _oracle_loop(fs, M, block_host, seconds_target)
     total = n_blocks * n_probe
-    return {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": "%d blocks x %d samples of the same synthetic IQ, all %d channels demodulated, %.1f s" %
-                      (n_blocks, n_probe, M, dt)}
+    out = {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": "%d blocks x %d samples of the same synthetic IQ, all %d channels demodulated, %.1f s" %
+                     (n_blocks, n_probe, M, dt)}
+    nb1, np1, dt1 = _oracle_loop(fs, M, block_host, seconds_target / 2, only_channel=0)
+    out["one_channel"] = {"value": nb1 * np1 / dt1 / 1e6, "cores": 1,
+                          "sample": "reference semantics: only the selected channel demodulated, %.1f s" % dt1}
+    try:
+        ncores = min(len(os.sched_getaffinity(0)), 32)
+        if ncores > 1:
+            procs = [subprocess.Popen([sys.executable, "-c", _WORKER % ROOT, str(fs), str(M), str(n_probe),
+                                       str(seconds_target / 2), str(i)], stdout=subprocess.PIPE, cwd=ROOT)
+                     for i in range(ncores)]
+            rates = []
+            for p in procs:
+                o = p.communicate(timeout=120)[0].split()
+                rates.append(float(o[0]) / float(o[1]))
+            out["multi"] = {"value": sum(rates) / 1e6, "cores": ncores,
+                            "sample": "%d independent streams, one single-threaded oracle per core" % ncores}
+    except Exception as e:                                              # the single-thread figure stands on its own
+        out["multi"] = {"value": None, "error": str(e)[:120]}
+    return out
 
 
 def load_measured_traffic(kernel, workload, block):
@@ -73,6 +111,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--log2-block", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-io", action="store_true",
+                    help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -170,6 +210,33 @@ def main():
                        "channels_demodulated": M, "hbm_frac_of_peak_whole_chain": value * 1e6 * b_alg / 1e9 / world / HBM_PEAK_GBPS},
             "roofline": roof,
         }
+        if args.host_io and world == 1:
+            # PCIe-inclusive rate of pmr_chain_process_block (host cf32 in, host int16 out), never the headline value
+            import numpy as np
+            nb = min(block, 1 << 22)                                     # 2^22 samples per call
+            import ctypes
+            res = {}
+            pcm_h = torch.zeros((M, S), dtype=torch.int16)
+            ns_c = ctypes.c_uint(0)
+
+            def host_call(xn, pcm_t):
+                rc = ch._L.pmr_chain_process_block(ch.h, xn.ctypes.data, nb, pcm_t.data_ptr(), S, ctypes.byref(ns_c),
+                                                   None, None)
+                assert rc == 0, rc
+
+            for kind in ("pageable", "pinned"):
+                xh = iq[:nb].cpu()
+                if kind == "pinned":
+                    xh = xh.pin_memory()
+                xn = xh.numpy().view(np.complex64).reshape(-1)
+                pcm_t = pcm_h.pin_memory() if kind == "pinned" else pcm_h
+                host_call(xn, pcm_t)
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    host_call(xn, pcm_t)
+                res[kind] = 8 * nb / (time.perf_counter() - t0) / 1e6
+            out["host_io"] = {"unit": "Msamples/s", "block_samples": nb, **res,
+                              "note": "synchronous pmr_chain_process_block: H2D + chain + D2H per call, no overlap"}
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = min(block, 1 << 24)
             out["cpu_baseline"] = cpu_baseline(fs, M, iq[:n_cpu].cpu().numpy())

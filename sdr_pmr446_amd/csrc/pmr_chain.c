@@ -80,6 +80,7 @@ struct pmr_chain_s {
     int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
     int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
     float fe_Kgain, fe_lam_wave, fe_lam_pow16[6];
+    float fe_taps_host[PMR_FE_MAX_STAGES * 64];
     float *d_fe_taps, *d_fe_GA, *d_fe_T1, *d_fe_T2, *d_fe_lam_lane;
     cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V[2];
     uint64_t *d_fe_stamps;           /* diagnostic per-phase cycle sums (PMR_FE_STAMP)                */
@@ -279,15 +280,19 @@ static int fe_init(pmr_chain q)
         H = S;
         L = D1 > 16 ? D1 : 16;
     }
-    int nt = 0;
+    int nt = 0, spt_sel = 16;
     unsigned long T_own = 0;
     {
         /* tile geometries (threads x 16 samples): 256 -> 4096-sample tiles; 1024 -> 16384 (deep cascades);
-         * PMR_FE_GEOM=128x16 / 192x16 / 512x8 select experimental ones */
+         * PMR_FE_GEOM=128x16 / 192x16 / 512x8 / 256x8 select experimental ones */
         const char *gm = getenv("PMR_FE_GEOM");
         int first = 256;
         if (gm && !strcmp(gm, "128x16")) first = 128;
         if (gm && !strcmp(gm, "192x16")) first = 192;
+        if (gm && !strcmp(gm, "256x8") && !q->fe_two) {
+            const unsigned long N0c = 2048;
+            if (N0c % L == 0 && H + L <= N0c && (N0c - H) / L * L * 2 >= N0c) { nt = 256; spt_sel = 8; T_own = (N0c - H) / L * L; }
+        }
         const int cands[4] = { first, 256, 512, 1024 };
         for (int ci = 0; ci < 4 && !nt; ci++) {
             const int cand = cands[ci];
@@ -304,9 +309,9 @@ static int fe_init(pmr_chain q)
         }
     }
     if (!nt) return PMR_OK;                      /* cascade too deep for one LDS tile: staged path */
-    const unsigned long N0 = (unsigned long)nt * 16;
-    q->fe_nt = nt; q->fe_spt = 16;
-    if (nt == 256) {                             /* alternative geometry for experiments: 512 threads x 8 samples */
+    const unsigned long N0 = (unsigned long)nt * spt_sel;
+    q->fe_nt = nt; q->fe_spt = spt_sel;
+    if (nt == 256 && spt_sel == 16) {            /* alternative geometry for experiments: 512 threads x 8 samples */
         const char *g = getenv("PMR_FE_GEOM");
         if (g && !strcmp(g, "512x8")) { q->fe_nt = 512; q->fe_spt = 8; }   /* measured slower than 256 x 16 */
     }
@@ -343,6 +348,7 @@ static int fe_init(pmr_chain q)
             memcpy(tmp + off, d->hb_h1[g], n * sizeof(float));
             off += (int)n;
         }
+        memcpy(q->fe_taps_host, tmp, sizeof(tmp));
         if ((rc = dev_upload(q, &q->d_fe_taps, tmp, off ? off : 1))) return rc;
     }
 
@@ -715,6 +721,17 @@ static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigne
     return PMR_OK;
 }
 
+/* branch taps of stages [e0, e0 + n) into the kernel-argument copy (specialised front-end kernel) */
+static void fe_fill_taps(const struct pmr_chain_s *q, pmr_fe_params *p, unsigned e0, unsigned n)
+{
+    unsigned total = 0;
+    for (unsigned e = e0; e < e0 + n; e++) total += 2u * (unsigned)q->fe_m[e];
+    p->taps_valid = 0;
+    if (n == 0 || total > sizeof(p->taps_k) / sizeof(p->taps_k[0])) return;
+    memcpy(p->taps_k, q->fe_taps_host + q->fe_tap_off[e0], total * sizeof(float));
+    p->taps_valid = 1;
+}
+
 /* front end, fused: one pass over the raw block (pmr_frontend.hip) */
 static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny_out)
 {
@@ -749,6 +766,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
         p.stamps = q->d_fe_stamps;
     }
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
+    fe_fill_taps(q, &p, 0, h);
     LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles, q->fe_nt, q->fe_spt));
 
     pmr_fe_tiles_params t;
@@ -815,6 +833,7 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     memcpy(p.m, q->fe_m, sizeof(p.m)); memcpy(p.tap_off, q->fe_tap_off, sizeof(p.tap_off));
     p.dc_a1 = d->dc_a1; p.zeta = 1.0f; p.lam_wave = q->fe_lam_wave;
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
+    fe_fill_taps(q, &p, 0, s1);
     LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles1, 256, 16));
 
     pmr_fe_tiles_params t;
@@ -850,6 +869,7 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
         for (unsigned e = 0; e < h2; e++) { p2.m[e] = q->fe_m[s1 + e]; p2.tap_off[e] = q->fe_tap_off[s1 + e]; }
         p2.dc_a1 = d->dc_a1; p2.zeta = d->zeta; p2.lam_wave = q->fe_lam_wave;
         memcpy(p2.lam_pow16, q->fe_lam_pow16, sizeof(p2.lam_pow16));
+        fe_fill_taps(q, &p2, s1, h2);
         (void)D2;
         LAUNCH_FE(K_FE_L2, pmr_launch_frontend(q->stream_fe, &p2, ntiles2, 256, 16));
 

@@ -18,6 +18,7 @@
 // both from LDS (the workgroup stages its 16-channel slab of the time-major discriminator stream once).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pmr_kernels.h"
 
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
                                                       long long row0, unsigned ns, const float *__restrict__ taps_c,
                                                       unsigned ntaps, float *__restrict__ out_tm,
                                                       int16_t *__restrict__ pcm, float *__restrict__ audio,
-                                                      unsigned stride)
+                                                      unsigned stride, int ablate)
 {
     constexpr int M = 16;
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
@@ -48,14 +49,14 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
     float *Xs = Qs + ((qlen + 31) & ~31u);                           // rows: r at r*16 + 16*(r>>5)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long T0 = (long)blockIdx.x * FM_TILE;                      // first frame of this workgroup (relative to row0)
-    const unsigned nrows = FM_TILE + ntaps - 1 + 18;                 // frames T0-(ntaps-1) .. T0+255 (+18: kappa padded to 16)
+    const unsigned nrows = FM_TILE + ntaps + 31;                     // frames T0-(ntaps-1) .. T0+255 (+32: kappa padded to 32)
 
     for (unsigned i = tid; i < qlen; i += FM_NT) Qs[i] = taps_c[i];
     for (unsigned u = tid; u < nrows * 4; u += FM_NT) {
         const unsigned r = u >> 2, q4 = (u & 3) * 4;
         const long t = T0 - (long)(ntaps - 1) + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < (long)ns) v = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + q4);
+        if (t < (long)ns && !(ablate & 1)) v = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + q4);
         *reinterpret_cast<float4 *>(Xs + r * 16 + 16 * (r >> 5) + q4) = v;
     }
     __syncthreads();
@@ -67,35 +68,38 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.f;
-    const float *qa = Qs + PMR_TAP_PAD + (ntaps - 1) + (lane & 31) - kk;   // tap for kappa = 2s + kk: qa[-2s]
-    int rb = Tj + kk;                                                // tile row for kappa = 2s + kk: rb + 2s
-    // kappa runs over [0, ntaps + 31); padded up to a multiple of 16 (the extra taps are zeros of the padded table) so
-    // that 8 (tap, sample) pairs are fetched from LDS ahead of the 8 MFMAs that consume them
-    const unsigned steps = ((ntaps + 31 + 15) / 16) * 8;
-    // explicit register double-buffering: the (tap, sample) pairs of the NEXT 8 steps are in flight from LDS while the
-    // 8 MFMAs of the current ones issue back to back (64 cycles each on this SIMD's matrix pipe)
-    float a[8], b[8], an[8], bn[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        a[u] = qa[-2 * u];
-        const int r = rb + 2 * u;
-        b[u] = Xs[r * 16 + 16 * (r >> 5) + ch];
+    // kappa runs over [0, ntaps + 31), padded up to a multiple of 32 (the extra taps are zeros of the padded table): 16
+    // MFMA steps per group.  Inside a group every LDS address is one per-lane base plus a compile-time offset:
+    //   tap     for kappa = 2s + kk :  Qs[PAD + (ntaps-1) + (lane&31) - kk - 2s]
+    //   sample  for kappa = 2s + kk :  row r = Tj + kk + 2s at r*16 + 16*(r>>5) + ch, and (kk + 2s) >> 5 == s >> 4,
+    //                                  so a group of 16 steps advances the base by 16*32 + 16 floats.
+    // Explicit two-set software pipeline (no register copies): the 32 operands of group g+1 are in flight from LDS while
+    // the 16 MFMAs of group g issue back to back; each set is waited for only right before its first use.
+    const unsigned groups = ((ntaps + 31 + 31) / 32) >> ((ablate >> 1) & 1);
+    const float *q0 = Qs + PMR_TAP_PAD + (ntaps - 1) + (lane & 31) - kk - 30;      // group 0, step 15; step s at q[2*(15-s)]
+    const float *x0 = Xs + (Tj + kk) * 16 + 16 * ((Tj + kk) >> 5) + ch;            // group 0, step 0;  step s at x[32*s]
+    float a0[16], b0[16], a1[16], b1[16];
+#define FM_LOAD(A, B, G) do { const unsigned gi_ = (G) < groups ? (G) : groups - 1;   /* clamped: never past the tables */ \
+        const float *q_ = q0 - 32 * (int)gi_, *x_ = x0 + (16 * 32 + 16) * (int)gi_;                                          \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) { A[u] = q_[2 * (15 - u)]; B[u] = x_[32 * u]; }                     \
+        __builtin_amdgcn_sched_barrier(0); } while (0)   /* keep the loads ahead of the MFMA block that hides them */
+#define FM_MMA(A, B) do { _Pragma("unroll") for (int u = 0; u < 16; u++)                                                  \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u], B[u], acc, 0, 0, 0);                                                \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+    FM_LOAD(a0, b0, 0u);
+    unsigned g = 0;
+    for (; g + 2 <= groups; g += 2) {
+        FM_LOAD(a1, b1, g + 1);
+        FM_MMA(a0, b0);
+        FM_LOAD(a0, b0, g + 2);
+        FM_MMA(a1, b1);
     }
-    for (unsigned s = 0; s < steps; s += 8) {
-        const unsigned sn = s + 8 < steps ? s + 8 : s;       // last round re-reads its own operands (harmless)
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            an[u] = qa[-2 * (int)(sn + u)];
-            const int r = rb + 2 * (int)(sn + u);
-            bn[u] = Xs[r * 16 + 16 * (r >> 5) + ch];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) { a[u] = an[u]; b[u] = bn[u]; }
-    }
+    if (groups & 1) FM_MMA(a0, b0);                                                // set 0 holds group groups-1 here
+#undef FM_LOAD
+#undef FM_MMA
 
     // D layout: lane holds column j; register g*4+q is row 8g + 4*kk + q  ->  4 consecutive frames per register group
+    if (ablate & 4) { if (acc[0] == 123.456f) pcm[0] = 1; return; }
     const bool vec_ok = ((stride & 3) == 0);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -144,7 +148,7 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
 {
     if (!ns) return 0;
     if (!pmr_fir_mfma_supported(M, ntaps)) return (int)hipErrorInvalidValue;
-    const unsigned qlen = ntaps + 2 * PMR_TAP_PAD, nrows = FM_TILE + ntaps - 1 + 18;
+    const unsigned qlen = ntaps + 2 * PMR_TAP_PAD, nrows = FM_TILE + ntaps + 31;
     const size_t lds = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float) +
                        ((size_t)nrows * 16 + 16 * ((nrows >> 5) + 1)) * sizeof(float);
     static bool attr_set = false;
@@ -154,6 +158,7 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
         attr_set = true;
     }
     hipLaunchKernelGGL(k_fir_mfma16, dim3((ns + FM_TILE - 1) / FM_TILE), dim3(FM_NT), lds, (hipStream_t)s, in,
-                       (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride);
+                       (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride,
+                       []{ const char *e = getenv("PMR_FIR_ABLATE"); return e ? atoi(e) : 0; }());
     return (int)hipGetLastError();
 }

@@ -19,6 +19,8 @@
 // arithmetic and was checked to 1e-15 in float64).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "pmr_kernels.h"
 
@@ -57,6 +59,9 @@ static __device__ __forceinline__ int lidx_rt(int e, int g_shift) { return e + (
 // ---------------------------------------------------------------------------------------------
 #ifndef FE_WAVES_512
 #define FE_WAVES_512 8      /* waves per SIMD requested for the 512 x 8 geometry (4 workgroups = 32 waves per CU) */
+#endif
+#ifndef FE_WAVES_256x8
+#define FE_WAVES_256x8 6     /* waves per SIMD requested for the 256 x 8 geometry (2048-sample tiles) */
 #endif
 #define FE_PAD 64      /* elements in front of the tile buffer; >= (4*10-2) * (1 + 1/2) */
 
@@ -160,7 +165,7 @@ static __device__ __forceinline__ unsigned long long ceil_div_u64(unsigned long 
 enum { FE_FULL = 0, FE_L1 = 1, FE_L2 = 2 };
 
 template <int NT, int SPT, int MODE>
-__global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) void k_frontend(pmr_fe_params p)
+__global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : (NT == 256 && SPT == 8) ? FE_WAVES_256x8 : 4) void k_frontend(pmr_fe_params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int N0 = NT * SPT;
@@ -424,6 +429,271 @@ __global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : 4) voi
 }
 
 // ---------------------------------------------------------------------------------------------
+// SPECIALISED front end for the cascades the As = 60 dB design produces: N3 six-tap stages (m = 3), optionally followed
+// by the m = 5 and m = 10 stages (TAIL), 256 threads x 16 samples.  Same arithmetic as k_frontend<256, 16, MODE>, same
+// order of operations; what changes is when things are fetched and how often the workgroup synchronises (the kernel is
+// latency-bound: its throughput is (tiles in flight) / (time one tile spends waiting)):
+//   * every table the tile needs -- branch taps (kernel-argument segment -> SGPRs), lambda powers, the polyphase taps of
+//     BOTH resampler outputs a thread can own -- is requested before the raw tile, not at the point of use behind a barrier;
+//   * the cascade ping-pongs between two LDS regions (z1 -> R0, z2 -> R1, z3 -> R0, ...), so a stage is
+//     read -> compute -> write -> ONE barrier instead of read -> barrier -> write -> barrier;
+//   * stage count, per-stage outputs per thread and LDS layouts are compile-time, so every LDS address is
+//     thread base + immediate.
+template <int P, int MM>
+static __device__ __forceinline__ void hb_stage_pp(const cf *__restrict__ src, cf *__restrict__ dst, int tid,
+                                                   int n_threads, const float *h1, float scale)
+{
+    constexpr int NE = P + 2 * MM - 1, G = 2 * P;
+    if (tid < n_threads) {
+        const cf *w = src + tid * (G + 1);
+        cf we[NE], wd[P];
+#pragma unroll
+        for (int i = 0; i < NE; i++) we[i] = w[loff<G>(2 * i - (4 * MM - 2))];
+#pragma unroll
+        for (int p = 0; p < P; p++) wd[p] = w[loff<G>(2 * p + 1 - 2 * MM)];
+        cf y[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            cf a = cfm(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 2 * MM; j++) a = cfma(h1[j], we[p + j], a);
+            y[p] = cadd_scale(wd[p], a, scale);
+        }
+        if constexpr (P >= 2) {
+            cf *o = dst + tid * (P + 1);               // L(P)
+#pragma unroll
+            for (int p = 0; p < P; p++) o[p] = y[p];
+        } else {
+            dst[tid + (tid >> 1)] = y[0];              // L(2)
+        }
+    }
+    __syncthreads();
+}
+
+template <int MODE, int N3, int TAIL>
+__global__ __launch_bounds__(256, 4) void k_frontend_fast(pmr_fe_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 256, SPT = 16, N0 = NT * SPT, LPT = N0 / 2 / NT;
+    constexpr int H = N3 + 2 * TAIL;
+    constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;         // z1 (2048 samples, layout L(8)) fills [0, R1_OFF) of the tile
+    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
+    cf *wagg = buf + (N0 + N0 / SPT);
+    cf *bnd = wagg + NT / 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const cf *__restrict__ x = (const cf *)p.x;
+    const cf *__restrict__ hist = (const cf *)p.hist;
+    const float lam = -p.dc_a1;
+    int c = blockIdx.x;
+    {
+        const int nt_all = gridDim.x, per = nt_all >> 3, main = per << 3;
+        if (c < main) c = (c & 7) * per + (c >> 3);         // XCD-aware tile order (see k_frontend)
+    }
+    const long b0 = (long)c * p.T_own - p.Hh - p.pend;
+
+    // ---- everything that comes from tables, requested up front ----
+    const unsigned long long qa = (unsigned long long)c * p.TQ;
+    unsigned long long ja = 0, jb = 0;
+    float bk0[14], bk1[14];
+    if constexpr (MODE != FE_L1) {
+        unsigned long long qb = qa + p.TQ;
+        if (qb > p.Q) qb = p.Q;
+        if (qa < qb) {
+            const unsigned long long sa = qa << 24, sb = qb << 24;
+            ja = sa <= p.phi0 ? 0ull : ceil_div_u64(sa - p.phi0, p.step);
+            jb = sb <= p.phi0 ? 0ull : ceil_div_u64(sb - p.phi0, p.step);
+            if (jb > p.ny) jb = p.ny;
+        }
+        const unsigned long long j0 = ja + tid, j1 = j0 + NT;
+        const unsigned long long ph0 = (unsigned long long)p.phi0 + j0 * p.step, ph1 = ph0 + (unsigned long long)NT * p.step;
+        const float *b0p = p.arb_bank + (j0 < jb ? (unsigned)(ph0 & 0xffffffu) >> 16 : 0u) * 14u;
+        const float *b1p = p.arb_bank + (j1 < jb ? (unsigned)(ph1 & 0xffffffu) >> 16 : 0u) * 14u;
+#pragma unroll
+        for (int k = 0; k < 14; k++) { bk0[k] = b0p[k]; bk1[k] = b1p[k]; }
+    }
+    float lp = 0.f, l15 = 0.f, l31 = 0.f;
+    if constexpr (MODE != FE_L2) {
+        lp = p.lam_lane_pow[lane]; l15 = p.lam_lane_pow[(lane & 15) + 1]; l31 = p.lam_lane_pow[(lane & 31) + 1];
+    }
+
+    // ---- phase A: raw samples -> LDS (layout L(16)) ----
+    if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
+    if constexpr (MODE == FE_L2) {
+        const cf *__restrict__ ring = (const cf *)p.in_ring;
+        const cf *__restrict__ V1 = (const cf *)p.fixV;
+        for (int i = tid; i < N0; i += NT) {
+            const long long a = (long long)p.in_abs0 + b0 + i;
+            const long long jn = b0 + i;
+            cf v = cfm(0.f, 0.f);
+            if (a >= 0 && jn < (long long)p.n_in) {
+                v = ring[(unsigned long long)a & p.in_mask];
+                if (V1 && jn >= 0) {
+                    const unsigned c1 = (unsigned)jn / p.fix_TQ;
+                    const unsigned ql = (unsigned)jn - c1 * p.fix_TQ + p.fix_HhQ;
+                    const float g = p.fix_K * (p.fix_T1[ql >> 5] * p.fix_T2[ql & 31]);
+                    const cf Vc = V1[c1];
+                    v = cf{fmaf(-Vc.x, g, v.x), fmaf(-Vc.y, g, v.y)};
+                }
+            }
+            buf[lidx<SPT>(i)] = v;
+        }
+    } else {
+        const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
+        if (fast) {
+            const float4 *__restrict__ src = reinterpret_cast<const float4 *>(x + b0);
+            float4 v[LPT];
+#pragma unroll
+            for (int i = 0; i < LPT; i++) v[i] = src[tid + NT * i];
+#pragma unroll
+            for (int i = 0; i < LPT; i++) {
+                cf *d = buf + lidx<SPT>(2 * (tid + NT * i));
+                d[0] = cfm(v[i].x, v[i].y);
+                d[1] = cfm(v[i].z, v[i].w);
+            }
+        } else {
+#pragma unroll 4
+            for (int i = tid; i < N0; i += NT) {
+                const long b = b0 + i;
+                cf v = cfm(0.f, 0.f);
+                if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) v = hist[hi]; }
+                else if (b < (long)p.n_in) v = x[b];
+                buf[lidx<SPT>(i)] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: dc blocker from zero state + first (six-tap) stage from registers ----
+    {
+        cf xs[SPT], yb[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; j++) xs[j] = buf[(SPT + 1) * tid + j];
+        if constexpr (MODE == FE_L2) {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) yb[j] = xs[j];
+        } else {
+            cf v = cfm(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < SPT; j++) v = cfma(lam, v, xs[j]);
+            v = cfma(p.lam_pow16[0], dpp0c<0x111>(v), v);
+            v = cfma(p.lam_pow16[1], dpp0c<0x112>(v), v);
+            v = cfma(p.lam_pow16[2], dpp0c<0x114>(v), v);
+            v = cfma(p.lam_pow16[3], dpp0c<0x118>(v), v);
+            v = cfma(l15, dpp0c<0x142, 0xA>(v), v);
+            v = cfma(l31, dpp0c<0x143, 0xC>(v), v);
+            if (lane == 63) wagg[wave] = v;
+            const cf ex = dpp0c<0x138>(v);
+            __syncthreads();
+            cf cw = cfm(0.f, 0.f);
+            for (int w = 0; w < wave; w++) cw = cfma(p.lam_wave, cw, wagg[w]);
+            cf v1 = cfma(lp, cw, ex);
+            const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
+            const int pE = (c == p.c_end) ? p.off_end : -1;
+            const bool stray = (pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid);
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                const cf v0 = cfma(lam, v1, xs[j]);
+                yb[j] = csub(v0, v1);
+                v1 = v0;
+                if (stray) {
+                    if (SPT * tid + j == pL) ((cf *)p.probeL)[0] = v0;
+                    if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = v0;
+                }
+            }
+            if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;
+            if (tid == NT - 1) ((cf *)p.probeB)[c] = v1;
+        }
+        cf W[26];
+#pragma unroll
+        for (int i = 0; i < 10; i++) W[i] = dpp0c<0x138>(yb[6 + i]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) W[10 + i] = yb[i];
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) bnd[wave * 10 + i] = yb[6 + i];
+        }
+        __syncthreads();                                   // also: every thread is done with the raw tile
+        if (lane == 0 && wave > 0) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * 10 + i];
+        }
+        const float scale0 = H == 1 ? p.zeta : 1.0f;
+        cf *o = buf + tid * 9;                             // z1 in layout L(8), region R0
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            cf a = cfm(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 6; j++) a = cfma(p.taps_k[j], W[2 * q + 2 * j], a);
+            o[q] = cadd_scale(W[2 * q + 5], a, scale0);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: remaining stages, ping-pong R0 <-> R1; stage e (execution index) has 2048 >> e outputs ----
+    cf *R0 = buf, *R1 = buf + R1_OFF;
+#define FE_STAGE(E, MM, TOFF) do { constexpr int NOUT = (N0 / 2) >> (E); constexpr int PP = NOUT >= NT ? NOUT / NT : 1;          \
+        hb_stage_pp<PP, MM>(((E) & 1) ? R0 : R1, ((E) & 1) ? R1 : R0, tid, NOUT / PP, p.taps_k + (TOFF),                         \
+                            (E) == H - 1 ? p.zeta : 1.0f); } while (0)
+    // six-tap stages 1 .. N3-1 (taps at 6 e), then the m = 5 and m = 10 stages
+    if constexpr (N3 >= 2) FE_STAGE(1, 3, 6);
+    if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
+    if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
+    if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
+    if constexpr (TAIL) { FE_STAGE(N3, 5, 6 * N3); FE_STAGE(N3 + 1, 10, 6 * N3 + 10); }
+#undef FE_STAGE
+    constexpr int NLAST = (N0 / 2) >> (H - 1);
+    constexpr int PLAST = H == 1 ? 8 : (NLAST >= NT ? NLAST / NT : 1);
+    constexpr int GS = PLAST >= 8 ? 3 : (PLAST == 4 ? 2 : 1);                   // final layout L(1 << GS)
+    const cf *fin = ((H - 1) & 1) ? R1 : R0;                                      // stage e writes R1 when e is odd
+
+    if constexpr (MODE == FE_L1) {
+        cf *__restrict__ out = (cf *)p.out;
+        for (int i = tid; i < p.TQ; i += NT) {
+            const unsigned long long q1 = qa + i;
+            if (q1 < p.Q) out[(p.out_pos0 + q1) & p.out_mask] = fin[(p.HhQ + i) + ((p.HhQ + i) >> GS)];
+        }
+    } else {
+        // ---- phase D: arbitrary resampler; a thread owns outputs ja + tid and ja + tid + 256 (taps already here) ----
+        cf *__restrict__ out = (cf *)p.out;
+        const unsigned long long j0 = ja + tid;
+        if (j0 < jb) {
+            const unsigned long long ph = (unsigned long long)p.phi0 + j0 * p.step;
+            const int ql = (int)((ph >> 24) - qa) + p.HhQ - 13;
+            cf y = cfm(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 14; k++) y = cfma(bk0[k], fin[(ql + k) + ((ql + k) >> GS)], y);
+            out[(p.out_pos0 + j0) & p.out_mask] = y;
+        }
+        if (j0 + NT < jb) {
+            const unsigned long long j1 = j0 + NT;
+            const unsigned long long ph = (unsigned long long)p.phi0 + j1 * p.step;
+            const int ql = (int)((ph >> 24) - qa) + p.HhQ - 13;
+            cf y = cfm(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 14; k++) y = cfma(bk1[k], fin[(ql + k) + ((ql + k) >> GS)], y);
+            out[(p.out_pos0 + j1) & p.out_mask] = y;
+        }
+        for (unsigned long long j = j0 + 2 * NT; j < jb; j += NT) {             // never taken for r_a <= 1 (<= 512 outputs/tile)
+            const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
+            const int ql = (int)((ph >> 24) - qa) + p.HhQ - 13;
+            const float *b = p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u;
+            cf y = cfm(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 14; k++) y = cfma(b[k], fin[(ql + k) + ((ql + k) >> GS)], y);
+            out[(p.out_pos0 + j) & p.out_mask] = y;
+        }
+    }
+    if (MODE != FE_L2 && c == 0 && p.new_hist) {
+        cf *__restrict__ nh = (cf *)p.new_hist;
+        for (int i = tid; i < p.hcap; i += NT) {
+            const long sb = (long)i + (long)p.n_in - (long)p.hcap;
+            nh[i] = sb < 0 ? hist[(long)i + p.n_in] : x[sb];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tile carries from the probes.  W_c = v just before tile c's OWN range, V_c = v just before its halo:
 //   W_{c+1} = rho W_c + (probeB_c - rho probeA_c),  rho = lambda^T_own;   V_c = (W_c - probeA_c) lambda^-Hh
 // rho^k vanishes after K terms, so every tile sums its K predecessors independently (no serial chain).
@@ -491,7 +761,8 @@ template <int NT, int SPT, int MODE>
 static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
 {
     const size_t n0 = (size_t)NT * SPT;
-    const size_t lds = (FE_PAD + n0 + n0 / SPT + 32 + 10 * (NT / 64 + 1)) * sizeof(cf);   /* pad + tile + scan scratch + halo exchange */
+    size_t lds = (FE_PAD + n0 + n0 / SPT + 32 + 10 * (NT / 64 + 1)) * sizeof(cf);   /* pad + tile + scan scratch + halo exchange */
+    { static long extra = -1; if (extra < 0) { const char *e = getenv("PMR_FE_LDS_EXTRA"); extra = e ? atol(e) : 0; } lds += (size_t)extra; }   /* experiment: fewer tiles per CU */
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend<NT, SPT, MODE>),
@@ -505,10 +776,53 @@ static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned nt
 
 /* tile geometries: (threads, samples per thread).  4096-sample tiles as 512 x 8 (default: twice the waves per CU
  * of 256 x 16 for the same LDS) or 256 x 16; 16384-sample tiles (deep cascades) as 1024 x 16.                 */
+template <int MODE, int N3, int TAIL>
+static int launch_frontend_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
+{
+    const size_t n0 = 4096;
+    size_t lds = (FE_PAD + n0 + n0 / 16 + 32 + 10 * (256 / 64 + 1)) * sizeof(cf);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend_fast<MODE, N3, TAIL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    auto kern = k_frontend_fast<MODE, N3, TAIL>;
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st, *p);
+    return (int)hipGetLastError();
+}
+
+/* the specialised kernel covers: N3 six-tap stages, then optionally (m = 5, m = 10); 256 x 16 tiles */
+static int fast_pattern(const pmr_fe_params *p, int *n3, int *tail)
+{
+    int k = 0;
+    while (k < p->h && p->m[k] == 3) k++;
+    *n3 = k;
+    if (k == p->h) { *tail = 0; return k >= 1; }
+    if (k >= 1 && k + 2 == p->h && p->m[k] == 5 && p->m[k + 1] == 10) { *tail = 1; return 1; }
+    return 0;
+}
+
 extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt)
 {
     if (!ntiles) return 0;
     hipStream_t st = (hipStream_t)s;
+    static int use_fast = -1;
+    if (use_fast < 0) { const char *e = getenv("PMR_FE_KERNEL"); use_fast = !(e && !strcmp(e, "generic")); }
+    int n3 = 0, tail = 0;
+    if (use_fast && nt == 256 && spt == 16 && !p->ablate && !p->stamps && p->taps_valid && fast_pattern(p, &n3, &tail)) {
+        if (p->mode == FE_FULL && tail) {
+            if (n3 == 1) return launch_frontend_fast<FE_FULL, 1, 1>(st, p, ntiles);
+            if (n3 == 2) return launch_frontend_fast<FE_FULL, 2, 1>(st, p, ntiles);
+            if (n3 == 3) return launch_frontend_fast<FE_FULL, 3, 1>(st, p, ntiles);
+        }
+        if (p->mode == FE_L2 && tail && n3 == 1) return launch_frontend_fast<FE_L2, 1, 1>(st, p, ntiles);
+        if (p->mode == FE_L1 && !tail) {
+            if (n3 == 2) return launch_frontend_fast<FE_L1, 2, 0>(st, p, ntiles);
+            if (n3 == 3) return launch_frontend_fast<FE_L1, 3, 0>(st, p, ntiles);
+            if (n3 == 4) return launch_frontend_fast<FE_L1, 4, 0>(st, p, ntiles);
+        }
+    }
     if (p->mode == FE_L1 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L1>(st, p, ntiles);
     if (p->mode == FE_L2 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L2>(st, p, ntiles);
     if (p->mode != FE_FULL) return (int)hipErrorInvalidValue;
@@ -516,6 +830,7 @@ extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsig
     if (nt == 1024 && spt == 16) return launch_frontend_t<1024, 16, FE_FULL>(st, p, ntiles);
     if (nt == 512 && spt == 16) return launch_frontend_t<512, 16, FE_FULL>(st, p, ntiles);
     if (nt == 512 && spt == 8) return launch_frontend_t<512, 8, FE_FULL>(st, p, ntiles);
+    if (nt == 256 && spt == 8) return launch_frontend_t<256, 8, FE_FULL>(st, p, ntiles);
     if (nt == 128 && spt == 16) return launch_frontend_t<128, 16, FE_FULL>(st, p, ntiles);
     if (nt == 192 && spt == 16) return launch_frontend_t<192, 16, FE_FULL>(st, p, ntiles);
     return (int)hipErrorInvalidValue;

@@ -144,6 +144,9 @@ typedef struct {
     int m[PMR_FE_MAX_STAGES], tap_off[PMR_FE_MAX_STAGES];
     float dc_a1, zeta, lam_wave;
     float lam_pow16[6];         /* lambda^(spt * 2^j)                                                */
+    int taps_valid;             /* taps_k holds all taps of this launch (they fit)                    */
+    float taps_k[48];           /* copy of this launch's branch taps (its stages only, execution order) in the kernel
+                                   argument segment: the specialised kernel reads them as scalars, no pointer chase */
 } pmr_fe_params;
 
 typedef struct {
