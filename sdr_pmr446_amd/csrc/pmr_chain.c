@@ -76,6 +76,8 @@ struct pmr_chain_s {
 
     /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
     int chan_small;                  /* small-M channelizer (pmr_channelize_small.hip) selected       */
+    int fix_skip;
+    int fix_fused;                   /* dc carry applied by the channelizer while staging (else: k_fe_dcfix in place) */
     int fe_on, fe_nt, fe_spt;        /* fused path selected; threads per tile workgroup, samples per thread */
     int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
     int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
@@ -519,6 +521,9 @@ static int chain_init(pmr_chain q)
     {
         const char *env = getenv("PMR_CHANNELIZER");
         q->chan_small = !(env && !strcmp(env, "generic")) && pmr_channelize_small_supported(M, p, d->nco_period);
+        const char *ff = getenv("PMR_DCFIX_FUSE");
+        q->fix_fused = ff ? atoi(ff) != 0 : 1;
+        q->fix_skip = getenv("PMR_NOFIX") != NULL;      /* timing experiment only: results are wrong */
     }
 
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0;
@@ -783,7 +788,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
     LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
 
-    if (ny && !(q->chan_small && !q->dbg_on)) {  /* else: the small-M channelizer applies the carry while staging */
+    if (ny && !(q->chan_small && q->fix_fused && !q->dbg_on)) {  /* else: the small-M channelizer applies the carry while staging */
         pmr_fe_fix_params f;
         memset(&f, 0, sizeof(f));
         f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[q->n_calls & 1]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
@@ -1079,7 +1084,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         c.fm_ref = d->fm_ref; c.chan_out = d_chan_out; c.chan_stride = pcm_stride;
         c.rssi_part = d_rssi_db ? q->d_rssi_part : NULL;
         if (q->chan_small) {
-            const int fuse_fix = q->fe_on && !q->fe_two && ny && !q->dbg_on;
+            const int fuse_fix = q->fe_on && !q->fe_two && ny && !q->dbg_on && q->fix_fused && !q->fix_skip;
             if (fuse_fix) {                      /* deferred dc carry of the fused front end, applied while staging */
                 c.V = q->d_fe_V[par]; c.GA = q->d_fe_GA; c.T1 = q->d_fe_T1; c.T2 = q->d_fe_T2;
                 c.fix_abs0 = xr_abs0; c.fix_ny = ny; c.TQ = (unsigned)q->fe_TQ; c.HhQ = (unsigned)q->fe_HhQ;
@@ -1122,7 +1127,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
             }
         }
     }
-    if (q->chan_small && q->fe_on && !q->fe_two && ny && !q->dbg_on) {
+    if (q->chan_small && q->fix_fused && q->fe_on && !q->fe_two && ny && !q->dbg_on && !q->fix_skip) {
         /* The staging pass corrected its private copy only.  What later blocks will re-read as history -- the last
          * (p+1)*M samples -- gets its dc carry in place now (after the channelizer, same stream). */
         const unsigned keep = (p + 1) * M;

@@ -61,22 +61,37 @@ static __device__ __forceinline__ void fft_dit(cf (&x)[M], const cf *__restrict_
     }
 }
 
+#ifndef CS_NT
 #define CS_NT 256
+#endif
+#ifndef CS_ABL
+#define CS_ABL 0                         /* timing experiments only: 1 no staging, 2 no filter bank, 4 no FFT, 8 no discriminator */
+#endif
 #define CS_FPT 2                          /* frames per thread */
 
-// deferred dc carry of the fused front end for resampled sample j of this call (pmr_frontend.hip, k_fe_dcfix):
-//   x -= V_c * K * mu^q' * GA[idx]
-static __device__ __forceinline__ void dc_fix(float &xr_, float &xi_, unsigned long long j, const pmr_chan_params &q)
+// Deferred dc carry of the fused front end (pmr_frontend.hip, k_fe_dcfix): resampled sample j of this call gets
+//   x -= V_c * K * mu^q' * GA[idx],   ph = phi0 + j*step,  qd = ph >> 24,  c = qd / TQ,  q' = qd - c*TQ + HhQ.
+// A thread walks j in increasing order, so (ph, qd, c, q') are carried and advanced incrementally: one 64-bit
+// multiply-add and a compare/subtract per step instead of a 32-bit division per sample.
+struct dc_track { unsigned long long ph, j; unsigned qd, c, ql; bool init; };
+
+// advance the tracker to sample j (>= the tracker's current sample) and return its (c, ql, ph)
+static __device__ __forceinline__ void dc_seek(dc_track &t, unsigned long long j, const pmr_chan_params &q)
 {
-    const unsigned long long ph = (unsigned long long)q.phi0 + j * q.step;
-    const unsigned qd = (unsigned)(ph >> 24);
-    const unsigned idx = (unsigned)(ph & 0xffffffu) >> 16;
-    const unsigned c = qd / q.TQ;
-    const unsigned ql = qd - c * q.TQ + q.HhQ;
-    const float g = q.Kgain * q.GA[idx] * (q.T1[ql >> 5] * q.T2[ql & 31]);
-    const cf V = ((const cf *)q.V)[c];
-    xr_ = fmaf(-V.x, g, xr_);
-    xi_ = fmaf(-V.y, g, xi_);
+    if (!t.init) {
+        t.ph = (unsigned long long)q.phi0 + j * q.step;
+        t.qd = (unsigned)(t.ph >> 24);
+        t.c = t.qd / q.TQ;
+        t.ql = t.qd - t.c * q.TQ;
+        t.init = true;
+    } else {
+        t.ph += (j - t.j) * q.step;
+        const unsigned qn = (unsigned)(t.ph >> 24);
+        t.ql += qn - t.qd;
+        t.qd = qn;
+        while (t.ql >= q.TQ) { t.ql -= q.TQ; t.c++; }
+    }
+    t.j = j;
 }
 
 template <int M>
@@ -110,22 +125,63 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
         const unsigned i0 = ((unsigned)s_base + 2u * tid) & nco_mask;
         const cf c0 = nco_cs[i0], c1 = nco_cs[(i0 + 1) & nco_mask];
         const long long xr_end = (long long)q.xr_end, fix0 = (long long)q.fix_abs0;
-        for (unsigned u = tid; u < units; u += CS_NT) {
-            const long long a = s_base + 2 * (long long)u;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a >= 0 && a + 1 < xr_end) v = *reinterpret_cast<const float4 *>(xr + ((unsigned long long)a & q.xr_mask));
-            else if (a >= 0 && a < xr_end) { const cf s1 = xr[(unsigned long long)a & q.xr_mask]; v.x = s1.x; v.y = s1.y; }
-            if (q.V && a + 1 >= fix0) {                   // samples produced by THIS call still miss their dc carry
-                if (a >= fix0 && a < xr_end) dc_fix(v.x, v.y, (unsigned long long)(a - fix0), q);
-                if (a + 1 < xr_end) dc_fix(v.z, v.w, (unsigned long long)(a + 1 - fix0), q);
+        dc_track trk;
+        trk.init = false; trk.ph = 0; trk.j = 0; trk.qd = trk.c = trk.ql = 0;
+        // Batches of CS_SB units per thread: all ring loads of a batch are issued before anything consumes them, then all
+        // table look-ups of the dc carry, then the arithmetic -- a plain one-unit-per-iteration loop pays the full L2
+        // latency of its load 17 times in a row.
+        constexpr int CS_SB = 6;
+        for (unsigned u0 = tid; u0 < ((CS_ABL & 1) ? 0u : units); u0 += CS_SB * CS_NT) {
+            float4 v[CS_SB];
+            float g0[CS_SB], g1[CS_SB];
+            cf V0[CS_SB], V1[CS_SB];
+#pragma unroll
+            for (int k = 0; k < CS_SB; k++) {
+                const unsigned u = u0 + k * CS_NT;
+                const long long a = s_base + 2 * (long long)u;
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u < units) {
+                    if (a >= 0 && a + 1 < xr_end) v[k] = *reinterpret_cast<const float4 *>(xr + ((unsigned long long)a & q.xr_mask));
+                    else if (a >= 0 && a < xr_end) { const cf s1 = xr[(unsigned long long)a & q.xr_mask]; v[k].x = s1.x; v[k].y = s1.y; }
+                }
             }
-            float4 o;
-            o.x = fmaf(v.x, c0.x, v.y * c0.y);            // x * conj(e^{j theta})
-            o.y = fmaf(v.y, c0.x, -(v.x * c0.y));
-            o.z = fmaf(v.z, c1.x, v.w * c1.y);
-            o.w = fmaf(v.w, c1.x, -(v.z * c1.y));
-            const unsigned f = (2 * u) >> L2M, c = (2 * u) & (M - 1);
-            *reinterpret_cast<float4 *>(xs + f * FS + c) = o;
+#pragma unroll
+            for (int k = 0; k < CS_SB; k++) {
+                const unsigned u = u0 + k * CS_NT;
+                const long long a = s_base + 2 * (long long)u;
+                g0[k] = g1[k] = 0.f; V0[k] = V1[k] = cfm(0.f, 0.f);
+                if (q.V && u < units && a + 1 >= fix0) {      // samples produced by THIS call still miss their dc carry
+                    if (a >= fix0 && a < xr_end) {
+                        dc_seek(trk, (unsigned long long)(a - fix0), q);
+                        const unsigned e = trk.ql + q.HhQ;
+                        g0[k] = q.GA[(unsigned)(trk.ph & 0xffffffu) >> 16] * (q.T1[e >> 5] * q.T2[e & 31]);
+                        V0[k] = ((const cf *)q.V)[trk.c];
+                    }
+                    if (a + 1 < xr_end) {
+                        dc_seek(trk, (unsigned long long)(a + 1 - fix0), q);
+                        const unsigned e = trk.ql + q.HhQ;
+                        g1[k] = q.GA[(unsigned)(trk.ph & 0xffffffu) >> 16] * (q.T1[e >> 5] * q.T2[e & 31]);
+                        V1[k] = ((const cf *)q.V)[trk.c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CS_SB; k++) {
+                const unsigned u = u0 + k * CS_NT;
+                if (u < units) {
+                    float4 w = v[k];
+                    const float ga = q.Kgain * g0[k], gb = q.Kgain * g1[k];
+                    w.x = fmaf(-V0[k].x, ga, w.x); w.y = fmaf(-V0[k].y, ga, w.y);
+                    w.z = fmaf(-V1[k].x, gb, w.z); w.w = fmaf(-V1[k].y, gb, w.w);
+                    float4 o;
+                    o.x = fmaf(w.x, c0.x, w.y * c0.y);        // x * conj(e^{j theta})
+                    o.y = fmaf(w.y, c0.x, -(w.x * c0.y));
+                    o.z = fmaf(w.z, c1.x, w.w * c1.y);
+                    o.w = fmaf(w.w, c1.x, -(w.z * c1.y));
+                    const unsigned f = (2 * u) >> L2M, c = (2 * u) & (M - 1);
+                    *reinterpret_cast<float4 *>(xs + f * FS + c) = o;
+                }
+            }
         }
     }
     __syncthreads();
@@ -136,7 +192,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
     for (int c = 0; c < M; c++) { XA[c] = cfm(0.f, 0.f); XB[c] = cfm(0.f, 0.f); }
     {
         const cf *row = xs + (size_t)(CS_FPT * tid) * FS;
-        for (unsigned j = 0; j <= p; j++) {               // buffer frame (local 2*tid + j) feeds A with tap j, B with tap j-1
+        for (unsigned j = 0; j <= ((CS_ABL & 2) ? 1u : p); j++) {   // buffer frame (local 2*tid + j) feeds A with tap j, B with tap j-1
             cf s[M];
 #pragma unroll
             for (int c = 0; c < M; c += 2) {
@@ -160,8 +216,10 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
     cf YA[M], YB[M];
 #pragma unroll
     for (int c = 0; c < M; c++) { YA[brev_c(c, L2M)] = XA[c]; YB[brev_c(c, L2M)] = XB[c]; }
-    fft_dit<M>(YA, fft_tw);
-    fft_dit<M>(YB, fft_tw);
+    if (!(CS_ABL & 4)) {
+        fft_dit<M>(YA, fft_tw);
+        fft_dit<M>(YB, fft_tw);
+    }
 
     // ---- previous frame for frame A: neighbour thread's frame B, through LDS ----
     __syncthreads();                                      // everyone is done reading the staged samples
@@ -198,7 +256,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const cf pv = PV[k + i], cu = YA[k + i];
-                rr[i] = atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
+                rr[i] = (CS_ABL & 8) ? pv.x + cu.y : atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
             }
             *reinterpret_cast<float4 *>(o + k) = r;
         }
@@ -212,7 +270,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const cf pv = YA[k + i], cu = YB[k + i];
-                rr[i] = atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
+                rr[i] = (CS_ABL & 8) ? pv.x + cu.y : atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
             }
             *reinterpret_cast<float4 *>(o + k) = r;
         }

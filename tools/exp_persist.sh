@@ -1,6 +1,7 @@
-for g in default 192x16; do
-  echo "GEOM=$g"
-  PMR_FE_GEOM=$g python3 bench.py --no-cpu-baseline --steps 30 2>&1 | python3 -c "
+for w in cfg2 cfg5; do
+for k in 0 4; do
+  echo "WORKLOAD=$w PERSIST=$k"
+  PMR_FE_PERSIST=$k python3 bench.py --workload $w --no-cpu-baseline --steps 30 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -8,4 +9,5 @@ for l in sys.stdin:
         print('value %.1f GS/s  ms/step %.4f  fe(contended) %.4f  isolated:'%(d['value']/1e3,d['ms_per_step'],r['avg_kernel_ms']), {k:round(v,4) for k,v in r['kernels_ms_per_step_isolated'].items()})
 "
 done
-PMR_FE_GEOM=192x16 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "cfg2 or blocks or split" 2>&1 | tail -2
+done
+python3 -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_gpu_dsd.py -m gpu -q -x 2>&1 | tail -3
