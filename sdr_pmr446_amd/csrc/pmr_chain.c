@@ -24,6 +24,9 @@
 #define AUX_HIST_FRAMES 128u    /* history of the time-major intermediates behind the HP stage        */
 #define ARB_KEEP 16             /* decimated-sample history kept for the 14-tap arbitrary resampler   */
 #define PROF_SLOTS 24
+#define PIPE_DEPTH 3u             /* blocks in flight: rings hold history + PIPE_DEPTH blocks; block b's front end waits for
+                                   the back end of block b - PIPE_DEPTH.  3 lets the front end run back to back: the back end of
+                                   block b (channelizer, audio FIR) then always has a front end to run under */
 
 typedef struct { float re, im; } cfl;
 
@@ -43,7 +46,7 @@ struct pmr_chain_s {
     int device;
     hipStream_t stream;              /* back-end stream (channelizer, audio, outputs): what callers synchronise on */
     hipStream_t stream_fe;           /* front-end stream: block b+1's front end overlaps block b's back end        */
-    hipEvent_t ev_fe[2], ev_be[2];   /* front end / back end of block (parity) finished                            */
+    hipEvent_t ev_fe[PIPE_DEPTH], ev_be[PIPE_DEPTH];   /* front end / back end of block (n mod PIPE_DEPTH) finished     */
     int overlap;                     /* two-stream pipelining enabled (PMR_OVERLAP=0 disables)                     */
     uint64_t n_calls;
     unsigned M, res_size, chan_size;
@@ -84,7 +87,7 @@ struct pmr_chain_s {
     float fe_Kgain, fe_lam_wave, fe_lam_pow16[6];
     float fe_taps_host[PMR_FE_MAX_STAGES * 64];
     float *d_fe_taps, *d_fe_GA, *d_fe_T1, *d_fe_T2, *d_fe_lam_lane;
-    cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V[2];
+    cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V[PIPE_DEPTH];
     uint64_t *d_fe_stamps;           /* diagnostic per-phase cycle sums (PMR_FE_STAMP)                */
     /* two-level front end for deep cascades: level 1 = dc-block + first fe_s1 stages -> decimated ring, level 2 = rest */
     int fe_two;                      /* 1: two launches of k_frontend (modes 1 and 2)                 */
@@ -403,7 +406,7 @@ static int fe_init(pmr_chain q)
     }
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeA, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeB, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
-    for (int i = 0; i < 2; i++)
+    for (unsigned i = 0; i < PIPE_DEPTH; i++)
         if ((rc = dev_alloc(q, (void **)&q->d_fe_V[i], (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeL, sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeE, sizeof(cfl)))) return rc;
@@ -491,14 +494,14 @@ static int chain_init(pmr_chain q)
         size_t cap = (size_t)q->keep[e] + ((size_t)mb >> e) + 2;
         if ((rc = dev_alloc(q, (void **)&q->d_z[e], cap * sizeof(cfl)))) return rc;
     }
-    /* rings sized for the filter history plus TWO blocks, so block b+1's front end never overwrites what block b's
+    /* rings sized for the filter history plus PIPE_DEPTH blocks, so block b+1's front end never overwrites what block b's
      * back end still reads */
     {
-        uint64_t need = (uint64_t)(p + 1) * M + 2ull * q->res_size + 64, cap = 1;
+        uint64_t need = (uint64_t)(p + 1) * M + (uint64_t)PIPE_DEPTH * q->res_size + 64, cap = 1;
         while (cap < need) cap <<= 1;
         q->xr_mask = cap - 1;
         if ((rc = dev_alloc(q, (void **)&q->d_xr, (size_t)cap * sizeof(cfl)))) return rc;
-        need = (uint64_t)FM_HIST_FRAMES + 2ull * q->chan_size + 64; cap = 1;
+        need = (uint64_t)FM_HIST_FRAMES + (uint64_t)PIPE_DEPTH * q->chan_size + 64; cap = 1;
         while (cap < need) cap <<= 1;
         q->fm_mask = cap - 1;
         if ((rc = dev_alloc(q, (void **)&q->d_fm, (size_t)cap * M * sizeof(float)))) return rc;
@@ -522,7 +525,7 @@ static int chain_init(pmr_chain q)
         const char *env = getenv("PMR_CHANNELIZER");
         q->chan_small = !(env && !strcmp(env, "generic")) && pmr_channelize_small_supported(M, p, d->nco_period);
         const char *ff = getenv("PMR_DCFIX_FUSE");
-        q->fix_fused = ff ? atoi(ff) != 0 : 1;
+        q->fix_fused = ff ? atoi(ff) != 0 : 0;   /* default: k_fe_tilefix corrects in place right after the front end */
         q->fix_skip = getenv("PMR_NOFIX") != NULL;      /* timing experiment only: results are wrong */
     }
 
@@ -562,11 +565,18 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
     }
     q->M = cfg->num_channels;
     pmr_design_buffer_sizes(&q->d, cfg->max_block, &q->res_size, &q->chan_size);
-    if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&q->stream_fe, hipStreamNonBlocking) != hipSuccess) {
+    /* The back end gets the higher stream priority: its kernels are short and their workgroups are bulky (77 KB / 45 KB
+     * of LDS), so at equal priority they starve behind the front end's 36 KB tiles and the whole pipeline runs at the
+     * back end's (contended) pace.  With priority they run at nearly their isolated speed and the front end -- the
+     * longer kernel -- fills every CU slot they leave. */
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       /* numerically lower = higher priority */
+    { const char *pe = getenv("PMR_STREAM_PRIO"); if (pe && !strcmp(pe, "0")) prio_hi = prio_lo; }
+    if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_lo) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
     }
-    for (int i = 0; i < 2; i++) {
+    for (unsigned i = 0; i < PIPE_DEPTH; i++) {
         if (hipEventCreateWithFlags(&q->ev_fe[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q->ev_be[i], hipEventDisableTiming) != hipSuccess) {
             pmr_design_free(&q->d); free(q); return NULL;
@@ -588,7 +598,7 @@ int pmr_chain_destroy(pmr_chain q)
     if (q->stream_fe) hipStreamSynchronize(q->stream_fe);
     if (q->stream) hipStreamSynchronize(q->stream);
     prof_resolve(q);
-    for (int i = 0; i < 2; i++) { if (q->ev_fe[i]) hipEventDestroy(q->ev_fe[i]); if (q->ev_be[i]) hipEventDestroy(q->ev_be[i]); }
+    for (unsigned i = 0; i < PIPE_DEPTH; i++) { if (q->ev_fe[i]) hipEventDestroy(q->ev_fe[i]); if (q->ev_be[i]) hipEventDestroy(q->ev_be[i]); }
     if (q->stream_fe) hipStreamDestroy(q->stream_fe);
     for (unsigned i = 0; i < q->npool; i++) hipEventDestroy(q->pool[i]);
     free(q->pool); free(q->pend);
@@ -600,7 +610,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_ring1, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     if (q->stream) hipStreamDestroy(q->stream);
@@ -782,19 +792,21 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     if (kterms < 1.0) kterms = 1.0;
     if (kterms > 1e6) kterms = 1e6;
     t.probeA = q->d_fe_probeA; t.probeB = q->d_fe_probeB; t.probeL = q->d_fe_probeL; t.probeE = q->d_fe_probeE;
-    t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V[q->n_calls & 1];
+    t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V[q->n_calls % PIPE_DEPTH];
     t.ntiles = ntiles; t.K = (unsigned)kterms; t.c_end = c_end;
     t.rho = (float)rho; t.lamHh = (float)pow(lam, (double)q->fe_Hh); t.inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
     t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
-    LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
-
-    if (ny && !(q->chan_small && q->fix_fused && !q->dbg_on)) {  /* else: the small-M channelizer applies the carry while staging */
-        pmr_fe_fix_params f;
-        memset(&f, 0, sizeof(f));
-        f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[q->n_calls & 1]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
-        f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
-        f.Kgain = q->fe_Kgain;
-        LAUNCH_FE(K_FE_FIX, pmr_launch_fe_dcfix(q->stream_fe, &f));
+    pmr_fe_fix_params f;
+    memset(&f, 0, sizeof(f));
+    f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[q->n_calls % PIPE_DEPTH]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
+    f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
+    f.Kgain = q->fe_Kgain;
+    if (q->chan_small && q->fix_fused && !q->dbg_on) {
+        /* older arrangement: carries only; the small-M channelizer applies them while staging (+ a tail fix afterwards) */
+        LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
+    } else {
+        /* carries and the whole block's correction in one launch, one wave per tile */
+        LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tilefix(q->stream_fe, &t, &f, Q));
     }
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
@@ -817,7 +829,7 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     unsigned ny = 0, ns_unused = 0; uint32_t new_phase = 0;
     plan_core(h, d->arb_step, q->M, q->n_raw, q->arb_phase, 0, n_in, &ny, &ns_unused, &new_phase);
     const int cur = q->fe_sel, nxt = cur ^ 1;
-    const unsigned par = (unsigned)(q->n_calls & 1);
+    const unsigned par = (unsigned)(q->n_calls % PIPE_DEPTH);
 
     /* ---- level 1 ---- */
     const unsigned long total1 = (unsigned long)pend1 + n_in;
@@ -1048,10 +1060,11 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
 
     /* ---- front end of this block on stream_fe.  It may run while the back end of the PREVIOUS block is still
      * busy on q->stream; it must not start before the back end of the block before that has released its part
-     * of the rings (they hold history + two blocks). ---- */
-    const unsigned par = (unsigned)(q->n_calls & 1);
-    if (q->n_calls >= 2) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
-    if (!q->overlap && q->n_calls >= 1) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par ^ 1], 0), "wait back end");
+     * of the rings (they hold history + PIPE_DEPTH blocks). ---- */
+    const unsigned par = (unsigned)(q->n_calls % PIPE_DEPTH);
+    if (q->n_calls >= PIPE_DEPTH) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
+    if (!q->overlap && q->n_calls >= 1)
+        HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[(q->n_calls - 1) % PIPE_DEPTH], 0), "wait back end");
     const uint32_t phi0 = q->arb_phase;          /* resampler phase before this block (dc carry bookkeeping) */
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "pmr_kernels.h"
 
@@ -36,6 +37,7 @@ static __device__ __forceinline__ int16_t pcm16(float y)
     return (int16_t)s;                            // truncation toward zero (src/dsd_in.c:174), saturated
 }
 
+template <bool GLB>
 __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ in, unsigned long long row_mask,
                                                       long long row0, unsigned ns, const float *__restrict__ taps_c,
                                                       unsigned ntaps, float *__restrict__ out_tm,
@@ -52,7 +54,11 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
     const unsigned nrows = FM_TILE + ntaps + 31;                     // frames T0-(ntaps-1) .. T0+255 (+32: kappa padded to 32)
 
     for (unsigned i = tid; i < qlen; i += FM_NT) Qs[i] = taps_c[i];
-    for (unsigned u = tid; u < nrows * 4; u += FM_NT) {
+    // GLB: no sample window in LDS at all -- the B operand comes straight from the time-major ring through the vector L1
+    // (a wave-instruction touches four 64-byte rows).  With ~2 KB of LDS and < 128 registers a workgroup of this kernel
+    // fits NEXT TO the front end's tiles on a CU (they leave 16 KB LDS and 128 VGPRs per SIMD free), so the otherwise idle
+    // matrix pipe works under the front end instead of after it.
+    for (unsigned u = tid; u < (GLB ? 0u : nrows * 4); u += FM_NT) {
         const unsigned r = u >> 2, q4 = (u & 3) * 4;
         const long t = T0 - (long)(ntaps - 1) + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -78,10 +84,16 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
     const unsigned groups = ((ntaps + 31 + 31) / 32) >> ((ablate >> 1) & 1);
     const float *q0 = Qs + PMR_TAP_PAD + (ntaps - 1) + (lane & 31) - kk - 30;      // group 0, step 15; step s at q[2*(15-s)]
     const float *x0 = Xs + (Tj + kk) * 16 + 16 * ((Tj + kk) >> 5) + ch;            // group 0, step 0;  step s at x[32*s]
+    const long long rb0 = row0 + T0 + Tj + kk - (long long)(ntaps - 1);            // GLB: ring row of group 0, step 0
+    const float *gin = in + ch;
     float a0[16], b0[16], a1[16], b1[16];
 #define FM_LOAD(A, B, G) do { const unsigned gi_ = (G) < groups ? (G) : groups - 1;   /* clamped: never past the tables */ \
         const float *q_ = q0 - 32 * (int)gi_, *x_ = x0 + (16 * 32 + 16) * (int)gi_;                                          \
-        _Pragma("unroll") for (int u = 0; u < 16; u++) { A[u] = q_[2 * (15 - u)]; B[u] = x_[32 * u]; }                     \
+        const long long rg_ = rb0 + 32 * (long long)gi_;                                                                      \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) {                                                                      \
+            A[u] = q_[2 * (15 - u)];                                                                                          \
+            if constexpr (GLB) B[u] = gin[((unsigned long long)(rg_ + 2 * u) & row_mask) * M];                                \
+            else B[u] = x_[32 * u]; }                                                                                         \
         __builtin_amdgcn_sched_barrier(0); } while (0)   /* keep the loads ahead of the MFMA block that hides them */
 #define FM_MMA(A, B) do { _Pragma("unroll") for (int u = 0; u < 16; u++)                                                  \
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u], B[u], acc, 0, 0, 0);                                                \
@@ -153,12 +165,23 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
                        ((size_t)nrows * 16 + 16 * ((nrows >> 5) + 1)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_fir_mfma16, dim3((ns + FM_TILE - 1) / FM_TILE), dim3(FM_NT), lds, (hipStream_t)s, in,
-                       (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride,
-                       []{ const char *e = getenv("PMR_FIR_ABLATE"); return e ? atoi(e) : 0; }());
+    /* PMR_FIR_MFMA=global: B operand straight from the ring (no LDS window; co-resides with front-end tiles).  Measured
+     * on MI355X: slower in isolation (0.082 vs 0.066 ms at cfg2) and equal within noise inside the pipelined chain, so the
+     * LDS-window kernel stays the default. */
+    static int glb = -1;
+    if (glb < 0) { const char *e = getenv("PMR_FIR_MFMA"); glb = (e && !strcmp(e, "global")); }
+    const int ablate = []{ const char *e = getenv("PMR_FIR_ABLATE"); return e ? atoi(e) : 0; }();
+    if (glb) {
+        const size_t lds_g = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float);
+        hipLaunchKernelGGL(k_fir_mfma16<true>, dim3((ns + FM_TILE - 1) / FM_TILE), dim3(FM_NT), lds_g, (hipStream_t)s, in,
+                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_fir_mfma16<false>, dim3((ns + FM_TILE - 1) / FM_TILE), dim3(FM_NT), lds, (hipStream_t)s, in,
+                       (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate);
     return (int)hipGetLastError();
 }

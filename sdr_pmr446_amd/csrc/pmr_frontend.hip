@@ -746,6 +746,67 @@ __global__ __launch_bounds__(256) void k_fe_dcfix(pmr_fe_fix_params p)
     *o = v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_fe_tiles + k_fe_dcfix in one launch, one WAVE per front-end tile: the lanes sum the K predecessor terms of the
+// tile's carry (wave reduction), then the same wave corrects the ~T_own * rate resampler outputs its tile produced, in
+// place.  q' is simply the tile-local decimated index here, so the 32-bit division per sample of k_fe_dcfix is gone, and
+// the consumer (channelizer) no longer has to apply the carry while staging.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_fe_fix_params f, unsigned n_q /*decimated samples of the block*/)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c >= t.ntiles) return;
+    const cf *pa = (const cf *)t.probeA, *pb = (const cf *)t.probeB;
+    // ---- V_c exactly as k_fe_tiles computes it, the K-term sum spread over the lanes ----
+    const unsigned kmax = c < t.K ? c : t.K;
+    float ar = 0.f, ai = 0.f;
+    for (unsigned k = 1 + lane; k <= kmax; k += 64u) {
+        const cf A = pa[c - k], B = pb[c - k];
+        const float pw = powf(t.rho, (float)(k - 1));
+        ar = fmaf(pw, fmaf(-t.rho, A.x, B.x), ar);
+        ai = fmaf(pw, fmaf(-t.rho, A.y, B.y), ai);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { ar += __shfl_xor(ar, d); ai += __shfl_xor(ai, d); }
+    if (c <= t.K) {
+        const cf vs = *(const cf *)t.v_in, pl = *(const cf *)t.probeL, a0 = pa[0];
+        const float V0r = (vs.x - pl.x) * t.inv_lamL, V0i = (vs.y - pl.y) * t.inv_lamL;
+        const float W0r = fmaf(t.lamHh, V0r, a0.x), W0i = fmaf(t.lamHh, V0i, a0.y);
+        const float pw = powf(t.rho, (float)kmax);
+        ar = fmaf(pw, W0r, ar); ai = fmaf(pw, W0i, ai);
+    }
+    const cf Ac = pa[c];
+    const float Vr = (ar - Ac.x) * t.inv_lamHh, Vi = (ai - Ac.y) * t.inv_lamHh;
+    if (lane == 0) {
+        ((cf *)t.V)[c] = cfm(Vr, Vi);
+        if (c == t.c_end) {
+            const cf pe = *(const cf *)t.probeE;
+            *(cf *)t.v_out = cfm(fmaf(t.lamEnd, Vr, pe.x), fmaf(t.lamEnd, Vi, pe.y));
+        }
+    }
+    // ---- the tile's own outputs: decimated samples [c TQ, (c+1) TQ) <-> outputs [ja, jb) ----
+    const unsigned long long qa = (unsigned long long)c * f.TQ;
+    unsigned long long qb = qa + f.TQ;
+    if (qb > n_q) qb = n_q;
+    if (qa >= qb) return;
+    const unsigned long long sa = qa << 24, sb = qb << 24;
+    unsigned long long ja = sa <= f.phi0 ? 0ull : ceil_div_u64(sa - f.phi0, f.step);
+    unsigned long long jb = sb <= f.phi0 ? 0ull : ceil_div_u64(sb - f.phi0, f.step);
+    if (jb > f.ny) jb = f.ny;
+    cf *xr = (cf *)f.xr;
+    for (unsigned long long j = ja + lane; j < jb; j += 64u) {
+        const unsigned long long ph = (unsigned long long)f.phi0 + j * f.step;
+        const unsigned ql = (unsigned)((ph >> 24) - qa) + f.HhQ;
+        const float g = f.Kgain * f.GA[(unsigned)(ph & 0xffffffu) >> 16] * (f.T1[ql >> 5] * f.T2[ql & 31]);
+        cf *o = xr + ((f.pos0 + j) & f.mask);
+        cf v = *o;
+        v.x = fmaf(-Vr, g, v.x);
+        v.y = fmaf(-Vi, g, v.y);
+        *o = v;
+    }
+}
+
 // raw history for the next call: last hcap samples of (old history || block)
 __global__ __launch_bounds__(256) void k_fe_hist(const cf *__restrict__ old_hist, const cf *__restrict__ x,
                                                  unsigned n_in, cf *__restrict__ new_hist, unsigned hcap)
@@ -847,6 +908,13 @@ extern "C" int pmr_launch_fe_dcfix(pmr_stream_t s, const pmr_fe_fix_params *p)
 {
     if (p->ny <= p->j0) return 0;
     hipLaunchKernelGGL(k_fe_dcfix, dim3((p->ny - p->j0 + 255) / 256), dim3(256), 0, (hipStream_t)s, *p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q)
+{
+    if (!t->ntiles) return 0;
+    hipLaunchKernelGGL(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, *t, *f, n_q);
     return (int)hipGetLastError();
 }
 

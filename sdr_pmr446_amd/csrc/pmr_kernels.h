@@ -168,6 +168,8 @@ typedef struct {
 int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt);
 int pmr_launch_fe_tiles(pmr_stream_t s, const pmr_fe_tiles_params *p);
 int pmr_launch_fe_dcfix(pmr_stream_t s, const pmr_fe_fix_params *p);
+/* both of the above in one launch (one wave per tile): carries, then the whole block's correction in place */
+int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q);
 int pmr_launch_fe_hist(pmr_stream_t s, const void *old_hist, const void *x, unsigned n_in, void *new_hist,
                        unsigned hcap);
 

@@ -76,6 +76,7 @@ def test_device_resident_variant_and_capacity_errors():
     d = chain.PmrDsd()
     dx = torch.from_numpy(x.view(np.float32).copy()).cuda()
     dp = torch.zeros(d.max_out, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()        # torch's fill runs on its own stream; the handle's stream is non-blocking
     nz = d.process_block_device(dx.data_ptr(), n, dp.data_ptr(), None, d.max_out)
     d.synchronize()
     assert nz == ref["n_out"]

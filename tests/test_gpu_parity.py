@@ -151,11 +151,13 @@ def test_full_size_split_invariance_and_known_answer():
     S1, S2 = g1.max_frames, g2.max_frames
     pcm1 = torch.zeros((M, S1), dtype=torch.int16, device="cuda")
     au1 = torch.zeros((M, S1), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()        # torch fills on ITS stream; the chain's streams are non-blocking (no implicit ordering)
     ns1 = g1.process_block_device(iq.data_ptr(), n, d_pcm=pcm1.data_ptr(), d_audio=au1.data_ptr(), stride=S1)
     g1.synchronize()
     parts = []
     for b in range(16):
         pcm2 = torch.zeros((M, S2), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
         ns = g2.process_block_device(iq.data_ptr() + b * (n // 16) * 8, n // 16, d_pcm=pcm2.data_ptr(), stride=S2)
         g2.synchronize()
         parts.append(pcm2[:, :ns].cpu())
