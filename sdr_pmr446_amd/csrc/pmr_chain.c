@@ -31,12 +31,12 @@
 typedef struct { float re, im; } cfl;
 
 enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
-       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_CHANNELIZE_SMALL, K_FE_L2, K_CT_FIR, K_CT_DC, K_CT_GOERTZEL, K_COUNT };
+       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_CHANNELIZE_SMALL, K_FE_L2, K_CT_FIR, K_CT_DC, K_CT_GOERTZEL, K_FE_TILEFIX, K_COUNT };
 static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
                                         "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
                                         "k_fir_tm<lp>", "k_frontend", "k_fe_tiles", "k_fe_dcfix", "k_fe_hist",
                                         "k_channelize_small", "k_frontend<level2>", "k_fir_tm<ctcss_lp>",
-                                        "k_ct_dc_*", "k_ct_goertzel+final" };
+                                        "k_ct_dc_*", "k_ct_goertzel+final", "k_fe_tilefix" };
 
 typedef struct { hipEvent_t a, b; int slot; } prof_pending;
 
@@ -806,7 +806,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
         LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
     } else {
         /* carries and the whole block's correction in one launch, one wave per tile */
-        LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tilefix(q->stream_fe, &t, &f, Q));
+        LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream_fe, &t, &f, Q));
     }
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
