@@ -752,14 +752,15 @@ __global__ __launch_bounds__(256) void k_fe_dcfix(pmr_fe_fix_params p)
 // place.  q' is simply the tile-local decimated index here, so the 32-bit division per sample of k_fe_dcfix is gone, and
 // the consumer (channelizer) no longer has to apply the carry while staging.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_fe_fix_params f, unsigned n_q /*decimated samples of the block*/)
+__global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_fe_fix_params f, unsigned n_q /*decimated samples of the block*/,
+                                                    int ablate /*timing experiments: 1 no carry sum, 2 no data pass*/)
 {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned c = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (c >= t.ntiles) return;
     const cf *pa = (const cf *)t.probeA, *pb = (const cf *)t.probeB;
     // ---- V_c exactly as k_fe_tiles computes it, the K-term sum spread over the lanes ----
-    const unsigned kmax = c < t.K ? c : t.K;
+    const unsigned kmax = (ablate & 1) ? 0u : (c < t.K ? c : t.K);
     float ar = 0.f, ai = 0.f;
     for (unsigned k = 1 + lane; k <= kmax; k += 64u) {
         const cf A = pa[c - k], B = pb[c - k];
@@ -789,21 +790,36 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
     const unsigned long long qa = (unsigned long long)c * f.TQ;
     unsigned long long qb = qa + f.TQ;
     if (qb > n_q) qb = n_q;
-    if (qa >= qb) return;
+    if (qa >= qb || (ablate & 2)) return;
     const unsigned long long sa = qa << 24, sb = qb << 24;
     unsigned long long ja = sa <= f.phi0 ? 0ull : ceil_div_u64(sa - f.phi0, f.step);
     unsigned long long jb = sb <= f.phi0 ? 0ull : ceil_div_u64(sb - f.phi0, f.step);
     if (jb > f.ny) jb = f.ny;
     cf *xr = (cf *)f.xr;
-    for (unsigned long long j = ja + lane; j < jb; j += 64u) {
-        const unsigned long long ph = (unsigned long long)f.phi0 + j * f.step;
-        const unsigned ql = (unsigned)((ph >> 24) - qa) + f.HhQ;
-        const float g = f.Kgain * f.GA[(unsigned)(ph & 0xffffffu) >> 16] * (f.T1[ql >> 5] * f.T2[ql & 31]);
-        cf *o = xr + ((f.pos0 + j) & f.mask);
-        cf v = *o;
-        v.x = fmaf(-Vr, g, v.x);
-        v.y = fmaf(-Vi, g, v.y);
-        *o = v;
+    // batches of four outputs per lane: every load of a batch (ring sample + three table look-ups) is in flight before
+    // the first is consumed -- one output per iteration would pay the full load latency ~5 times in a row
+    for (unsigned long long jbase = ja + lane; jbase < jb; jbase += 256u) {
+        cf v[4]; float g[4]; cf *o[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned long long j = jbase + 64u * u;
+            const bool ok = j < jb;
+            const unsigned long long ph = (unsigned long long)f.phi0 + (ok ? j : ja) * f.step;
+            const unsigned ql = (unsigned)((ph >> 24) - qa) + f.HhQ;
+            o[u] = xr + ((f.pos0 + (ok ? j : ja)) & f.mask);
+            v[u] = *o[u];
+            g[u] = f.GA[(unsigned)(ph & 0xffffffu) >> 16] * (f.T1[ql >> 5] * f.T2[ql & 31]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (jbase + 64u * u < jb) {
+                const float gg = f.Kgain * g[u];
+                cf w = v[u];
+                w.x = fmaf(-Vr, gg, w.x);
+                w.y = fmaf(-Vi, gg, w.y);
+                *o[u] = w;
+            }
+        }
     }
 }
 
@@ -914,7 +930,8 @@ extern "C" int pmr_launch_fe_dcfix(pmr_stream_t s, const pmr_fe_fix_params *p)
 extern "C" int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q)
 {
     if (!t->ntiles) return 0;
-    hipLaunchKernelGGL(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, *t, *f, n_q);
+    const char *e = getenv("PMR_TILEFIX_ABLATE");
+    hipLaunchKernelGGL(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, *t, *f, n_q, e ? atoi(e) : 0);
     return (int)hipGetLastError();
 }
 
