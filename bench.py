@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--log2-block", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one "
+                                                          "GPU to exercise the N > 1 code path on a 1-GPU box")
     ap.add_argument("--host-io", action="store_true",
                     help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
@@ -127,9 +129,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.dist_backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()          # self-test only: ranks may share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = multigpu.init_dist("nccl", dev)
+    dist = multigpu.init_dist(args.dist_backend, dev)
 
     fs, M, lb = WORKLOADS[args.workload]
     lb = args.log2_block if args.log2_block is not None else lb
@@ -159,7 +163,7 @@ def main():
         ch.synchronize()
         return n
 
-    dt, frames = multigpu.timed_region(run, dist, torch.cuda.synchronize, dev)
+    dt, frames = multigpu.timed_region(run, dist, torch.cuda.synchronize, dev if args.dist_backend == "nccl" else None)
     ch.profile_enable(0)
     prof_roof = ch.profile()
     breakdown_steps = 0

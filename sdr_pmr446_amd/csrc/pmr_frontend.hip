@@ -471,14 +471,21 @@ static __device__ __forceinline__ void hb_stage_pp(const cf *__restrict__ src, c
 }
 
 template <int MODE, int N3, int TAIL>
-__global__ __launch_bounds__(256, 4) void k_frontend_fast(pmr_fe_params p)
+__global__ __launch_bounds__(256, MODE == FE_L2 ? 4 : 5) void k_frontend_fast(pmr_fe_params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256, SPT = 16, N0 = NT * SPT, LPT = N0 / 2 / NT;
     constexpr int H = N3 + 2 * TAIL;
     constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;         // z1 (2048 samples, layout L(8)) fills [0, R1_OFF) of the tile
+    // LDS budget.  The raw tile never sits in LDS as a whole: it passes through in two halves (2048 samples each, layout
+    // L(16)) on its way into the threads' registers, in the area z1 will occupy afterwards.  What stays is z1 (R0, 2304
+    // slots) + z2 (R1, 1280 slots) + scratch = 29.5 KB, i.e. FIVE tiles per CU instead of the four a whole raw tile
+    // (34.8 KB) allows -- this kernel's throughput is proportional to the tiles in flight.  (Level 2 keeps the whole-tile
+    // staging: its input is 1/8 of the data.)
+    constexpr int HALF = N0 / 2;
+    constexpr int BODY = MODE == FE_L2 ? (N0 + N0 / SPT) : (R1_OFF + (N0 / 4) + (N0 / 4) / 4);   // R0 + R1
     cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
-    cf *wagg = buf + (N0 + N0 / SPT);
+    cf *wagg = buf + BODY;
     cf *bnd = wagg + NT / 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -496,6 +503,7 @@ __global__ __launch_bounds__(256, 4) void k_frontend_fast(pmr_fe_params p)
     const unsigned long long qa = (unsigned long long)c * p.TQ;
     unsigned long long ja = 0, jb = 0;
     float bk0[14], bk1[14];
+    const float *b0p = nullptr, *b1p = nullptr;
     if constexpr (MODE != FE_L1) {
         unsigned long long qb = qa + p.TQ;
         if (qb > p.Q) qb = p.Q;
@@ -507,10 +515,8 @@ __global__ __launch_bounds__(256, 4) void k_frontend_fast(pmr_fe_params p)
         }
         const unsigned long long j0 = ja + tid, j1 = j0 + NT;
         const unsigned long long ph0 = (unsigned long long)p.phi0 + j0 * p.step, ph1 = ph0 + (unsigned long long)NT * p.step;
-        const float *b0p = p.arb_bank + (j0 < jb ? (unsigned)(ph0 & 0xffffffu) >> 16 : 0u) * 14u;
-        const float *b1p = p.arb_bank + (j1 < jb ? (unsigned)(ph1 & 0xffffffu) >> 16 : 0u) * 14u;
-#pragma unroll
-        for (int k = 0; k < 14; k++) { bk0[k] = b0p[k]; bk1[k] = b1p[k]; }
+        b0p = p.arb_bank + (j0 < jb ? (unsigned)(ph0 & 0xffffffu) >> 16 : 0u) * 14u;
+        b1p = p.arb_bank + (j1 < jb ? (unsigned)(ph1 & 0xffffffu) >> 16 : 0u) * 14u;
     }
     float lp = 0.f, l15 = 0.f, l31 = 0.f;
     if constexpr (MODE != FE_L2) {
@@ -538,37 +544,59 @@ __global__ __launch_bounds__(256, 4) void k_frontend_fast(pmr_fe_params p)
             }
             buf[lidx<SPT>(i)] = v;
         }
+    }
+    cf xs[SPT];
+    if constexpr (MODE == FE_L2) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPT; j++) xs[j] = buf[(SPT + 1) * tid + j];
     } else {
         const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
+        float4 v[LPT];
         if (fast) {
             const float4 *__restrict__ src = reinterpret_cast<const float4 *>(x + b0);
-            float4 v[LPT];
 #pragma unroll
-            for (int i = 0; i < LPT; i++) v[i] = src[tid + NT * i];
+            for (int i = 0; i < LPT; i++) v[i] = src[tid + NT * i];       // all eight loads in flight before the first LDS write
+        }
 #pragma unroll
-            for (int i = 0; i < LPT; i++) {
-                cf *d = buf + lidx<SPT>(2 * (tid + NT * i));
-                d[0] = cfm(v[i].x, v[i].y);
-                d[1] = cfm(v[i].z, v[i].w);
-            }
-        } else {
+        for (int hf = 0; hf < 2; hf++) {
+            if (fast) {
+#pragma unroll
+                for (int i = 0; i < LPT / 2; i++) {
+                    cf *d = buf + lidx<SPT>(2 * (tid + NT * i));          // local index inside the half
+                    const float4 w = v[hf * (LPT / 2) + i];
+                    d[0] = cfm(w.x, w.y);
+                    d[1] = cfm(w.z, w.w);
+                }
+            } else {
 #pragma unroll 4
-            for (int i = tid; i < N0; i += NT) {
-                const long b = b0 + i;
-                cf v = cfm(0.f, 0.f);
-                if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) v = hist[hi]; }
-                else if (b < (long)p.n_in) v = x[b];
-                buf[lidx<SPT>(i)] = v;
+                for (int i = tid; i < HALF; i += NT) {
+                    const long b = b0 + hf * HALF + i;
+                    cf w = cfm(0.f, 0.f);
+                    if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) w = hist[hi]; }
+                    else if (b < (long)p.n_in) w = x[b];
+                    buf[lidx<SPT>(i)] = w;
+                }
             }
+            __syncthreads();
+            if ((tid >> 7) == hf) {                                       // threads 0..127 own the first half, 128..255 the second
+#pragma unroll
+                for (int j = 0; j < SPT; j++) xs[j] = buf[(SPT + 1) * (tid & 127) + j];
+            }
+            if (hf == 0) __syncthreads();                                 // the second half overwrites the staging area
         }
     }
-    __syncthreads();
+
+    // polyphase taps of the (at most two) resampler outputs this thread owns: requested now that the raw tile has left
+    // the registers it was loaded into, consumed in phase D -- phases B and C hide the latency
+    if constexpr (MODE != FE_L1) {
+#pragma unroll
+        for (int k = 0; k < 14; k++) { bk0[k] = b0p[k]; bk1[k] = b1p[k]; }
+    }
 
     // ---- phase B: dc blocker from zero state + first (six-tap) stage from registers ----
     {
-        cf xs[SPT], yb[SPT];
-#pragma unroll
-        for (int j = 0; j < SPT; j++) xs[j] = buf[(SPT + 1) * tid + j];
+        cf yb[SPT];
         if constexpr (MODE == FE_L2) {
 #pragma unroll
             for (int j = 0; j < SPT; j++) yb[j] = xs[j];
@@ -857,7 +885,8 @@ template <int MODE, int N3, int TAIL>
 static int launch_frontend_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
 {
     const size_t n0 = 4096;
-    size_t lds = (FE_PAD + n0 + n0 / 16 + 32 + 10 * (256 / 64 + 1)) * sizeof(cf);
+    const size_t body = MODE == FE_L2 ? n0 + n0 / 16 : (n0 / 2 + n0 / 16) + (n0 / 4 + n0 / 16);   /* whole raw tile | R0 + R1 */
+    size_t lds = (FE_PAD + body + 11 * (256 / 64)) * sizeof(cf);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend_fast<MODE, N3, TAIL>),
