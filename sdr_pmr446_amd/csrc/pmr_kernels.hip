@@ -186,6 +186,42 @@ static __host__ __device__ inline unsigned chan_ft(unsigned M, unsigned ns)
     return want < cap ? want : cap;
 }
 
+// Polyphase bank for one tile, thread-per-channel with a sliding window over the tile's F frames (P taps per branch).
+// Same products, same oldest-first accumulation order as the item-per-thread loop in k_channelize.
+template <int F, int P>
+static __device__ __forceinline__ void pfb_rows(const pmr_chan_params &q, unsigned log2M, cf *Xs, long long fbase,
+                                                unsigned nfl /*frames to store*/, unsigned tid)
+{
+    const unsigned M = q.M, nco_mask = q.nco_period - 1;
+    const cf *__restrict__ xr = (const cf *)q.xr;
+    const cf *__restrict__ nco_cs = (const cf *)q.nco_cs;
+    for (unsigned c = tid; c < M; c += 256) {
+        float h[P];
+#pragma unroll
+        for (int k = 0; k < P; k++) h[k] = q.taps_t[k * M + c];
+        float ar[F], ai[F];
+#pragma unroll
+        for (int f = 0; f < F; f++) { ar[f] = 0.f; ai[f] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < F + P - 1; r++) {
+            const long long a = (fbase + r) * (long long)M + c;       // absolute resampled sample index
+            const cf x = xr[(unsigned long long)a & q.xr_mask];
+            const cf cs = nco_cs[(unsigned)a & nco_mask];
+            const float xmr = fmaf(x.x, cs.x, x.y * cs.y);            // x * conj(e^{j theta})
+            const float xmi = fmaf(x.y, cs.x, -(x.x * cs.y));
+#pragma unroll
+            for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < F - 1 ? r : F - 1); f++) {
+                ar[f] = fmaf(h[r - f], xmr, ar[f]);
+                ai[f] = fmaf(h[r - f], xmi, ai[f]);
+            }
+        }
+        const unsigned rc = __brev(c) >> (32 - log2M);
+#pragma unroll
+        for (int f = 0; f < F; f++)
+            if ((unsigned)f < nfl) Xs[f * M + rc] = cf_make(ar[f], ai[f]);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned log2M)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -204,6 +240,13 @@ __global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned 
 
     // phase 1: X[f][c] = sum_k taps_t[k][c] * xm[(F + f - p + k) * M + c],  local f = 0 is frame t0-1
     const long long fbase = (long long)q.frame0 + t0 - (long long)p;   // absolute frame of (f = 0, k = 0)
+    if (p == 26 && FT <= 16) {
+        // sliding window: a thread owns one channel and ALL frames of the tile, so a resampled sample is loaded (and
+        // NCO-mixed) once per tile instead of once per tap -- (F + 25) loads for F frames instead of 3 * 26 * F
+        if (FT > 8)      pfb_rows<16, 26>(q, log2M, Xs, fbase, nf + 1, tid);
+        else if (FT > 4) pfb_rows<8, 26>(q, log2M, Xs, fbase, nf + 1, tid);
+        else             pfb_rows<4, 26>(q, log2M, Xs, fbase, nf + 1, tid);
+    } else {
     const unsigned items = (nf + 1) * M;
     for (unsigned w = tid; w < items; w += 256) {
         const unsigned f = w >> log2M, c = w & (M - 1);
@@ -220,6 +263,7 @@ __global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned 
         }
         const unsigned rc = __brev(c) >> (32 - log2M);
         Xs[f * M + rc] = cf_make(ar, ai);
+    }
     }
     __syncthreads();
 
