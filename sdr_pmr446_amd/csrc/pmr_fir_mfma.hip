@@ -1,5 +1,6 @@
 // pmr_fir_mfma.hip -- the audio FIR (reference src/sdr_pmr446.c:882-904: 377-tap CTCSS high-pass, gain, 50 us
-// de-emphasis, PCM hand-off) for M = 16 on the gfx950 MATRIX pipe.
+// de-emphasis, PCM hand-off) on the gfx950 MATRIX pipe, 16 channels per workgroup (M = 16: the whole row; larger M:
+// blockIdx.y walks the groups of 16 channels).
 //
 // Why MFMA here although the chain is "streaming DSP": with all 16 channels demodulated this stage is the FLOP
 // hot spot at small decimation ratios (383 MACs per audio sample = 32 MACs per raw input sample at cfg2, 2/3 of all
@@ -42,9 +43,14 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
                                                       long long row0, unsigned ns, const float *__restrict__ taps_c,
                                                       unsigned ntaps, float *__restrict__ out_tm,
                                                       int16_t *__restrict__ pcm, float *__restrict__ audio,
-                                                      unsigned stride, int ablate)
+                                                      unsigned stride, int ablate, unsigned M /*row width, multiple of 16*/)
 {
-    constexpr int M = 16;
+    // blockIdx.y selects a group of 16 channels: the tile is 16 channels wide whatever M is
+    const unsigned cg0 = blockIdx.y * 16u;
+    in += cg0;
+    if (out_tm) out_tm += cg0;
+    if (pcm) pcm += (size_t)cg0 * stride;
+    if (audio) audio += (size_t)cg0 * stride;
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
     float *Qs = reinterpret_cast<float *>(smem_m);                   // [ntaps + 2*PMR_TAP_PAD] padded taps
     const unsigned qlen = ntaps + 2 * PMR_TAP_PAD;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
     }
 }
 
-extern "C" int pmr_fir_mfma_supported(unsigned M, unsigned ntaps) { return M == 16 && ntaps >= 2 && ntaps <= 1024; }
+extern "C" int pmr_fir_mfma_supported(unsigned M, unsigned ntaps) { return M >= 16 && M % 16 == 0 && M <= 16 * 65535u && ntaps >= 2 && ntaps <= 1024; }
 
 extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
                                    unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm,
@@ -177,11 +183,11 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
     const int ablate = []{ const char *e = getenv("PMR_FIR_ABLATE"); return e ? atoi(e) : 0; }();
     if (glb) {
         const size_t lds_g = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float);
-        hipLaunchKernelGGL(k_fir_mfma16<true>, dim3((ns + FM_TILE - 1) / FM_TILE), dim3(FM_NT), lds_g, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate);
+        hipLaunchKernelGGL(k_fir_mfma16<true>, dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds_g, (hipStream_t)s, in,
+                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(k_fir_mfma16<false>, dim3((ns + FM_TILE - 1) / FM_TILE), dim3(FM_NT), lds, (hipStream_t)s, in,
-                       (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate);
+    hipLaunchKernelGGL(k_fir_mfma16<false>, dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
+                       (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
     return (int)hipGetLastError();
 }
