@@ -38,8 +38,10 @@ static __device__ __forceinline__ int16_t pcm16(float y)
     return (int16_t)s;                            // truncation toward zero (src/dsd_in.c:174), saturated
 }
 
-template <bool GLB>
-__global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ in, unsigned long long row_mask,
+#define FM_PRE 11                                /* float4 prefetch registers per thread: windows up to 704 rows */
+
+template <bool GLB, int TPW /*tiles per workgroup: 2 = the second tile's window is prefetched under the first tile's MFMAs*/>
+__global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict__ in, unsigned long long row_mask,
                                                       long long row0, unsigned ns, const float *__restrict__ taps_c,
                                                       unsigned ntaps, float *__restrict__ out_tm,
                                                       int16_t *__restrict__ pcm, float *__restrict__ audio,
@@ -56,27 +58,47 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
     const unsigned qlen = ntaps + 2 * PMR_TAP_PAD;
     float *Xs = Qs + ((qlen + 31) & ~31u);                           // rows: r at r*16 + 16*(r>>5)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long T0 = (long)blockIdx.x * FM_TILE;                      // first frame of this workgroup (relative to row0)
     const unsigned nrows = FM_TILE + ntaps + 31;                     // frames T0-(ntaps-1) .. T0+255 (+32: kappa padded to 32)
-
-    for (unsigned i = tid; i < qlen; i += FM_NT) Qs[i] = taps_c[i];
-    // GLB: no sample window in LDS at all -- the B operand comes straight from the time-major ring through the vector L1
-    // (a wave-instruction touches four 64-byte rows).  With ~2 KB of LDS and < 128 registers a workgroup of this kernel
-    // fits NEXT TO the front end's tiles on a CU (they leave 16 KB LDS and 128 VGPRs per SIMD free), so the otherwise idle
-    // matrix pipe works under the front end instead of after it.
-    for (unsigned u = tid; u < (GLB ? 0u : nrows * 4); u += FM_NT) {
-        const unsigned r = u >> 2, q4 = (u & 3) * 4;
-        const long t = T0 - (long)(ntaps - 1) + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < (long)ns && !(ablate & 1)) v = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + q4);
-        *reinterpret_cast<float4 *>(Xs + r * 16 + 16 * (r >> 5) + q4) = v;
-    }
-    __syncthreads();
-
     const int j = lane & 31, kk = lane >> 5, ch = j & 15, blk = j >> 4;
     const int Tj = 64 * wave + 32 * blk;                             // frame offset of this column inside the tile
-    if (T0 + 64 * wave >= (long)ns) return;                          // whole wave beyond the block (after the only barrier)
 
+    for (unsigned i = tid; i < qlen; i += FM_NT) Qs[i] = taps_c[i];
+
+    // window of the tile starting at frame T0: global -> registers (issue), registers -> LDS (commit)
+    float4 pre[FM_PRE];
+    auto issue = [&](long T0) {
+#pragma unroll
+        for (int i = 0; i < FM_PRE; i++) {
+            const unsigned u = tid + FM_NT * i, r = u >> 2, q4 = (u & 3) * 4;
+            const long t = T0 - (long)(ntaps - 1) + r;
+            pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < nrows * 4 && t < (long)ns && !(ablate & 1))
+                pre[i] = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + q4);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < FM_PRE; i++) {
+            const unsigned u = tid + FM_NT * i, r = u >> 2, q4 = (u & 3) * 4;
+            if (u < nrows * 4) *reinterpret_cast<float4 *>(Xs + r * 16 + 16 * (r >> 5) + q4) = pre[i];
+        }
+    };
+    // GLB: no sample window in LDS at all -- the B operand comes straight from the time-major ring through the vector L1
+    // (a wave-instruction touches four 64-byte rows).  With ~2 KB of LDS and < 128 registers a workgroup of this kernel
+    // fits NEXT TO the front end's tiles on a CU.
+    const long tile0 = (long)blockIdx.x * TPW;
+    if constexpr (!GLB) { issue(tile0 * FM_TILE); commit(); }
+    __syncthreads();
+
+#pragma unroll
+    for (int it = 0; it < TPW; it++) {
+    const long T0 = (tile0 + it) * FM_TILE;                          // first frame of this tile (relative to row0)
+    if (T0 >= (long)ns) break;                                       // uniform
+    const bool more = !GLB && it + 1 < TPW && T0 + FM_TILE < (long)ns;
+    if (more) issue(T0 + FM_TILE);                                   // in flight during this tile's MFMAs
+    const bool active = T0 + 64 * wave < (long)ns;                   // else: whole wave beyond the block
+
+    if (active) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -117,12 +139,12 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
 #undef FM_MMA
 
     // D layout: lane holds column j; register g*4+q is row 8g + 4*kk + q  ->  4 consecutive frames per register group
-    if (ablate & 4) { if (acc[0] == 123.456f) pcm[0] = 1; return; }
+    if (!(ablate & 4)) {
     const bool vec_ok = ((stride & 3) == 0);
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const long t = T0 + Tj + 8 * g + 4 * kk;                     // frame of register 4g (relative to row0)
-        const float y0 = acc[4 * g], y1 = acc[4 * g + 1], y2 = acc[4 * g + 2], y3 = acc[4 * g + 3];
+    for (int g4 = 0; g4 < 4; g4++) {
+        const long t = T0 + Tj + 8 * g4 + 4 * kk;                    // frame of register 4g (relative to row0)
+        const float y0 = acc[4 * g4], y1 = acc[4 * g4 + 1], y2 = acc[4 * g4 + 2], y3 = acc[4 * g4 + 3];
         if (t + 3 < (long)ns && vec_ok) {
             if (pcm && ((reinterpret_cast<uintptr_t>(pcm) & 7) == 0)) {
                 uint2 w;
@@ -156,9 +178,20 @@ __global__ __launch_bounds__(FM_NT) void k_fir_mfma16(const float *__restrict__ 
                 if (t + q < (long)ns) out_tm[((unsigned long long)(row0 + t + q) & row_mask) * M + ch] = yy[q];
         }
     }
+    } else if (acc[0] == 123.456f) pcm[0] = 1;
+    }   // active
+    if (more) {                                                      // uniform
+        __syncthreads();                                             // every wave is done with this tile's window
+        commit();
+        __syncthreads();
+    }
+    }   // tiles
 }
 
-extern "C" int pmr_fir_mfma_supported(unsigned M, unsigned ntaps) { return M >= 16 && M % 16 == 0 && M <= 16 * 65535u && ntaps >= 2 && ntaps <= 1024; }
+extern "C" int pmr_fir_mfma_supported(unsigned M, unsigned ntaps)
+{
+    return M >= 16 && M % 16 == 0 && M <= 16 * 65535u && ntaps >= 2 && (FM_TILE + ntaps + 31) * 4 <= FM_PRE * FM_NT;
+}
 
 extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
                                    unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm,
@@ -171,7 +204,9 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
                        ((size_t)nrows * 16 + 16 * ((nrows >> 5) + 1)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -183,11 +218,21 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
     const int ablate = []{ const char *e = getenv("PMR_FIR_ABLATE"); return e ? atoi(e) : 0; }();
     if (glb) {
         const size_t lds_g = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float);
-        hipLaunchKernelGGL(k_fir_mfma16<true>, dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds_g, (hipStream_t)s, in,
+        hipLaunchKernelGGL((k_fir_mfma16<true, 1>), dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds_g, (hipStream_t)s, in,
                            (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
         return (int)hipGetLastError();
     }
-    hipLaunchKernelGGL(k_fir_mfma16<false>, dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
+    const unsigned tiles = (ns + FM_TILE - 1) / FM_TILE;
+    static int tpw = -1;                          /* PMR_FIR_TPW=1: one tile per workgroup, no window prefetch */
+    if (tpw < 0) { const char *e = getenv("PMR_FIR_TPW"); tpw = e ? atoi(e) : 2; }
+    /* two tiles per workgroup only while that still leaves enough workgroups to fill the chip (3 per CU fit) */
+    if (tpw == 2 && nrows * 4 <= FM_PRE * FM_NT && (size_t)((tiles + 1) / 2) * (M / 16) >= 384) {
+        hipLaunchKernelGGL((k_fir_mfma16<false, 2>), dim3((tiles + 1) / 2, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
+                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+        return (int)hipGetLastError();
+    }
+    if (nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_fir_mfma16<false, 1>), dim3(tiles, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
                        (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
     return (int)hipGetLastError();
 }

@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void k_arb(const cf *__restrict__ dec, cf *__r
 // that a block still yields ~1000 workgroups (the work per frame is small; parallelism is what matters)
 static __host__ __device__ inline unsigned chan_ft(unsigned M, unsigned ns)
 {
-    unsigned cap = 8192u / M; if (cap < 4u) cap = 4u;
-    unsigned want = ns / 1024u + 2u;
+    unsigned cap = 4096u / M; if (cap < 4u) cap = 4u;     // 32 KB of LDS per tile
+    unsigned want = M >= 256u ? ns / 1024u + 2u : cap;     // many channels: small tiles keep ~1000 workgroups in the grid
     return want < cap ? want : cap;
 }
 
@@ -195,7 +195,11 @@ static __device__ __forceinline__ void pfb_rows(const pmr_chan_params &q, unsign
     const unsigned M = q.M, nco_mask = q.nco_period - 1;
     const cf *__restrict__ xr = (const cf *)q.xr;
     const cf *__restrict__ nco_cs = (const cf *)q.nco_cs;
-    for (unsigned c = tid; c < M; c += 256) {
+    // work item = (channel c, group g of F consecutive frames); M >= 256: one group, a thread walks channels;
+    // small M: the 256 threads are 256/M groups side by side (16 lanes = one 128-byte row at M = 16)
+    const unsigned G = (nfl + F - 1) / F;
+    for (unsigned w = tid; w < M * G; w += 256) {
+        const unsigned c = w & (M - 1), f0 = (w >> log2M) * F;
         float h[P];
 #pragma unroll
         for (int k = 0; k < P; k++) h[k] = q.taps_t[k * M + c];
@@ -204,7 +208,7 @@ static __device__ __forceinline__ void pfb_rows(const pmr_chan_params &q, unsign
         for (int f = 0; f < F; f++) { ar[f] = 0.f; ai[f] = 0.f; }
 #pragma unroll
         for (int r = 0; r < F + P - 1; r++) {
-            const long long a = (fbase + r) * (long long)M + c;       // absolute resampled sample index
+            const long long a = (fbase + f0 + r) * (long long)M + c;  // absolute resampled sample index
             const cf x = xr[(unsigned long long)a & q.xr_mask];
             const cf cs = nco_cs[(unsigned)a & nco_mask];
             const float xmr = fmaf(x.x, cs.x, x.y * cs.y);            // x * conj(e^{j theta})
@@ -218,7 +222,7 @@ static __device__ __forceinline__ void pfb_rows(const pmr_chan_params &q, unsign
         const unsigned rc = __brev(c) >> (32 - log2M);
 #pragma unroll
         for (int f = 0; f < F; f++)
-            if ((unsigned)f < nfl) Xs[f * M + rc] = cf_make(ar[f], ai[f]);
+            if (f0 + f < nfl) Xs[(f0 + f) * M + rc] = cf_make(ar[f], ai[f]);
     }
 }
 
@@ -240,9 +244,9 @@ __global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned 
 
     // phase 1: X[f][c] = sum_k taps_t[k][c] * xm[(F + f - p + k) * M + c],  local f = 0 is frame t0-1
     const long long fbase = (long long)q.frame0 + t0 - (long long)p;   // absolute frame of (f = 0, k = 0)
-    if (p == 26 && FT <= 16) {
-        // sliding window: a thread owns one channel and ALL frames of the tile, so a resampled sample is loaded (and
-        // NCO-mixed) once per tile instead of once per tap -- (F + 25) loads for F frames instead of 3 * 26 * F
+    if (p == 26) {
+        // sliding window: a thread owns one channel and F consecutive frames, so a resampled sample is loaded (and
+        // NCO-mixed) once per group instead of once per tap -- (F + 25) loads for F frames instead of 3 * 26 * F
         if (FT > 8)      pfb_rows<16, 26>(q, log2M, Xs, fbase, nf + 1, tid);
         else if (FT > 4) pfb_rows<8, 26>(q, log2M, Xs, fbase, nf + 1, tid);
         else             pfb_rows<4, 26>(q, log2M, Xs, fbase, nf + 1, tid);
