@@ -95,6 +95,7 @@ struct pmr_chain_s {
     int fe2_T_own, fe2_Hh, fe2_HhQ, fe2_TQ;   /* level-2 tile geometry, in level-1 output samples      */
     float fe1_K;                     /* alpha * prod G_e (e < s1): dc-carry gain at the level-1 output */
     cfl *d_fe_ring1; uint64_t ring1_mask;
+    uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     unsigned fe_max_tiles;
 
@@ -410,6 +411,21 @@ static int fe_init(pmr_chain q)
         if ((rc = dev_alloc(q, (void **)&q->d_fe_V[i], (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeL, sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_fe_probeE, sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_tile_j, (size_t)q->fe_max_tiles * 2 * sizeof(uint64_t)))) return rc;
+    {
+        /* carry look-back length and the powers of rho = lambda^T_own it needs */
+        const double rho = pow(lam, (double)T_own);
+        double kterms = rho > 0.0 && rho < 1.0 ? ceil(log(1e-12) / log(rho)) : 1.0;
+        if (kterms < 1.0) kterms = 1.0;
+        if (kterms > 4096.0) kterms = 4096.0;
+        q->fe_K = (unsigned)kterms;
+        float *rp = (float *)calloc(q->fe_K + 2, sizeof(float));
+        if (!rp) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+        for (unsigned k = 0; k <= q->fe_K + 1; k++) rp[k] = (float)pow(rho, (double)k);
+        rc = dev_upload(q, &q->d_fe_rho_pow, rp, q->fe_K + 2);
+        free(rp);
+        if (rc) return rc;
+    }
     q->fe_sel = 0;
     q->fe_on = 1;
     return PMR_OK;
@@ -610,7 +626,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     if (q->stream) hipStreamDestroy(q->stream);
@@ -769,6 +785,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     memset(&p, 0, sizeof(p));
     p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr; p.out_pos0 = q->xr_abs; p.out_mask = q->xr_mask;
     p.probeA = q->d_fe_probeA; p.probeB = q->d_fe_probeB; p.probeL = q->d_fe_probeL; p.probeE = q->d_fe_probeE;
+    p.tile_j = q->d_fe_tile_j;
     p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
     p.n_in = n_in; p.ny = ny; p.Q = Q; p.phi0 = q->arb_phase; p.step = d->arb_step;
     p.h = (int)h; p.T_own = q->fe_T_own; p.Hh = q->fe_Hh; p.HhQ = q->fe_HhQ; p.TQ = q->fe_TQ;
@@ -796,6 +813,8 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     t.ntiles = ntiles; t.K = (unsigned)kterms; t.c_end = c_end;
     t.rho = (float)rho; t.lamHh = (float)pow(lam, (double)q->fe_Hh); t.inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
     t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
+    if (t.K > q->fe_K) t.K = q->fe_K;
+    t.rho_pow = q->d_fe_rho_pow; t.tile_j = q->d_fe_tile_j;
     pmr_fe_fix_params f;
     memset(&f, 0, sizeof(f));
     f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[q->n_calls % PIPE_DEPTH]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(NT, (NT == 512 && SPT == 8) ? FE_WAVES_512 : (NT ==
             jb = sb <= p.phi0 ? 0ull : ceil_div_u64(sb - p.phi0, p.step);
             if (jb > p.ny) jb = p.ny;
         }
+        if (p.tile_j && tid == 0 && MODE != FE_L1) { ((unsigned long long *)p.tile_j)[2 * c] = ja; ((unsigned long long *)p.tile_j)[2 * c + 1] = jb; }
     }
     float bk0[14];
     {
@@ -513,6 +514,7 @@ __global__ __launch_bounds__(256, MODE == FE_L2 ? 4 : 5) void k_frontend_fast(pm
             jb = sb <= p.phi0 ? 0ull : ceil_div_u64(sb - p.phi0, p.step);
             if (jb > p.ny) jb = p.ny;
         }
+        if (p.tile_j && tid == 0) { ((unsigned long long *)p.tile_j)[2 * c] = ja; ((unsigned long long *)p.tile_j)[2 * c + 1] = jb; }
         const unsigned long long j0 = ja + tid, j1 = j0 + NT;
         const unsigned long long ph0 = (unsigned long long)p.phi0 + j0 * p.step, ph1 = ph0 + (unsigned long long)NT * p.step;
         b0p = p.arb_bank + (j0 < jb ? (unsigned)(ph0 & 0xffffffu) >> 16 : 0u) * 14u;
@@ -792,7 +794,7 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
     float ar = 0.f, ai = 0.f;
     for (unsigned k = 1 + lane; k <= kmax; k += 64u) {
         const cf A = pa[c - k], B = pb[c - k];
-        const float pw = powf(t.rho, (float)(k - 1));
+        const float pw = t.rho_pow[k - 1];                           // rho^(k-1), tabulated in double on the host
         ar = fmaf(pw, fmaf(-t.rho, A.x, B.x), ar);
         ai = fmaf(pw, fmaf(-t.rho, A.y, B.y), ai);
     }
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
         const cf vs = *(const cf *)t.v_in, pl = *(const cf *)t.probeL, a0 = pa[0];
         const float V0r = (vs.x - pl.x) * t.inv_lamL, V0i = (vs.y - pl.y) * t.inv_lamL;
         const float W0r = fmaf(t.lamHh, V0r, a0.x), W0i = fmaf(t.lamHh, V0i, a0.y);
-        const float pw = powf(t.rho, (float)kmax);
+        const float pw = t.rho_pow[kmax];
         ar = fmaf(pw, W0r, ar); ai = fmaf(pw, W0i, ai);
     }
     const cf Ac = pa[c];
@@ -814,15 +816,11 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
             *(cf *)t.v_out = cfm(fmaf(t.lamEnd, Vr, pe.x), fmaf(t.lamEnd, Vi, pe.y));
         }
     }
-    // ---- the tile's own outputs: decimated samples [c TQ, (c+1) TQ) <-> outputs [ja, jb) ----
+    // ---- the tile's own outputs [ja, jb): the range the front-end kernel published for this tile ----
+    if (ablate & 2) return;
     const unsigned long long qa = (unsigned long long)c * f.TQ;
-    unsigned long long qb = qa + f.TQ;
-    if (qb > n_q) qb = n_q;
-    if (qa >= qb || (ablate & 2)) return;
-    const unsigned long long sa = qa << 24, sb = qb << 24;
-    unsigned long long ja = sa <= f.phi0 ? 0ull : ceil_div_u64(sa - f.phi0, f.step);
-    unsigned long long jb = sb <= f.phi0 ? 0ull : ceil_div_u64(sb - f.phi0, f.step);
-    if (jb > f.ny) jb = f.ny;
+    if (qa >= n_q) return;
+    const unsigned long long ja = ((const unsigned long long *)t.tile_j)[2 * c], jb = ((const unsigned long long *)t.tile_j)[2 * c + 1];
     cf *xr = (cf *)f.xr;
     // batches of four outputs per lane: every load of a batch (ring sample + three table look-ups) is in flight before
     // the first is consumed -- one output per iteration would pay the full load latency ~5 times in a row

@@ -139,6 +139,7 @@ typedef struct {
      * of level-1 tile c1 = j / fix_TQ is subtracted at load: V[c1] * fix_K * mu^(j - c1 fix_TQ + fix_HhQ)       */
     const void *in_ring; uint64_t in_mask; int64_t in_abs0;
     const void *fixV; const float *fix_T1, *fix_T2; unsigned fix_TQ, fix_HhQ; float fix_K;
+    void *tile_j;               /* nullable [ntiles][2] u64: the tile's resampler output range [ja, jb), for k_fe_tilefix */
     void *stamps;               /* diagnostic: 8 x u64 per-phase cycle sums (PMR_FE_STAMP), else NULL  */
     int ablate;                 /* timing experiments only (PMR_FE_ABLATE): bit0 skip load, 1 dc, 2 cascade, 3 resampler */
     int m[PMR_FE_MAX_STAGES], tap_off[PMR_FE_MAX_STAGES];
@@ -154,6 +155,8 @@ typedef struct {
     void *v_out, *V;
     unsigned ntiles, K, c_end;
     float rho, lamHh, inv_lamHh, inv_lamL, lamEnd;
+    const float *rho_pow;       /* [K + 1] rho^k (k_fe_tilefix)                                       */
+    const void *tile_j;         /* [ntiles][2] u64: resampler output range of every tile, published by k_frontend* */
 } pmr_fe_tiles_params;
 
 typedef struct {
