@@ -96,6 +96,7 @@ struct pmr_chain_s {
     float fe1_K;                     /* alpha * prod G_e (e < s1): dc-carry gain at the level-1 output */
     cfl *d_fe_ring1; uint64_t ring1_mask;
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
+    int tilefix_on_backend, pend_tilefix; pmr_fe_tiles_params pend_t; pmr_fe_fix_params pend_f; unsigned pend_Q;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     unsigned fe_max_tiles;
 
@@ -405,13 +406,15 @@ static int fe_init(pmr_chain q)
         if ((rc = dev_alloc(q, (void **)&q->d_fe_hist[i], (size_t)q->fe_hcap * sizeof(cfl)))) return rc;
         if ((rc = dev_alloc(q, (void **)&q->d_fe_vstate[i], sizeof(cfl)))) return rc;
     }
-    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeA, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeB, (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
+    /* probes / tile ranges: one set per block in flight (the carry kernel of block b runs on the back-end stream while the
+     * front end of block b+1 is already writing its own) */
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeA, (size_t)PIPE_DEPTH * q->fe_max_tiles * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeB, (size_t)PIPE_DEPTH * q->fe_max_tiles * sizeof(cfl)))) return rc;
     for (unsigned i = 0; i < PIPE_DEPTH; i++)
         if ((rc = dev_alloc(q, (void **)&q->d_fe_V[i], (size_t)q->fe_max_tiles * sizeof(cfl)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeL, sizeof(cfl)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeE, sizeof(cfl)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_fe_tile_j, (size_t)q->fe_max_tiles * 2 * sizeof(uint64_t)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeL, PIPE_DEPTH * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_probeE, PIPE_DEPTH * sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_fe_tile_j, (size_t)PIPE_DEPTH * q->fe_max_tiles * 2 * sizeof(uint64_t)))) return rc;
     {
         /* carry look-back length and the powers of rho = lambda^T_own it needs */
         const double rho = pow(lam, (double)T_own);
@@ -543,6 +546,9 @@ static int chain_init(pmr_chain q)
         const char *ff = getenv("PMR_DCFIX_FUSE");
         q->fix_fused = ff ? atoi(ff) != 0 : 0;   /* default: k_fe_tilefix corrects in place right after the front end */
         q->fix_skip = getenv("PMR_NOFIX") != NULL;      /* timing experiment only: results are wrong */
+        /* PMR_TILEFIX_STREAM=be runs the carry kernel on the back-end stream: measured slower (the back end becomes the
+         * critical path: cfg2 256 vs 269 GS/s), so the front-end stream keeps it */
+        { const char *tb = getenv("PMR_TILEFIX_STREAM"); q->tilefix_on_backend = (tb && !strcmp(tb, "be")); }
     }
 
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0;
@@ -784,8 +790,12 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
     p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr; p.out_pos0 = q->xr_abs; p.out_mask = q->xr_mask;
-    p.probeA = q->d_fe_probeA; p.probeB = q->d_fe_probeB; p.probeL = q->d_fe_probeL; p.probeE = q->d_fe_probeE;
-    p.tile_j = q->d_fe_tile_j;
+    const unsigned slot = (unsigned)(q->n_calls % PIPE_DEPTH);
+    cfl *prA = q->d_fe_probeA + (size_t)slot * q->fe_max_tiles, *prB = q->d_fe_probeB + (size_t)slot * q->fe_max_tiles;
+    cfl *prL = q->d_fe_probeL + slot, *prE = q->d_fe_probeE + slot;
+    uint64_t *tj = q->d_fe_tile_j + (size_t)slot * 2 * q->fe_max_tiles;
+    p.probeA = prA; p.probeB = prB; p.probeL = prL; p.probeE = prE;
+    p.tile_j = tj;
     p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
     p.n_in = n_in; p.ny = ny; p.Q = Q; p.phi0 = q->arb_phase; p.step = d->arb_step;
     p.h = (int)h; p.T_own = q->fe_T_own; p.Hh = q->fe_Hh; p.HhQ = q->fe_HhQ; p.TQ = q->fe_TQ;
@@ -808,13 +818,13 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     double kterms = rho > 0.0 && rho < 1.0 ? ceil(log(1e-12) / log(rho)) : 1.0;
     if (kterms < 1.0) kterms = 1.0;
     if (kterms > 1e6) kterms = 1e6;
-    t.probeA = q->d_fe_probeA; t.probeB = q->d_fe_probeB; t.probeL = q->d_fe_probeL; t.probeE = q->d_fe_probeE;
+    t.probeA = prA; t.probeB = prB; t.probeL = prL; t.probeE = prE;
     t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V[q->n_calls % PIPE_DEPTH];
     t.ntiles = ntiles; t.K = (unsigned)kterms; t.c_end = c_end;
     t.rho = (float)rho; t.lamHh = (float)pow(lam, (double)q->fe_Hh); t.inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
     t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
     if (t.K > q->fe_K) t.K = q->fe_K;
-    t.rho_pow = q->d_fe_rho_pow; t.tile_j = q->d_fe_tile_j;
+    t.rho_pow = q->d_fe_rho_pow; t.tile_j = tj;
     pmr_fe_fix_params f;
     memset(&f, 0, sizeof(f));
     f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[q->n_calls % PIPE_DEPTH]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
@@ -823,8 +833,10 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     if (q->chan_small && q->fix_fused && !q->dbg_on) {
         /* older arrangement: carries only; the small-M channelizer applies them while staging (+ a tail fix afterwards) */
         LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
+    } else if (q->tilefix_on_backend) {
+        /* experiment: carries + correction deferred to the BACK-END stream (its first consumer step) */
+        q->pend_t = t; q->pend_f = f; q->pend_Q = Q; q->pend_tilefix = 1;
     } else {
-        /* carries and the whole block's correction in one launch, one wave per tile */
         LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream_fe, &t, &f, Q));
     }
     q->fe_sel = nxt;
@@ -934,11 +946,13 @@ int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsig
     plan_counts(q, n_in, &ny_plan, &ns_plan);
     if (ny_plan > q->res_size) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
     *xr_abs0 = q->xr_abs;
-    const int keep_dbg = q->dbg_on;
-    q->dbg_on = 1;                                /* forces the in-place dc fix even if a fused consumer exists */
+    const int keep_dbg = q->dbg_on, keep_tb = q->tilefix_on_backend;
+    q->dbg_on = 1;
+    q->tilefix_on_backend = 0;                    /* this entry point has no back-end stream: everything on stream_fe */                                /* forces the in-place dc fix even if a fused consumer exists */
     int rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                        : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny);
     q->dbg_on = keep_dbg;
+    q->tilefix_on_backend = keep_tb;
     if (rc) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
     q->n_raw += n_in;
@@ -1097,6 +1111,10 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
 
     /* ---- back end on q->stream ---- */
     HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
+    if (q->pend_tilefix) {
+        q->pend_tilefix = 0;
+        LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t, &q->pend_f, q->pend_Q));
+    }
     if (q->dbg_on && ny)
         if ((rc = ring_to_linear(q, q->d_dbg_xr, q->d_xr, q->xr_mask, xr_abs0, ny, sizeof(cfl)))) return rc;
 

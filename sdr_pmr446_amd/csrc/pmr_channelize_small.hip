@@ -17,6 +17,17 @@
 
 #include "pmr_kernels.h"
 
+// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
+// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
+static inline bool pmr_attr_needed(unsigned long long &mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if (mask >> dev & 1ull) return false;
+    mask |= 1ull << dev;
+    return true;
+}
+
 // complex = ext-vector pair: real-tap MACs and butterflies map onto v_pk_fma_f32 / v_pk_add_f32 (~1.8x the FLOP rate of
 // the scalar forms on gfx950, tools/ubench/valu_rate.hip)
 typedef float cf __attribute__((ext_vector_type(2)));
@@ -317,11 +328,10 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
     if (!p->ns) return 0;
     if (p->M != 16) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)(CS_NT * CS_FPT + p->p - 1) * (p->M + 2) * sizeof(cf);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_small<16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_channelize_small<16>, dim3(ntiles), dim3(CS_NT), lds, (hipStream_t)s, *p);
     return (int)hipGetLastError();

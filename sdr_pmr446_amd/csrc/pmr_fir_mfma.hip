@@ -24,6 +24,17 @@
 
 #include "pmr_kernels.h"
 
+// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
+// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
+static inline bool pmr_attr_needed(unsigned long long &mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if (mask >> dev & 1ull) return false;
+    mask |= 1ull << dev;
+    return true;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FM_NT 256
@@ -202,13 +213,12 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
     const unsigned qlen = ntaps + 2 * PMR_TAP_PAD, nrows = FM_TILE + ntaps + 31;
     const size_t lds = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float) +
                        ((size_t)nrows * 16 + 16 * ((nrows >> 5) + 1)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     /* PMR_FIR_MFMA=global: B operand straight from the ring (no LDS window; co-resides with front-end tiles).  Measured
      * on MI355X: slower in isolation (0.082 vs 0.066 ms at cfg2) and equal within noise inside the pipelined chain, so the

@@ -24,6 +24,17 @@
 
 #include "pmr_kernels.h"
 
+// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
+// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
+static inline bool pmr_attr_needed(unsigned long long &mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if (mask >> dev & 1ull) return false;
+    mask |= 1ull << dev;
+    return true;
+}
+
 // complex sample = clang ext-vector pair: (re, im) arithmetic with a real scalar tap maps onto v_pk_fma_f32 with the tap
 // broadcast from one SGPR.  Measured on MI355X (tools/ubench/valu_rate.hip): v_fma_f32 peaks at ~67 TFLOP/s,
 // v_pk_fma_f32 at ~115-120 TFLOP/s, so packed math is worth ~1.8x wherever the kernel is VALU-bound.
@@ -866,11 +877,10 @@ static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned nt
     const size_t n0 = (size_t)NT * SPT;
     size_t lds = (FE_PAD + n0 + n0 / SPT + 32 + 10 * (NT / 64 + 1)) * sizeof(cf);   /* pad + tile + scan scratch + halo exchange */
     { static long extra = -1; if (extra < 0) { const char *e = getenv("PMR_FE_LDS_EXTRA"); extra = e ? atol(e) : 0; } lds += (size_t)extra; }   /* experiment: fewer tiles per CU */
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend<NT, SPT, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     auto kern = k_frontend<NT, SPT, MODE>;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), lds, st, *p);
@@ -885,11 +895,10 @@ static int launch_frontend_fast(hipStream_t st, const pmr_fe_params *p, unsigned
     const size_t n0 = 4096;
     const size_t body = MODE == FE_L2 ? n0 + n0 / 16 : (n0 / 2 + n0 / 16) + (n0 / 4 + n0 / 16);   /* whole raw tile | R0 + R1 */
     size_t lds = (FE_PAD + body + 11 * (256 / 64)) * sizeof(cf);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend_fast<MODE, N3, TAIL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     auto kern = k_frontend_fast<MODE, N3, TAIL>;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st, *p);

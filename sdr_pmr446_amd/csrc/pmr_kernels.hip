@@ -13,6 +13,17 @@
 
 #include "pmr_kernels.h"
 
+// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
+// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
+static inline bool pmr_attr_needed(unsigned long long &mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if (mask >> dev & 1ull) return false;
+    mask |= 1ull << dev;
+    return true;
+}
+
 typedef float2 cf;
 
 static __device__ __forceinline__ cf cf_make(float r, float i) { cf v; v.x = r; v.y = i; return v; }
@@ -679,11 +690,10 @@ extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, u
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
     const size_t lds = ((size_t)chan_ft(p->M, p->ns) * p->M + p->M / 2) * sizeof(cf);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_channelize, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p, ilog2(p->M));
     return (int)hipGetLastError();
@@ -720,11 +730,10 @@ extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_m
     if (mode == 1 && M >= 16 && ntaps <= 512) {
         const unsigned rows = FL_T + PMR_AUDIO_J + ntaps - 1;
         const size_t lds = ((size_t)rows * 16 + 16 * ((rows >> 5) + 1)) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_set = 0;
+        if (pmr_attr_needed(attr_set)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_lds),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
         }
         const unsigned tiles = (ns + FL_T - 1) / FL_T;
         hipLaunchKernelGGL(k_fir_lds, dim3(tiles * (M >> 4)), dim3(256), lds, (hipStream_t)s, in,
