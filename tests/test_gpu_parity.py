@@ -177,3 +177,24 @@ def test_full_size_split_invariance_and_known_answer():
             de = abs(b0 * (1 + np.exp(-1j * w)) / (1 + a1 * np.exp(-1j * w)))
             expect = 4.0 * (2 * 500.0 / 12500.0) * de
             assert abs(amp - expect) < 0.03 * expect, (k, amp, expect)
+
+
+def test_two_handles_interleaved_are_independent():
+    """Handles are independent IQ streams (that is the multi-GPU model): two chains with different
+    configurations on ONE device, calls interleaved, give exactly what each gives when run alone."""
+    from sdr_pmr446_amd import chain
+    cfgs = [(2.4e6, 16, 60000), (61.44e6, 256, 300000)]
+    xs = [synth.synth_iq(3 * mb, fs, M, stream_id=i, channels=None if M <= 64 else list(range(0, M, 16)))
+          for i, (fs, M, mb) in enumerate(cfgs)]
+    alone = []
+    for (fs, M, mb), x in zip(cfgs, xs):
+        g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb)
+        alone.append(np.concatenate([g.process_block(x[i * mb:(i + 1) * mb])["pcm"] for i in range(3)], axis=1))
+        g.close()
+    gs = [chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb) for fs, M, mb in cfgs]
+    parts = [[], []]
+    for i in range(3):
+        for k, ((fs, M, mb), x) in enumerate(zip(cfgs, xs)):
+            parts[k].append(gs[k].process_block(x[i * mb:(i + 1) * mb])["pcm"])
+    for k in range(2):
+        assert np.array_equal(np.concatenate(parts[k], axis=1), alone[k])
