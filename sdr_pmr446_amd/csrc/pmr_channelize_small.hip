@@ -14,6 +14,8 @@
 //     its range, recomputed so tiles are independent.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "pmr_kernels.h"
 
@@ -43,6 +45,8 @@ static constexpr unsigned brev_c(unsigned v, int bits)
     for (int b = 0; b < bits; b++) if (v & (1u << b)) r |= 1u << (bits - 1 - b);
     return r;
 }
+
+static __device__ __forceinline__ unsigned brev_rt(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
 
 // in-register forward DFT, radix-2 decimation in time; x must already be in bit-reversed order
 template <int M>
@@ -314,7 +318,155 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
     }
 }
 
-extern "C" unsigned pmr_channelize_small_tiles(unsigned ns) { return (ns + CS_NT * CS_FPT - 2) / (CS_NT * CS_FPT - 1); }
+// ---------------------------------------------------------------------------------------------------------------
+// Second mapping for M = 16 (the default): sliding-window filter bank + per-frame register FFT.
+//   pass 1  thread = (channel c, group of 16 consecutive frames): the 26 branch taps sit in registers, the group's
+//           16 + 25 input rows are read straight from the resampled ring (16 lanes = one 128-byte row; the NCO phase of
+//           a (c, row) pair has period 2 rows), every sample is loaded and mixed ONCE and feeds up to 16 frames.
+//           No staging pass, no sample window in LDS: X[frame][c] (36 KB per 256-frame tile) is all the LDS there is,
+//           so four tiles fit a CU where the two-frames-per-thread kernel above fits two.
+//   pass 2  thread = frame: FFT-16 in registers, previous frame through LDS, discriminator, stores (as above).
+// Same products and the same oldest-first accumulation order as k_channelize_small / the oracle.
+// ---------------------------------------------------------------------------------------------------------------
+#define CW_NT 256
+#define CW_F 16                          /* frames per (channel, group) work item */
+
+template <int M, int P>
+__global__ __launch_bounds__(CW_NT, 4) void k_channelize_win(pmr_chan_params q)
+{
+    constexpr int L2M = log2c<M>::v;
+    constexpr int FS = M + 2;                             // padded frame row in LDS (cf elements)
+    constexpr int NFT = CW_NT;                            // frames per tile; local frame 0 = frame t0-1 (recomputed)
+    static_assert(CW_NT % M == 0 && (CW_NT / M) * CW_F == NFT, "groups x frames must cover the tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf *Xs = reinterpret_cast<cf *>(smem);                // [NFT][FS]
+    const cf *__restrict__ xr = (const cf *)q.xr;
+    const cf *__restrict__ nco_cs = (const cf *)q.nco_cs;
+    const cf *__restrict__ fft_tw = (const cf *)q.fft_tw;
+    const unsigned ns = q.ns, nco_mask = q.nco_period - 1;
+    const float fm_ref = q.fm_ref;
+    const int tid = threadIdx.x;
+    const long t0 = (long)blockIdx.x * (NFT - 1);         // first NEW frame of this tile, relative to q.frame0
+
+    // ---- pass 1: polyphase bank, X[f][brev(c)] ----
+    {
+        const unsigned c = tid & (M - 1), f0 = (tid >> L2M) * CW_F;
+        // sample of (local frame f0 + r - P ... ) : absolute frame of row r is frame0 + t0 - 1 - (P - 1) + f0 + r  (k = 0 oldest)
+        const long long fbase = (long long)q.frame0 + t0 - (long long)P + f0;
+        float h[P];
+#pragma unroll
+        for (int k = 0; k < P; k++) h[k] = q.taps_t[k * M + c];
+        cf acc[CW_F];
+#pragma unroll
+        for (int f = 0; f < CW_F; f++) acc[f] = cfm(0.f, 0.f);
+        const unsigned a0 = (unsigned)((unsigned long long)fbase * (unsigned long long)M) + c, xr_mask32 = (unsigned)q.xr_mask;
+        // rows in chunks of CW_RB: the chunk's loads are issued together, then its MACs; the scheduling barrier keeps the
+        // compiler from hoisting all 41 row loads (and their NCO factors) to the top, which costs > 128 registers
+        constexpr int CW_RB = 8;
+#pragma unroll
+        for (int r0 = 0; r0 < CW_F + P - 1; r0 += CW_RB) {
+            cf xm[CW_RB];
+#pragma unroll
+            for (int u = 0; u < CW_RB; u++) {
+                const int r = r0 + u;
+                if (r < CW_F + P - 1) {
+                    // low 32 bits of the absolute sample index (fbase + r) * M + c are all the ring / NCO masks need; indices
+                    // before the stream start wrap into the zero-initialised top of the ring, as in k_channelize
+                    const unsigned a = a0 + (unsigned)r * M;
+                    const float2 v = reinterpret_cast<const float2 *>(xr)[a & xr_mask32];
+                    const cf x = cfm(v.x, v.y);
+                    const float2 csv = reinterpret_cast<const float2 *>(nco_cs)[a & nco_mask];
+                    xm[u] = cfm(fmaf(x.x, csv.x, x.y * csv.y), fmaf(x.y, csv.x, -(x.x * csv.y)));   // x * conj(e^{j theta})
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CW_RB; u++) {
+                const int r = r0 + u;
+                if (r < CW_F + P - 1) {
+#pragma unroll
+                    for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < CW_F - 1 ? r : CW_F - 1); f++)
+                        acc[f] = cfma(h[r - f], xm[u], acc[f]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned rc = brev_rt(c, L2M);
+#pragma unroll
+        for (int f = 0; f < CW_F; f++) Xs[(f0 + f) * FS + rc] = acc[f];
+    }
+    __syncthreads();
+
+    // ---- pass 2: thread = local frame tid; FFT in registers ----
+    cf Y[M];
+    {
+        const cf *row = Xs + (size_t)tid * FS;
+#pragma unroll
+        for (int c = 0; c < M; c += 2) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + c);
+            Y[c] = cfm(v.x, v.y); Y[c + 1] = cfm(v.z, v.w);
+        }
+    }
+    fft_dit<M>(Y, fft_tw);
+    __syncthreads();                                      // every X row has been read
+    {
+        cf *ex = Xs + (size_t)tid * FS;
+#pragma unroll
+        for (int c = 0; c < M; c += 2)
+            *reinterpret_cast<float4 *>(ex + c) = make_float4(Y[c].x, Y[c].y, Y[c + 1].x, Y[c + 1].y);
+    }
+    __syncthreads();
+    const long tA = t0 - 1 + tid;                         // frame of this thread, relative to q.frame0
+    const bool outA = tid > 0 && tA < (long)ns;
+    if (outA) {
+        const cf *pvrow = Xs + (size_t)(tid - 1) * FS;
+        float *o = q.fm + ((unsigned long long)(q.frame0 + tA) & q.fm_mask) * M;
+#pragma unroll
+        for (int k = 0; k < M; k += 4) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(pvrow + k), p1 = *reinterpret_cast<const float4 *>(pvrow + k + 2);
+            const cf pv[4] = {cfm(p0.x, p0.y), cfm(p0.z, p0.w), cfm(p1.x, p1.y), cfm(p1.z, p1.w)};
+            float4 r;
+            float *rr = &r.x;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const cf cu = Y[k + i];
+                rr[i] = atan2f(fmaf(pv[i].x, cu.y, -(pv[i].y * cu.x)), fmaf(pv[i].x, cu.x, pv[i].y * cu.y)) * fm_ref;
+            }
+            *reinterpret_cast<float4 *>(o + k) = r;
+        }
+        cf *__restrict__ chan_out = (cf *)q.chan_out;
+        if (chan_out) {
+#pragma unroll
+            for (int k = 0; k < M; k++) chan_out[(size_t)k * q.chan_stride + tA] = Y[k];
+        }
+    }
+    if (q.rssi_part) {
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(Xs);       // [CW_NT/64][M]
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            float a = outA ? hypotf(Y[k].x, Y[k].y) : 0.f;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d);
+            if (lane == 0) red[wave * M + k] = a;
+        }
+        __syncthreads();
+        if (tid < M) {
+            float a = 0.f;
+            for (int w = 0; w < CW_NT / 64; w++) a += red[w * M + tid];
+            q.rssi_part[(size_t)blockIdx.x * M + tid] = a;
+        }
+    }
+}
+
+static int cs_use_win()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PMR_CHANNELIZER_SMALL"); v = !(e && !strcmp(e, "pair")); }   /* pair = two frames per thread */
+    return v;
+}
+
+extern "C" unsigned pmr_channelize_small_tiles(unsigned ns) { return (ns + CS_NT * CS_FPT - 2) / (CS_NT * CS_FPT - 1); }   /* pair kernel */
 
 extern "C" int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned nco_period)
 {
@@ -323,10 +475,16 @@ extern "C" int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned n
 
 extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out)
 {
-    const unsigned ntiles = pmr_channelize_small_tiles(p->ns);
+    const bool win = cs_use_win() && p->p == 26 && !p->V;      /* the windowed kernel does not apply a deferred dc carry */
+    const unsigned ntiles = win ? (p->ns + CW_NT - 2) / (CW_NT - 1) : pmr_channelize_small_tiles(p->ns);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
     if (p->M != 16) return (int)hipErrorInvalidValue;
+    if (win) {
+        const size_t lds_w = (size_t)CW_NT * (16 + 2) * sizeof(cf);
+        hipLaunchKernelGGL((k_channelize_win<16, 26>), dim3(ntiles), dim3(CW_NT), lds_w, (hipStream_t)s, *p);
+        return (int)hipGetLastError();
+    }
     const size_t lds = (size_t)(CS_NT * CS_FPT + p->p - 1) * (p->M + 2) * sizeof(cf);
     static unsigned long long attr_set = 0;
     if (pmr_attr_needed(attr_set)) {
