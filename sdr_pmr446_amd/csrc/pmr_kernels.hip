@@ -209,31 +209,49 @@ static __device__ __forceinline__ void pfb_rows(const pmr_chan_params &q, unsign
     // work item = (channel c, group g of F consecutive frames); M >= 256: one group, a thread walks channels;
     // small M: the 256 threads are 256/M groups side by side (16 lanes = one 128-byte row at M = 16)
     const unsigned G = (nfl + F - 1) / F;
+    typedef float v2 __attribute__((ext_vector_type(2)));       // (re, im): real-tap MACs map onto v_pk_fma_f32
+    const unsigned xr_mask32 = (unsigned)q.xr_mask;
+    // low 32 bits of the absolute sample index are all the ring / NCO masks need (indices before the stream start wrap
+    // into the zero-initialised top of the ring)
+    const unsigned abase = (unsigned)((unsigned long long)fbase * (unsigned long long)M);
     for (unsigned w = tid; w < M * G; w += 256) {
         const unsigned c = w & (M - 1), f0 = (w >> log2M) * F;
         float h[P];
 #pragma unroll
         for (int k = 0; k < P; k++) h[k] = q.taps_t[k * M + c];
-        float ar[F], ai[F];
+        v2 acc[F];
 #pragma unroll
-        for (int f = 0; f < F; f++) { ar[f] = 0.f; ai[f] = 0.f; }
+        for (int f = 0; f < F; f++) acc[f] = v2{0.f, 0.f};
+        const unsigned a0 = abase + f0 * M + c;
+        constexpr int RB = 8;                                    // rows per batch: loads first, then the MACs
 #pragma unroll
-        for (int r = 0; r < F + P - 1; r++) {
-            const long long a = (fbase + f0 + r) * (long long)M + c;  // absolute resampled sample index
-            const cf x = xr[(unsigned long long)a & q.xr_mask];
-            const cf cs = nco_cs[(unsigned)a & nco_mask];
-            const float xmr = fmaf(x.x, cs.x, x.y * cs.y);            // x * conj(e^{j theta})
-            const float xmi = fmaf(x.y, cs.x, -(x.x * cs.y));
+        for (int r0 = 0; r0 < F + P - 1; r0 += RB) {
+            v2 xm[RB];
 #pragma unroll
-            for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < F - 1 ? r : F - 1); f++) {
-                ar[f] = fmaf(h[r - f], xmr, ar[f]);
-                ai[f] = fmaf(h[r - f], xmi, ai[f]);
+            for (int u = 0; u < RB; u++) {
+                const int r = r0 + u;
+                if (r < F + P - 1) {
+                    const unsigned a = a0 + (unsigned)r * M;
+                    const cf x = xr[a & xr_mask32];
+                    const cf cs = nco_cs[a & nco_mask];
+                    xm[u] = v2{fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y))};   // x * conj(e^{j theta})
+                }
             }
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int r = r0 + u;
+                if (r < F + P - 1) {
+#pragma unroll
+                    for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < F - 1 ? r : F - 1); f++)
+                        acc[f] = __builtin_elementwise_fma(v2{h[r - f], h[r - f]}, xm[u], acc[f]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const unsigned rc = __brev(c) >> (32 - log2M);
 #pragma unroll
         for (int f = 0; f < F; f++)
-            if (f0 + f < nfl) Xs[(f0 + f) * M + rc] = cf_make(ar[f], ai[f]);
+            if (f0 + f < nfl) Xs[(f0 + f) * M + rc] = cf_make(acc[f].x, acc[f].y);
     }
 }
 
