@@ -19,7 +19,7 @@ for w in ("cfg2", "cfg3", "cfg5"):
         print(w, "%.1f GS/s" % (d["value"] / 1e3), "frac", round(d["roofline"]["frac"], 3))
 
 # kernel stats from the trace (same numbers rocprofv3 --stats prints, restricted to this library's kernels)
-tr = glob.glob(os.path.join(P, "stats", "**", "*kernel_trace.csv"), recursive=True)
+tr = sorted(glob.glob(os.path.join(P, "stats", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime, reverse=True)
 if tr:
     agg = {}
     for r in csv.DictReader(open(tr[0])):
@@ -36,7 +36,7 @@ if tr:
 # PMC: average counter value per launch and kernel (KB)
 pm = {}
 for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    cc = glob.glob(os.path.join(P, sub, "**", "*counter_collection.csv"), recursive=True)
+    cc = sorted(glob.glob(os.path.join(P, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if not cc:
         continue
     acc = {}
