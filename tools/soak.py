@@ -14,7 +14,36 @@ CFGS = [(1.024e6, 16), (2.4e6, 16), (3.2e6, 32), (1.6e6, 32), (10.0e6, 64), (4.0
 t_end = time.time() + budget
 n_cases = 0
 worst = 0
+def dsd_case():
+    """dsd_in chain (include/pmr_dsd.h) against the oracle: random rates and ragged splits."""
+    fs = float(rng.choice([1.024e6, 2.4e6, 250e3, 500e3, 4.0e6]))
+    au = float(rng.choice([48000.0, 24000.0, 96000.0, 12500.0, 44100.0]))
+    mb = int(rng.choice([5000, 60000, 200000]))
+    splits = [int(rng.integers(0, mb + 1)) if rng.random() < 0.8 else int(rng.integers(0, 70)) for _ in range(int(rng.integers(1, 5)))]
+    n = sum(splits)
+    if n == 0:
+        return 0
+    x = synth.synth_iq(n, fs, 1, dev_hz=float(rng.choice([1500.0, 2500.0])), dc_offset=float(rng.choice([0.0, 0.002])))
+    g = chain.PmrDsd(fs_in=fs, audio_rate=au, max_block=mb)
+    o = oracle.OracleDsd(fs_in=fs, audio_rate=au, max_block=mb)
+    pg, po, pos = [], [], 0
+    for sp in splits:
+        a = g.process_block(x[pos:pos + sp]); b = o.process_block(x[pos:pos + sp]); pos += sp
+        assert a["n_out"] == b["n_out"], ("dsd", fs, au, splits)
+        pg.append(a["pcm"]); po.append(b["pcm"])
+    pg, po = np.concatenate(pg), np.concatenate(po)
+    d = int(np.abs(pg.astype(np.int32) - po.astype(np.int32)).max()) if len(pg) else 0
+    print("%s dsd fs=%g audio=%g max_block=%d splits=%s out=%d maxdiff=%d" % ("ok" if d <= 1 else "FAIL", fs, au, mb, splits, len(pg), d), flush=True)
+    g.close(); o.close()
+    if d > 1:
+        sys.exit(1)
+    return d
+
+
 while time.time() < t_end:
+    if rng.random() < 0.15:
+        worst = max(worst, dsd_case()); n_cases += 1
+        continue
     fs, M = CFGS[rng.integers(len(CFGS))]
     opts = dict(lowpass=bool(rng.integers(2)) and rng.random() < 0.3, deemph_fir=rng.random() < 0.2)
     max_block = int(rng.choice([3000, 20000, 100000, 400000]))
