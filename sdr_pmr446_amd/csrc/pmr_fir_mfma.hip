@@ -51,7 +51,8 @@ static __device__ __forceinline__ int16_t pcm16(float y)
 
 #define FM_PRE 11                                /* float4 prefetch registers per thread: windows up to 704 rows */
 
-template <bool GLB, int TPW /*tiles per workgroup: 2 = the second tile's window is prefetched under the first tile's MFMAs*/>
+template <bool GLB, int TPW /*tiles per workgroup: 2 = the second tile's window is prefetched under the first tile's MFMAs*/,
+          bool SWAP /*operands exchanged: the accumulators hold the TRANSPOSED tile (lane = frame), see the epilogue*/>
 __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict__ in, unsigned long long row_mask,
                                                       long long row0, unsigned ns, const float *__restrict__ taps_c,
                                                       unsigned ntaps, float *__restrict__ out_tm,
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
             else B[u] = x_[32 * u]; }                                                                                         \
         __builtin_amdgcn_sched_barrier(0); } while (0)   /* keep the loads ahead of the MFMA block that hides them */
 #define FM_MMA(A, B) do { _Pragma("unroll") for (int u = 0; u < 16; u++)                                                  \
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u], B[u], acc, 0, 0, 0);                                                \
+        acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(B[u], A[u], acc, 0, 0, 0)                                          \
+                   : __builtin_amdgcn_mfma_f32_32x32x2f32(A[u], B[u], acc, 0, 0, 0);                                         \
         __builtin_amdgcn_sched_barrier(0); } while (0)
     FM_LOAD(a0, b0, 0u);
     unsigned g = 0;
@@ -149,8 +151,24 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
 #undef FM_LOAD
 #undef FM_MMA
 
-    // D layout: lane holds column j; register g*4+q is row 8g + 4*kk + q  ->  4 consecutive frames per register group
     if (!(ablate & 4)) {
+    if constexpr (SWAP) {
+        // Operands exchanged => D' = D^T (same products, same k order): lane = frame (column lane & 31), register 4g + q =
+        // row 8g + 4kk + q = (channel, time block).  A half-wave then stores 32 CONSECUTIVE frames of one channel row: 64
+        // contiguous bytes of PCM (128 of float audio) per store instead of 8-byte pieces scattered over 32 rows.
+        // (Used when there is no time-major output, whose rows want the untransposed layout.)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i2 = 8 * (r >> 2) + 4 * kk + (r & 3);
+            const int ch2 = i2 & 15, blk2 = i2 >> 4;
+            const long t = T0 + 64 * wave + 32 * blk2 + (lane & 31);
+            if (t < (long)ns) {
+                if (pcm) pcm[(size_t)ch2 * stride + t] = pcm16(acc[r]);
+                if (audio) audio[(size_t)ch2 * stride + t] = acc[r];
+            }
+        }
+    } else {
+    // D layout: lane holds column j; register g*4+q is row 8g + 4*kk + q  ->  4 consecutive frames per register group
     const bool vec_ok = ((stride & 3) == 0);
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++) {
@@ -189,6 +207,7 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
                 if (t + q < (long)ns) out_tm[((unsigned long long)(row0 + t + q) & row_mask) * M + ch] = yy[q];
         }
     }
+    }
     } else if (acc[0] == 123.456f) pcm[0] = 1;
     }   // active
     if (more) {                                                      // uniform
@@ -215,9 +234,13 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
                        ((size_t)nrows * 16 + 16 * ((nrows >> 5) + 1)) * sizeof(float);
     static unsigned long long attr_set = 0;
     if (pmr_attr_needed(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 1, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 2, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     /* PMR_FIR_MFMA=global: B operand straight from the ring (no LDS window; co-resides with front-end tiles).  Measured
@@ -228,7 +251,7 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
     const int ablate = []{ const char *e = getenv("PMR_FIR_ABLATE"); return e ? atoi(e) : 0; }();
     if (glb) {
         const size_t lds_g = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float);
-        hipLaunchKernelGGL((k_fir_mfma16<true, 1>), dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds_g, (hipStream_t)s, in,
+        hipLaunchKernelGGL((k_fir_mfma16<true, 1, false>), dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds_g, (hipStream_t)s, in,
                            (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
         return (int)hipGetLastError();
     }
@@ -237,12 +260,20 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
     if (tpw < 0) { const char *e = getenv("PMR_FIR_TPW"); tpw = e ? atoi(e) : 2; }
     /* two tiles per workgroup only while that still leaves enough workgroups to fill the chip (3 per CU fit) */
     if (tpw == 2 && nrows * 4 <= FM_PRE * FM_NT && (size_t)((tiles + 1) / 2) * (M / 16) >= 384) {
-        hipLaunchKernelGGL((k_fir_mfma16<false, 2>), dim3((tiles + 1) / 2, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+        if (!out_tm)
+            hipLaunchKernelGGL((k_fir_mfma16<false, 2, true>), dim3((tiles + 1) / 2, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
+                               (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+        else
+            hipLaunchKernelGGL((k_fir_mfma16<false, 2, false>), dim3((tiles + 1) / 2, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
+                               (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
         return (int)hipGetLastError();
     }
     if (nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_fir_mfma16<false, 1>), dim3(tiles, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                       (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+    if (!out_tm)
+        hipLaunchKernelGGL((k_fir_mfma16<false, 1, true>), dim3(tiles, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
+                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+    else
+        hipLaunchKernelGGL((k_fir_mfma16<false, 1, false>), dim3(tiles, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
+                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
     return (int)hipGetLastError();
 }
