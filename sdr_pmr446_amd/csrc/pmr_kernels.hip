@@ -190,15 +190,25 @@ __global__ __launch_bounds__(256) void k_arb(const cf *__restrict__ dec, cf *__r
 // ------------------------------------------------------------------------------------------------
 // frames held in LDS per workgroup (one of them is the recomputed previous frame): at most 64 KB worth, and few enough
 // that a block still yields ~1000 workgroups (the work per frame is small; parallelism is what matters)
-static __host__ __device__ inline unsigned chan_ft(unsigned M, unsigned ns)
+static __host__ __device__ inline unsigned chan_ft_auto(unsigned M, unsigned ns)
 {
-    unsigned cap = 4096u / M; if (cap < 4u) cap = 4u;     // 32 KB of LDS per tile
-    unsigned want = M >= 256u ? ns / 1024u + 2u : cap;     // many channels: small tiles keep ~1000 workgroups in the grid
+    // LDS: X[FT][M] complex -- 32 KB per tile, 64 KB for M >= 512 (taller tiles amortise the 25-frame filter history)
+    unsigned cap = (M >= 512u ? 8192u : 4096u) / M; if (cap < 2u) cap = 2u;
+    // many channels: about one tile per CU at least (measured at cfg5, 838 frames x 1024 channels: FT 4..6 is 25 % faster
+    // than FT 2); few channels: the cap
+    unsigned want = M >= 256u ? ns / 256u + 1u : cap;
+    if (want < 2u) want = 2u;
     return want < cap ? want : cap;
 }
+// the tile height is chosen on the host (PMR_CHAN_FT overrides it for experiments) and handed to the kernel
+static unsigned chan_ft(unsigned M, unsigned ns)
+{
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("PMR_CHAN_FT"); forced = e ? atoi(e) : 0; }
+    if (forced >= 2) { unsigned cap = 8192u / M; if (cap < 2u) cap = 2u; return (unsigned)forced < cap ? (unsigned)forced : cap; }
+    return chan_ft_auto(M, ns);
+}
 
-// Polyphase bank for one tile, thread-per-channel with a sliding window over the tile's F frames (P taps per branch).
-// Same products, same oldest-first accumulation order as the item-per-thread loop in k_channelize.
 template <int F, int P>
 static __device__ __forceinline__ void pfb_rows(const pmr_chan_params &q, unsigned log2M, cf *Xs, long long fbase,
                                                 unsigned nfl /*frames to store*/, unsigned tid)
@@ -255,11 +265,11 @@ static __device__ __forceinline__ void pfb_rows(const pmr_chan_params &q, unsign
     }
 }
 
-__global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned log2M)
+__global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned log2M, unsigned FT)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned M = q.M, p = q.p, ns = q.ns;
-    const unsigned FT = chan_ft(M, ns), TFN = FT - 1;
+    const unsigned TFN = FT - 1;
     cf *Xs = reinterpret_cast<cf *>(smem);            // [FT][M]
     cf *tw = Xs + (size_t)FT * M;                     // [M/2]
     const cf *__restrict__ xr = (const cf *)q.xr;
@@ -707,13 +717,14 @@ extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, u
     const unsigned ntiles = pmr_channelize_tiles(p->ns, p->M);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
-    const size_t lds = ((size_t)chan_ft(p->M, p->ns) * p->M + p->M / 2) * sizeof(cf);
+    const unsigned ft = chan_ft(p->M, p->ns);
+    const size_t lds = ((size_t)ft * p->M + p->M / 2) * sizeof(cf);
     static unsigned long long attr_set = 0;
     if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL(k_channelize, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p, ilog2(p->M));
+    hipLaunchKernelGGL(k_channelize, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p, ilog2(p->M), ft);
     return (int)hipGetLastError();
 }
 
