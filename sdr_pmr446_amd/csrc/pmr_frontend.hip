@@ -541,21 +541,41 @@ __global__ __launch_bounds__(256, MODE == FE_L2 ? 4 : 5) void k_frontend_fast(pm
     if constexpr (MODE == FE_L2) {
         const cf *__restrict__ ring = (const cf *)p.in_ring;
         const cf *__restrict__ V1 = (const cf *)p.fixV;
-        for (int i = tid; i < N0; i += NT) {
-            const long long a = (long long)p.in_abs0 + b0 + i;
-            const long long jn = b0 + i;
-            cf v = cfm(0.f, 0.f);
-            if (a >= 0 && jn < (long long)p.n_in) {
-                v = ring[(unsigned long long)a & p.in_mask];
-                if (V1 && jn >= 0) {
-                    const unsigned c1 = (unsigned)jn / p.fix_TQ;
-                    const unsigned ql = (unsigned)jn - c1 * p.fix_TQ + p.fix_HhQ;
-                    const float g = p.fix_K * (p.fix_T1[ql >> 5] * p.fix_T2[ql & 31]);
-                    const cf Vc = V1[c1];
-                    v = cf{fmaf(-Vc.x, g, v.x), fmaf(-Vc.y, g, v.y)};
+        // Two batches of eight samples per thread: the ring loads of a batch are all issued first, then the table
+        // look-ups of level 1's dc carry (tile index and local offset advance incrementally: one division per thread), then
+        // the arithmetic -- a one-sample-per-iteration loop pays the load latency sixteen times in a row.
+        unsigned c1 = 0, ql = 0; bool trk = false;
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++) {
+            cf v[8], Vc[8]; float g[8]; bool fx[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = tid + NT * (8 * hb + k);
+                const long long a = (long long)p.in_abs0 + b0 + i, jn = b0 + i;
+                v[k] = cfm(0.f, 0.f);
+                if (a >= 0 && jn < (long long)p.n_in) v[k] = ring[(unsigned long long)a & p.in_mask];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = tid + NT * (8 * hb + k);
+                const long long a = (long long)p.in_abs0 + b0 + i, jn = b0 + i;
+                fx[k] = V1 && a >= 0 && jn >= 0 && jn < (long long)p.n_in;
+                g[k] = 0.f; Vc[k] = cfm(0.f, 0.f);
+                if (fx[k]) {
+                    if (!trk) { c1 = (unsigned)jn / p.fix_TQ; ql = (unsigned)jn - c1 * p.fix_TQ; trk = true; }
+                    else { ql += NT; while (ql >= p.fix_TQ) { ql -= p.fix_TQ; c1++; } }
+                    const unsigned e = ql + p.fix_HhQ;
+                    g[k] = p.fix_K * (p.fix_T1[e >> 5] * p.fix_T2[e & 31]);
+                    Vc[k] = V1[c1];
                 }
             }
-            buf[lidx<SPT>(i)] = v;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = tid + NT * (8 * hb + k);
+                cf w = v[k];
+                if (fx[k]) w = cf{fmaf(-Vc[k].x, g[k], w.x), fmaf(-Vc[k].y, g[k], w.y)};
+                buf[lidx<SPT>(i)] = w;
+            }
         }
     }
     cf xs[SPT];
