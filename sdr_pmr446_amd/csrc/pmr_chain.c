@@ -96,6 +96,7 @@ struct pmr_chain_s {
     float fe1_K;                     /* alpha * prod G_e (e < s1): dc-carry gain at the level-1 output */
     cfl *d_fe_ring1; uint64_t ring1_mask;
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
+    int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
     int tilefix_on_backend, pend_tilefix; pmr_fe_tiles_params pend_t; pmr_fe_fix_params pend_f; unsigned pend_Q;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     unsigned fe_max_tiles;
@@ -338,7 +339,7 @@ static int fe_init(pmr_chain q)
         if (H2 + L2 > 4096) return PMR_OK;
         const unsigned long t2 = (4096 - H2) / L2 * L2;
         q->fe2_T_own = (int)t2; q->fe2_Hh = (int)(4096 - t2); q->fe2_HhQ = q->fe2_Hh / (int)D2; q->fe2_TQ = (int)(t2 / D2);
-        uint64_t need = (uint64_t)q->fe2_Hh + D2 + 2ull * ((q->cfg.max_block >> s1) + 2) + 64, cap = 1;
+        uint64_t need = (uint64_t)q->fe2_Hh + D2 + (uint64_t)PIPE_DEPTH * ((q->cfg.max_block >> s1) + 2) + 64, cap = 1;
         while (cap < need) cap <<= 1;
         q->ring1_mask = cap - 1;
         if ((rc = dev_alloc(q, (void **)&q->d_fe_ring1, (size_t)cap * sizeof(cfl)))) return rc;
@@ -548,6 +549,7 @@ static int chain_init(pmr_chain q)
         q->fix_skip = getenv("PMR_NOFIX") != NULL;      /* timing experiment only: results are wrong */
         /* PMR_TILEFIX_STREAM=be runs the carry kernel on the back-end stream: measured slower (the back end becomes the
          * critical path: cfg2 256 vs 269 GS/s), so the front-end stream keeps it */
+        { const char *l2 = getenv("PMR_L2_STREAM"); q->l2_on_backend = !(l2 && !strcmp(l2, "fe")); }
         { const char *tb = getenv("PMR_TILEFIX_STREAM"); q->tilefix_on_backend = (tb && !strcmp(tb, "be")); }
     }
 
@@ -919,7 +921,12 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
         memcpy(p2.lam_pow16, q->fe_lam_pow16, sizeof(p2.lam_pow16));
         fe_fill_taps(q, &p2, s1, h2);
         (void)D2;
-        LAUNCH_FE(K_FE_L2, pmr_launch_frontend(q->stream_fe, &p2, ntiles2, 256, 16));
+        /* Level 2 (and the ring fix-up after it) belong to the BACK-END stream when there is one: level 2 touches 1/2^s1 of
+         * the data in a few thousand tiles -- too few to fill the chip -- so it runs best under the next block's level 1
+         * instead of between two level-1 launches on the same stream. */
+        const int defer = q->l2_on_backend;
+        if (defer) { q->pend_p2 = p2; q->pend_ntiles2 = ntiles2; }
+        else LAUNCH_FE(K_FE_L2, pmr_launch_frontend(q->stream_fe, &p2, ntiles2, 256, 16));
 
         /* level 2 corrected its private copy; what the next call re-reads as history gets its dc carry in place */
         const unsigned keep = (unsigned)q->fe2_Hh + D2 + 16;
@@ -928,7 +935,8 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
         f.xr = q->d_fe_ring1; f.pos0 = A; f.mask = q->ring1_mask; f.V = q->d_fe_V[par]; f.GA = q->d_fe_GA;
         f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2; f.ny = Q1; f.j0 = Q1 > keep ? Q1 - keep : 0;
         f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = 0; f.step = 0; f.Kgain = q->fe1_K;
-        LAUNCH_FE(K_FE_FIX, pmr_launch_fe_dcfix(q->stream_fe, &f));
+        if (defer) { q->pend_f2 = f; q->pend_l2 = 1; }
+        else LAUNCH_FE(K_FE_FIX, pmr_launch_fe_dcfix(q->stream_fe, &f));
     }
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
@@ -946,13 +954,15 @@ int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsig
     plan_counts(q, n_in, &ny_plan, &ns_plan);
     if (ny_plan > q->res_size) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
     *xr_abs0 = q->xr_abs;
-    const int keep_dbg = q->dbg_on, keep_tb = q->tilefix_on_backend;
+    const int keep_dbg = q->dbg_on, keep_tb = q->tilefix_on_backend, keep_l2 = q->l2_on_backend;
     q->dbg_on = 1;
+    q->l2_on_backend = 0;
     q->tilefix_on_backend = 0;                    /* this entry point has no back-end stream: everything on stream_fe */                                /* forces the in-place dc fix even if a fused consumer exists */
     int rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                        : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny);
     q->dbg_on = keep_dbg;
     q->tilefix_on_backend = keep_tb;
+    q->l2_on_backend = keep_l2;
     if (rc) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
     q->n_raw += n_in;
@@ -1111,6 +1121,11 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
 
     /* ---- back end on q->stream ---- */
     HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
+    if (q->pend_l2) {
+        q->pend_l2 = 0;
+        LAUNCH(K_FE_L2, pmr_launch_frontend(q->stream, &q->pend_p2, q->pend_ntiles2, 256, 16));
+        LAUNCH(K_FE_FIX, pmr_launch_fe_dcfix(q->stream, &q->pend_f2));
+    }
     if (q->pend_tilefix) {
         q->pend_tilefix = 0;
         LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t, &q->pend_f, q->pend_Q));
