@@ -514,6 +514,7 @@ __global__ __launch_bounds__(256, MODE == FE_L2 ? 4 : 5) void k_frontend_fast(pm
     // ---- everything that comes from tables, requested up front ----
     const unsigned long long qa = (unsigned long long)c * p.TQ;
     unsigned long long ja = 0, jb = 0, jh = 0;
+    bool pairs = false;
     float bk0[14], bk1[14];
     const float *b0p = nullptr, *b1p = nullptr;
     if constexpr (MODE != FE_L1) {
@@ -528,8 +529,10 @@ __global__ __launch_bounds__(256, MODE == FE_L2 ? 4 : 5) void k_frontend_fast(pm
         if (p.tile_j && tid == 0) { ((unsigned long long *)p.tile_j)[2 * c] = ja; ((unsigned long long *)p.tile_j)[2 * c + 1] = jb; }
         // a thread owns the PAIR of adjacent outputs jh + 2 tid, + 1 (jh = ja rounded up to an even ring position; the
         // odd head sample, if any, is thread 0's extra job): one 16-byte store per thread instead of two 8-byte ones
-        jh = ja + ((p.out_pos0 + ja) & 1ull);
-        const unsigned long long j0 = jh + 2ull * tid, j1 = j0 + 1;
+        // (only when the tile has more outputs than threads -- otherwise one output per thread is the shorter phase D)
+        pairs = jb - ja > (unsigned long long)NT;
+        jh = pairs ? ja + ((p.out_pos0 + ja) & 1ull) : ja;
+        const unsigned long long j0 = pairs ? jh + 2ull * tid : ja + tid, j1 = pairs ? j0 + 1 : jb;
         const unsigned long long ph0 = (unsigned long long)p.phi0 + j0 * p.step, ph1 = ph0 + p.step;
         b0p = p.arb_bank + (j0 < jb ? (unsigned)(ph0 & 0xffffffu) >> 16 : 0u) * 14u;
         b1p = p.arb_bank + (j1 < jb ? (unsigned)(ph1 & 0xffffffu) >> 16 : 0u) * 14u;
@@ -737,8 +740,8 @@ __global__ __launch_bounds__(256, MODE == FE_L2 ? 4 : 5) void k_frontend_fast(pm
             for (int k = 0; k < 14; k++) y = cfma(bk[k], fin[(ql + k) + ((ql + k) >> GS)], y);
             return y;
         };
-        const unsigned long long j0 = jh + 2ull * tid;
-        if (j0 + 1 < jb) {
+        const unsigned long long j0 = pairs ? jh + 2ull * tid : ja + tid;
+        if (pairs && j0 + 1 < jb) {
             const cf y0 = resamp(j0, bk0), y1 = resamp(j0 + 1, bk1);
             *reinterpret_cast<float4 *>(out + ((p.out_pos0 + j0) & p.out_mask)) = make_float4(y0.x, y0.y, y1.x, y1.y);
         } else if (j0 < jb) {
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(256, MODE == FE_L2 ? 4 : 5) void k_frontend_fast(pm
             const unsigned long long ph = (unsigned long long)p.phi0 + ja * p.step;
             out[(p.out_pos0 + ja) & p.out_mask] = resamp(ja, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
         }
-        for (unsigned long long j = jh + 2ull * NT + tid; j < jb; j += NT) {
+        for (unsigned long long j = (pairs ? jh + 2ull * NT : ja + NT) + tid; j < jb; j += NT) {
             const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
             out[(p.out_pos0 + j) & p.out_mask] = resamp(j, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
         }
