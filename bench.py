@@ -194,6 +194,8 @@ def main():
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": ms / n,
                     "launches_per_step": launches_per_step,
                     "algorithmic_bytes_per_sample": b_alg,
+                    "kernel_symbols": "slot k_frontend = k_frontend_fast<MODE,N3,TAIL> (specialised cascades) or "
+                                      "k_frontend<NT,SPT,MODE> in a rocprofv3 trace; k_fir_tm<hp> = k_fir_mfma16<...>",
                     "kernels_ms_per_step_isolated": {k: v[0] / max(1, breakdown_steps)
                                                      for k, v in sorted(prof.items())}}
             iso = prof.get(name)
