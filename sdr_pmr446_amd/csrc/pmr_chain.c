@@ -672,6 +672,7 @@ int pmr_chain_reset(pmr_chain q)
     }
     q->fe_sel = 0;
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
+    q->pend_l2 = 0; q->pend_tilefix = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
     return PMR_OK;
 }
