@@ -1,0 +1,61 @@
+"""The A/B code paths behind the PMR_* environment switches keep parity too: each variant runs in its own
+process (the switches are read once per process) and must match the oracle within +-1 LSB on the same blocks."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SNIPPET = r"""
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r + "/tests")
+import numpy as np
+import oracle
+from sdr_pmr446_amd import chain, synth
+fs, M, splits = %r
+ks = None if M <= 64 else list(range(0, M, M // 16))
+n = sum(splits)
+x = synth.synth_iq(n, fs, M, channels=ks, dev_hz=1500.0, dc_offset=0.003)
+g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(splits))
+o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=max(splits))
+pg, po, pos = [], [], 0
+for s in splits:
+    pg.append(g.process_block(x[pos:pos + s])["pcm"]); po.append(o.process_block(x[pos:pos + s])["pcm"]); pos += s
+pg, po = np.concatenate(pg, axis=1), np.concatenate(po, axis=1)
+act = [k for k in (ks or range(M)) if synth.channel_kind(k) != "empty"]
+d = int(np.abs(pg[act].astype(np.int32) - po[act].astype(np.int32)).max())
+print("frames", pg.shape[1], "maxdiff", d)
+sys.exit(0 if (d <= 1 and pg.shape[1] > 50) else 1)
+"""
+
+CFG2 = (2.4e6, 16, [150000, 1, 99999, 130000])
+CFG5 = (1.0e9, 1024, [1 << 22, 3000000])
+CFG3 = (61.44e6, 256, [1 << 21, 1500000])
+
+VARIANTS = [
+    ({"PMR_FRONTEND": "staged"}, CFG2),
+    ({"PMR_FE_KERNEL": "generic"}, CFG2),
+    ({"PMR_FE_LEVELS": "2"}, CFG3),
+    ({"PMR_L2_STREAM": "fe"}, CFG5),
+    ({"PMR_TILEFIX_STREAM": "be"}, CFG2),
+    ({"PMR_DCFIX_FUSE": "1"}, CFG2),
+    ({"PMR_CHANNELIZER": "generic"}, CFG2),
+    ({"PMR_CHANNELIZER_SMALL": "pair"}, CFG2),
+    ({"PMR_CHAN_FT": "7"}, CFG3),
+    ({"PMR_FIR": "pair"}, CFG2),
+    ({"PMR_FIR_MFMA": "global"}, CFG2),
+    ({"PMR_FIR_TPW": "1"}, CFG2),
+    ({"PMR_OVERLAP": "0", "PMR_STREAM_PRIO": "0"}, CFG2),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,cfg", VARIANTS, ids=["+".join("%s=%s" % kv for kv in e.items()) for e, _ in VARIANTS])
+def test_variant_keeps_parity(env, cfg):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", SNIPPET % (ROOT, ROOT, cfg)], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-600:])
