@@ -3,28 +3,43 @@
 
 One "step" = one pmr_chain_process_block_device() call: one block of synthetic cf32 IQ, already resident in
 HBM, through dc-block -> resample -> NCO -> M-channel polyphase channelizer -> NBFM discriminator for all M
-channels -> CTCSS high-pass -> gain -> de-emphasis -> int16 PCM (left in HBM).  The path shards by independent
-IQ stream: rank r owns stream r on GPU r, no data-path collective (torch.distributed is used only for the
-start/stop barrier and the max-over-ranks of the elapsed time).
+channels -> CTCSS high-pass -> gain -> de-emphasis -> int16 PCM (left in HBM).  Consecutive steps are NOT
+synchronised: they pipeline on the chain's two HIP streams, as a streaming receiver would run them.  The path shards
+by independent IQ stream: rank r owns stream r on GPU r, no data-path collective (torch.distributed is used only for
+the start/stop barrier and the max-over-ranks of the elapsed time).
+
+Headline workload (N = 1 and N > 1): cfg5 = BASELINE.json configs[4], the largest single-GPU configuration (the metric
+is quoted on no configuration; BASELINE.md calls cfg5 the HBM-roofline config).  At N = 1 the same line carries cfg2
+(configs[1]) and cfg3 (configs[2]) as "also" sub-records, each with its own roofline and parity check.
+
+The timed region (W warm-up steps, then exactly K steps between barrier + synchronize) is REPEATED `--regions` times;
+`value` / `ms_per_step` are the median region, `timed_regions` lists first / min / median / max.
+Outside the timed regions every workload is checked against the CPU oracle (`parity_checked`): un-synchronised
+pipelined calls on the bench block, int16 PCM within +-1 LSB.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (fs_in, M, default log2 block)  -- BASELINE.json configs
-    "cfg2": (2.4e6, 16, 26),      # configs[1]: 16-ch PMR446 chain @ 2.4 MS/s on one MI355X (the metric's config)
-    "cfg3": (61.44e6, 256, 26),   # configs[2]
-    "cfg5": (1.0e9, 1024, 26),    # configs[4]
+    # name: (fs_in, M, default log2 block, BASELINE.json configs index)
+    "cfg2": (2.4e6, 16, 26, 1),      # 16-ch PMR446 chain @ 2.4 MS/s on one MI355X
+    "cfg3": (61.44e6, 256, 26, 2),   # 256-ch channelizer + NBFM @ 61.44 MS/s (cfg4 = this, one stream per GPU)
+    "cfg5": (1.0e9, 1024, 26, 4),    # 1024-ch channelizer + demod @ 1 GS/s -- HBM-roofline config
 }
+HEADLINE = "cfg5"
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+KERNEL_SYMBOLS = ("slot k_frontend = k_frontend_fast<MODE,N3,TAIL> (specialised cascades; MODE 1 = level 1 of the two-level "
+                  "front end) or k_frontend<NT,SPT,MODE> in a rocprofv3 trace; k_fir_tm<hp> = k_fir_mfma16<...>")
 
 
 def _oracle_loop(fs, M, block_host, seconds_target, only_channel=-1):
@@ -53,96 +68,140 @@ import bench
 fs, M, n, secs = float(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])
 from sdr_pmr446_amd import synth
 x = synth.synth_iq(n, fs, M, stream_id=int(sys.argv[5]), channels=list(range(0, M, max(1, M // 16))))
-nb, npr, dt = bench._oracle_loop(fs, M, x, secs)
+nb, npr, dt = bench._oracle_loop(fs, M, x, secs, only_channel=int(sys.argv[6]))
 print(nb * npr, dt)
 """
 
 
-def cpu_baseline(fs, M, block_host, seconds_target=8.0):
-    """Time the CPU oracle (kind 'port': the reference itself needs liquid-dsp and cannot be built here) on a
-    bounded sample of the same workload: (i) single thread like the reference's DSP thread (src/sdr_pmr446.c:788) --
-    the headline `value`; (ii) N independent streams on N cores, the CPU analogue of one stream per GPU (SURVEY s8d);
-    (iii) the reference's own semantics, one squelch-selected channel demodulated (:876-877)."""
+def _native_oracle():
+    """Build the oracle with -march=native ON THIS MACHINE (bit-identical to the portable build, see
+    oracle/Makefile) for the cpu_baseline workers.  Returns (path or None, flags string)."""
     import subprocess
-    import sys
-    n_blocks, n_probe, dt = _oracle_loop(fs, M, block_host, seconds_target)
-    total = n_blocks * n_probe
-    out = {"value": total / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
-           "sample": "%d blocks x %d samples of the same synthetic IQ, all %d channels demodulated, %.1f s" %
-                     (n_blocks, n_probe, M, dt)}
-    nb1, np1, dt1 = _oracle_loop(fs, M, block_host, seconds_target / 2, only_channel=0)
-    out["one_channel"] = {"value": nb1 * np1 / dt1 / 1e6, "cores": 1,
+    try:
+        subprocess.check_call(["make", "-B", "-C", os.path.join(ROOT, "oracle"), "-s", "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=120)
+        p = os.path.join(ROOT, "oracle", "liboracle_pmr_native.so")
+        if os.path.exists(p):
+            return p, "gcc -O3 -march=native -ffp-contract=off"
+    except Exception:
+        pass
+    return None, "gcc -O3 -ffp-contract=off (portable build; -march=native build failed on this box)"
+
+
+def cpu_baseline(fs, M, seconds_target=8.0):
+    """Time the CPU oracle (kind 'port': the reference itself needs liquid-dsp and cannot be built here) on a
+    bounded sample of the same workload (1 Msample blocks of the same synthetic channel plan, one process per stream):
+    (i) single thread like the reference's DSP thread (src/sdr_pmr446.c:788) -- the headline `value`; (ii) N independent
+    streams on N cores, the CPU analogue of one stream per GPU; (iii) the reference's own semantics, one
+    squelch-selected channel demodulated (:876-877)."""
+    import subprocess
+    lib, flags = _native_oracle()
+    env = dict(os.environ)
+    if lib:
+        env["PMR_ORACLE_LIB"] = lib
+    n_probe = 1 << 20
+    host_cores = os.cpu_count() or 1
+
+    def workers(count, secs, only):
+        procs = [subprocess.Popen([sys.executable, "-c", _WORKER % ROOT, str(fs), str(M), str(n_probe), str(secs), str(i),
+                                   str(only)], stdout=subprocess.PIPE, cwd=ROOT, env=env) for i in range(count)]
+        outs = [p.communicate(timeout=300)[0].split() for p in procs]
+        return [(float(o[0]), float(o[1])) for o in outs]
+
+    (tot, dt), = workers(1, seconds_target, -1)
+    out = {"value": tot / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port", "host_cores": host_cores,
+           "build": flags,
+           "sample": "%d blocks x %d samples of the same synthetic channel plan, all %d channels demodulated, %.1f s" %
+                     (int(tot) // n_probe, n_probe, M, dt)}
+    (tot1, dt1), = workers(1, seconds_target / 2, 0)
+    out["one_channel"] = {"value": tot1 / dt1 / 1e6, "cores": 1,
                           "sample": "reference semantics: only the selected channel demodulated, %.1f s" % dt1}
     try:
-        ncores = min(len(os.sched_getaffinity(0)), 32)
+        ncores = len(os.sched_getaffinity(0))                           # every core this process may use
         if ncores > 1:
-            procs = [subprocess.Popen([sys.executable, "-c", _WORKER % ROOT, str(fs), str(M), str(n_probe),
-                                       str(seconds_target / 2), str(i)], stdout=subprocess.PIPE, cwd=ROOT)
-                     for i in range(ncores)]
-            rates = []
-            for p in procs:
-                o = p.communicate(timeout=120)[0].split()
-                rates.append(float(o[0]) / float(o[1]))
+            rates = [t / d for t, d in workers(ncores, seconds_target / 2, -1)]
             out["multi"] = {"value": sum(rates) / 1e6, "cores": ncores,
-                            "sample": "%d independent streams, one single-threaded oracle per core" % ncores}
+                            "sample": "%d independent streams, one single-threaded oracle per core (host has %d cores)"
+                                      % (ncores, host_cores)}
     except Exception as e:                                              # the single-thread figure stands on its own
         out["multi"] = {"value": None, "error": str(e)[:120]}
     return out
 
 
-def load_measured_traffic(kernel, workload, block):
+def load_measured_traffic(workload, block):
     """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE), if they were taken for this workload/block."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        e = t.get("%s/%s/%d" % (workload, kernel, block))
+        e = t.get("%s/k_frontend/%d" % (workload, block))
         return e["hbm_bytes_per_launch"] if e else None
     except Exception:
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--log2-block", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one "
-                                                          "GPU to exercise the N > 1 code path on a 1-GPU box")
-    ap.add_argument("--host-io", action="store_true",
-                    help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
-    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
-    args = ap.parse_args()
+def parity_check(ch, fs, M, iq, block, pcm_bufs, S, nblk):
+    """Outside the timed region: `nblk` consecutive process_block_device calls on the bench block, NOT synchronised in
+    between (the timed code path), PCM of every call vs the CPU oracle fed the same stream.  Returns the record."""
+    import numpy as np
+    import torch
+    import oracle
+    from sdr_pmr446_amd import synth
+    x_host = iq.cpu().numpy()
+    ref, err = [], []
 
+    def run_oracle():
+        try:
+            chunk = 1 << 22
+            o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=chunk)
+            for _ in range(nblk):
+                for p in range(0, block, chunk):
+                    ref.append(o.process_block(x_host[p:p + chunk], want=("pcm",))["pcm"])
+            o.close()
+        except Exception as e:                                          # reported below, never swallowed
+            err.append(repr(e))
+
+    th = threading.Thread(target=run_oracle)                            # ctypes releases the GIL: the oracle runs beside the GPU
+    t0 = time.perf_counter()
+    th.start()
+    ch.reset()
+    ns = []
+    for b in range(nblk):
+        ns.append(ch.process_block_device(iq.data_ptr(), block, d_pcm=pcm_bufs[b].data_ptr(), stride=S))
+    ch.synchronize()
+    got = torch.cat([pcm_bufs[b][:, :ns[b]] for b in range(nblk)], dim=1).cpu().numpy().astype(np.int32)
+    th.join()
+    if err:
+        return {"ok": False, "error": err[0]}
+    ref = np.concatenate(ref, axis=1).astype(np.int32)
+    act = [k for k in range(M) if synth.channel_kind(k) != "empty"]
+    ok = got.shape == ref.shape
+    d = int(np.abs(got[act] - ref[act]).max()) if ok else -1
+    return {"ok": bool(ok and d <= 1), "max_abs_pcm_diff_lsb": d, "tolerance_lsb": 1, "blocks": nblk,
+            "block_samples": block, "frames_checked": int(got.shape[1]), "channels_checked": len(act),
+            "mode": "consecutive process_block_device calls, no synchronisation in between, block pipelining on",
+            "oracle": "oracle.OracleChain (CPU restatement) on the same %d samples" % (nblk * block),
+            "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def measure(name, args, rank, local_rank, world, dist, dev, headline):
+    """One workload: synth the block in HBM, warm up, time `regions` x K un-synchronised steps, per-kernel breakdown,
+    parity check.  Returns the record (rank 0) or None."""
     import torch
     from sdr_pmr446_amd import chain as pmr
     from sdr_pmr446_amd import multigpu
     from sdr_pmr446_amd.synth_torch import synth_iq_torch
 
-    rank, local_rank, world = multigpu.env_world()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    if args.dist_backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()          # self-test only: ranks may share a device
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = multigpu.init_dist(args.dist_backend, dev)
-
-    fs, M, lb = WORKLOADS[args.workload]
+    fs, M, lb, cfg_idx = WORKLOADS[name]
     lb = args.log2_block if args.log2_block is not None else lb
     block = 1 << lb
-
     ch = pmr.PmrChain(fs_in=fs, num_channels=M, max_block=block, device=local_rank)
     S = ch.max_frames
     iq = synth_iq_torch(block, fs, M, dev, stream_id=multigpu.stream_id_for_rank(rank))   # resident in HBM before timing
-    pcm = torch.zeros((M, S), dtype=torch.int16, device=dev)        # PCM stays in HBM
+    nchk = max(1, args.parity_blocks)
+    pcm_bufs = [torch.zeros((M, S), dtype=torch.int16, device=dev) for _ in range(nchk)]   # PCM stays in HBM
+    pcm = pcm_bufs[0]
     torch.cuda.synchronize()
 
     def step():
@@ -152,7 +211,7 @@ def main():
         step()
     ch.synchronize()
     ch.profile_reset()
-    # HIP events in the timed region only around the roofline kernel (k_frontend): event records around all six
+    # HIP events in the timed region only around the roofline kernel (k_frontend): event records around all
     # kernels of a step cost 6-16 % of the step time (measured); the full per-kernel breakdown is taken right after
     ch.profile_enable(0 if args.no_kernel_events else 2)
 
@@ -163,7 +222,11 @@ def main():
         ch.synchronize()
         return n
 
-    dt, frames = multigpu.timed_region(run, dist, torch.cuda.synchronize, dev if args.dist_backend == "nccl" else None)
+    sync_dev = dev if args.dist_backend == "nccl" else None
+    dts, frames = [], 0
+    for _ in range(max(1, args.regions if headline or world == 1 else 1)):
+        dt, frames = multigpu.timed_region(run, dist, torch.cuda.synchronize, sync_dev)
+        dts.append(dt)
     ch.profile_enable(0)
     prof_roof = ch.profile()
     breakdown_steps = 0
@@ -178,76 +241,141 @@ def main():
         ch.synchronize()
         ch.profile_enable(0)
         ch.set_overlap(True)
-
     prof = ch.profile()
+
+    rec = None
     if rank == 0:
         r = M * 12500.0 / fs
         b_alg = 8.0 + 2.0 * r                                        # bytes per input sample
-        value = multigpu.aggregate_throughput(world, args.steps, block, dt) / 1e6
+        dt_med = statistics.median(dts)
+        value = multigpu.aggregate_throughput(world, args.steps, block, dt_med) / 1e6
         roof = None
         if prof_roof:
-            name, (ms, n) = max(prof_roof.items(), key=lambda kv: kv[1][0])
+            kname, (ms, n) = max(prof_roof.items(), key=lambda kv: kv[1][0])
             avg_s = ms / n * 1e-3
-            launches_per_step = n / args.steps
-            achieved = b_alg * block / launches_per_step / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": ms / n,
-                    "launches_per_step": launches_per_step,
-                    "algorithmic_bytes_per_sample": b_alg,
-                    "kernel_symbols": "slot k_frontend = k_frontend_fast<MODE,N3,TAIL> (specialised cascades) or "
-                                      "k_frontend<NT,SPT,MODE> in a rocprofv3 trace; k_fir_tm<hp> = k_fir_mfma16<...>",
-                    "kernels_ms_per_step_isolated": {k: v[0] / max(1, breakdown_steps)
-                                                     for k, v in sorted(prof.items())}}
-            iso = prof.get(name)
+            launches_per_step = n / (args.steps * len(dts))
+            achieved = b_alg * block / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": load_measured_traffic(name, block),
+                    "avg_kernel_ms": ms / n, "launches_timed": n, "launches_per_step": launches_per_step,
+                    "algorithmic_bytes_per_sample": b_alg, "algorithmic_bytes_per_launch": b_alg * block,
+                    "kernel_symbols": KERNEL_SYMBOLS,
+                    "kernels_ms_per_step_isolated": {k: v[0] / max(1, breakdown_steps) for k, v in sorted(prof.items())}}
+            iso = prof.get(kname)
             if iso and iso[1]:
                 iso_s = iso[0] / iso[1] * 1e-3
                 roof["isolated"] = {"avg_kernel_ms": iso[0] / iso[1], "achieved": b_alg * block / iso_s / 1e9,
                                     "frac": b_alg * block / iso_s / 1e9 / HBM_PEAK_GBPS,
                                     "note": "same kernel with block pipelining off (no other kernel sharing the GPU)"}
-            roof["traffic"] = load_measured_traffic(name, args.workload, block)
-        out = {
-            "metric": "complex-IQ Msamples/s through full channelize+demod chain", "value": value,
-            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d-ch PMR446 chain @ %.4g MS/s, one independent IQ stream per GPU" %
-                                   (args.workload, M, fs / 1e6),
+        ms_all = [d / args.steps * 1e3 for d in dts]
+        rec = {
+            "value": value, "unit": "Msamples/s", "ms_per_step": dt_med / args.steps * 1e3,
+            "timed_regions": {"n": len(dts), "steps_each": args.steps, "ms_per_step_first": ms_all[0],
+                              "ms_per_step_min": min(ms_all), "ms_per_step_median": statistics.median(ms_all),
+                              "ms_per_step_max": max(ms_all), "value_is": "median region"},
+            "config": {"workload": "%s (BASELINE.json configs[%d]): %d-ch PMR446 chain @ %.4g MS/s, one independent IQ "
+                                   "stream per GPU" % (name, cfg_idx, M, fs / 1e6),
                        "block_samples": block, "frames_per_step": frames // max(1, args.steps),
-                       "channels_demodulated": M, "hbm_frac_of_peak_whole_chain": value * 1e6 * b_alg / 1e9 / world / HBM_PEAK_GBPS},
+                       "channels_demodulated": M,
+                       "hbm_frac_of_peak_whole_chain": value * 1e6 * b_alg / 1e9 / world / HBM_PEAK_GBPS},
             "roofline": roof,
         }
-        if args.host_io and world == 1:
-            # PCIe-inclusive rate of pmr_chain_process_block (host cf32 in, host int16 out), never the headline value
-            import numpy as np
-            nb = min(block, 1 << 22)                                     # 2^22 samples per call
-            import ctypes
-            res = {}
-            pcm_h = torch.zeros((M, S), dtype=torch.int16)
-            ns_c = ctypes.c_uint(0)
-
-            def host_call(xn, pcm_t):
-                rc = ch._L.pmr_chain_process_block(ch.h, xn.ctypes.data, nb, pcm_t.data_ptr(), S, ctypes.byref(ns_c),
-                                                   None, None)
-                assert rc == 0, rc
-
-            for kind in ("pageable", "pinned"):
-                xh = iq[:nb].cpu()
-                if kind == "pinned":
-                    xh = xh.pin_memory()
-                xn = xh.numpy().view(np.complex64).reshape(-1)
-                pcm_t = pcm_h.pin_memory() if kind == "pinned" else pcm_h
-                host_call(xn, pcm_t)
-                t0 = time.perf_counter()
-                for _ in range(8):
-                    host_call(xn, pcm_t)
-                res[kind] = 8 * nb / (time.perf_counter() - t0) / 1e6
-            out["host_io"] = {"unit": "Msamples/s", "block_samples": nb, **res,
-                              "note": "synchronous pmr_chain_process_block: H2D + chain + D2H per call, no overlap"}
-        if world == 1 and not args.no_cpu_baseline:
-            n_cpu = min(block, 1 << 24)
-            out["cpu_baseline"] = cpu_baseline(fs, M, iq[:n_cpu].cpu().numpy())
-        print(json.dumps(out), flush=True)
+        if world == 1 and args.parity_blocks > 0:
+            rec["parity_checked"] = parity_check(ch, fs, M, iq, block, pcm_bufs, S, nchk)
+        if headline and args.host_io and world == 1:
+            rec["host_io"] = host_io(ch, iq, block, M, S)
+        if headline and world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(fs, M)
     ch.close()
+    del iq, pcm_bufs
+    torch.cuda.empty_cache()
+    return rec
+
+
+def host_io(ch, iq, block, M, S):
+    """PCIe-inclusive rate of the host-buffer entry points (host cf32 in, host int16 out), never the headline value."""
+    import ctypes
+    import numpy as np
+    import torch
+    nb = min(block, 1 << 22)                                     # SURVEY s8(d): 2^22 samples per call
+    res = {}
+    ns_c = ctypes.c_uint(0)
+    for kind in ("pageable", "pinned"):
+        xh = iq[:nb].cpu()
+        pcm_t = torch.zeros((M, S), dtype=torch.int16)
+        if kind == "pinned":
+            xh, pcm_t = xh.pin_memory(), pcm_t.pin_memory()
+        xn = xh.numpy().view(np.complex64).reshape(-1)
+
+        def host_call():
+            rc = ch._L.pmr_chain_process_block(ch.h, xn.ctypes.data, nb, pcm_t.data_ptr(), S, ctypes.byref(ns_c), None, None)
+            assert rc == 0, rc
+
+        host_call()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            host_call()
+        res[kind] = 8 * nb / (time.perf_counter() - t0) / 1e6
+    return {"unit": "Msamples/s", "block_samples": nb, **res,
+            "note": "synchronous pmr_chain_process_block: H2D + chain + D2H per call, no overlap between calls"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
+    ap.add_argument("--also", default=None, help="comma list of further workloads reported as sub-records "
+                                                 "(default at N = 1 with the default workload: cfg2,cfg3; 'none' disables)")
+    ap.add_argument("--regions", type=int, default=25, help="how often the timed K-step region is repeated")
+    ap.add_argument("--parity-blocks", type=int, default=4, help="blocks of the un-synchronised oracle check (0 = skip)")
+    ap.add_argument("--log2-block", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one "
+                                                          "GPU to exercise the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--host-io", action="store_true",
+                    help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    from sdr_pmr446_amd import multigpu
+
+    rank, local_rank, world = multigpu.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if args.dist_backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()          # self-test only: ranks may share a device
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = multigpu.init_dist(args.dist_backend, dev)
+
+    if args.also is None:
+        also = [w for w in ("cfg2", "cfg3") if w != args.workload] if (world == 1 and args.workload == HEADLINE) else []
+    else:
+        also = [w for w in args.also.split(",") if w in WORKLOADS and w != args.workload]
+
+    head = measure(args.workload, args, rank, local_rank, world, dist, dev, headline=True)
+    subs = {}
+    for w in also:
+        r = measure(w, args, rank, local_rank, world, dist, dev, headline=False)
+        if r is not None:
+            subs[w] = r
+    if rank == 0:
+        out = {"metric": "complex-IQ Msamples/s through full channelize+demod chain", "value": head["value"],
+               "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic"}
+        for k in ("timed_regions", "config", "roofline", "parity_checked", "host_io", "cpu_baseline"):
+            if k in head:
+                out[k] = head[k]
+        if subs:
+            out["also"] = subs
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -9,11 +9,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle_pmr.so")
+_DEFAULT_LIB = os.path.join(_HERE, "liboracle_pmr.so")
+# PMR_ORACLE_LIB: bench.py's cpu_baseline workers load the -march=native build made on the box they run on
+_LIB_PATH = os.environ.get("PMR_ORACLE_LIB") or _DEFAULT_LIB
 
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("orc_dsp.c", "orc_chain.c", "orc_dsd.c", "orc_dsp.h", "orc_chain.h", "orc_dsd.h")]
+    if _LIB_PATH != _DEFAULT_LIB:
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])

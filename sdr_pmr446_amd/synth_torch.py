@@ -12,14 +12,15 @@ from .synth import CHANNEL_WIDTH_HZ, CTCSS_FREQS, SEED_BASE, audio_tone_hz, chan
 
 
 def synth_iq_torch(n, fs_in, num_channels, device, stream_id=0, snr_db=30.0, dev_hz=2500.0, ctcss_dev_hz=300.0,
-                   chunk_elems=1 << 24):
-    """complex64 tensor [n] on `device` (viewable as float32 [n, 2], i.e. interleaved cf32)."""
+                   chunk_elems=1 << 24, channels=None):
+    """complex64 tensor [n] on `device` (viewable as float32 [n, 2], i.e. interleaved cf32).
+    channels: channel indices to synthesise (default all M); amplitudes / noise do not depend on it."""
     M = num_channels
     g = torch.Generator(device=device)
     g.manual_seed((SEED_BASE + stream_id) & 0x7FFFFFFFFFFFFFFF)
     amp = 0.5 / math.sqrt(M)
     sigma = math.sqrt(amp * amp / (10.0 ** (snr_db / 10.0)) * (fs_in / CHANNEL_WIDTH_HZ))
-    ks = [k for k in range(M) if channel_kind(k) != "empty"]
+    ks = [k for k in (range(M) if channels is None else channels) if channel_kind(k) != "empty"]
     fk = torch.tensor([(k - (M - 1) / 2.0) * CHANNEL_WIDTH_HZ for k in ks], dtype=torch.float64, device=device)
     fm_on = torch.tensor([1.0 if channel_kind(k) == "fm" else 0.0 for k in ks], dtype=torch.float64, device=device)
     fa = torch.tensor([audio_tone_hz(k) for k in ks], dtype=torch.float64, device=device)
