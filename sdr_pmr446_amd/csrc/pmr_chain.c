@@ -31,10 +31,10 @@
 typedef struct { float re, im; } cfl;
 
 enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
-       K_FE, K_FE_TILES, K_FE_FIX, K_FE_HIST, K_CHANNELIZE_SMALL, K_FE_L2, K_CT_FIR, K_CT_DC, K_CT_GOERTZEL, K_FE_TILEFIX, K_COUNT };
+       K_FE, K_FE_TILES, K_CHANNELIZE_SMALL, K_FE_L2, K_CT_FIR, K_CT_DC, K_CT_GOERTZEL, K_FE_TILEFIX, K_COUNT };
 static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
                                         "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
-                                        "k_fir_tm<lp>", "k_frontend", "k_fe_tiles", "k_fe_dcfix", "k_fe_hist",
+                                        "k_fir_tm<lp>", "k_frontend", "k_fe_carry",
                                         "k_channelize_small", "k_frontend<level2>", "k_fir_tm<ctcss_lp>",
                                         "k_ct_dc_*", "k_ct_goertzel+final", "k_fe_tilefix" };
 
@@ -78,9 +78,8 @@ struct pmr_chain_s {
     unsigned hp_len_raw;             /* length of the un-folded high-pass table (377)                 */
 
     /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
+    pmr_switches sw;                 /* A/B switches, read once from the environment at create */
     int chan_small;                  /* small-M channelizer (pmr_channelize_small.hip) selected       */
-    int fix_skip;
-    int fix_fused;                   /* dc carry applied by the channelizer while staging (else: k_fe_dcfix in place) */
     int fe_on, fe_nt, fe_spt;        /* fused path selected; threads per tile workgroup, samples per thread */
     int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
     int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
@@ -88,16 +87,15 @@ struct pmr_chain_s {
     float fe_taps_host[PMR_FE_MAX_STAGES * 64];
     float *d_fe_taps, *d_fe_GA, *d_fe_T1, *d_fe_T2, *d_fe_lam_lane;
     cfl *d_fe_hist[2], *d_fe_vstate[2], *d_fe_probeA, *d_fe_probeB, *d_fe_probeL, *d_fe_probeE, *d_fe_V[PIPE_DEPTH];
-    uint64_t *d_fe_stamps;           /* diagnostic per-phase cycle sums (PMR_FE_STAMP)                */
     /* two-level front end for deep cascades: level 1 = dc-block + first fe_s1 stages -> decimated ring, level 2 = rest */
     int fe_two;                      /* 1: two launches of k_frontend (modes 1 and 2)                 */
     int fe_s1;                       /* stages in level 1 (all 6-tap)                                  */
     int fe2_T_own, fe2_Hh, fe2_HhQ, fe2_TQ;   /* level-2 tile geometry, in level-1 output samples      */
+    int fe2_N0, fe2_fast;            /* level-2 tile size; specialised k_fe_level2 (m = 5, 10) selected   */
     float fe1_K;                     /* alpha * prod G_e (e < s1): dc-carry gain at the level-1 output */
     cfl *d_fe_ring1; uint64_t ring1_mask;
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
-    int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
-    int tilefix_on_backend, pend_tilefix; pmr_fe_tiles_params pend_t; pmr_fe_fix_params pend_f; unsigned pend_Q;
+    int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_tiles_params pend_t2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     unsigned fe_max_tiles;
 
@@ -256,8 +254,7 @@ static int fe_init(pmr_chain q)
     const unsigned h = d->num_stages, D = d->decim;
     int rc;
     q->fe_on = 0;
-    const char *env = getenv("PMR_FRONTEND");
-    if (env && !strcmp(env, "staged")) return PMR_OK;
+    if (q->sw.fe_staged) return PMR_OK;
     if (h > PMR_FE_MAX_STAGES) return PMR_OK;
 
     /* raw-sample history the cascade needs: S = sum_e (4 m_e - 2) 2^e (execution order) + 13 decimated samples */
@@ -268,17 +265,17 @@ static int fe_init(pmr_chain q)
     }
     unsigned long H = S + 13ul * D;
     unsigned long L = D > 16 ? D : 16;
-    /* Deep cascades: with 4096-sample tiles the halo H would eat the tile.  Split: level 1 = all but the last three
-     * stages (6-tap filters, halo 10*(2^s1 - 1) raw samples), level 2 = the last three stages + resampler on the
-     * 2^s1-times decimated stream.  Costs 16/2^s1 B per raw sample of extra HBM traffic, keeps 4 workgroups per CU. */
+    /* Deep cascades: with 4096-sample tiles the halo H would eat the tile.  Split: level 1 = dc-block + all but the last two
+     * stages (6-tap filters, halo 10*(2^s1 - 1) raw samples) -> decimated ring; level 2 = the m = 5 and m = 10 stages +
+     * resampler on the 2^s1-times decimated stream.  Costs 16/2^s1 B per raw sample of extra HBM traffic (1 B at s1 = 4). */
     q->fe_two = 0; q->fe_s1 = 0;
     {
-        const char *lv = getenv("PMR_FE_LEVELS");
-        const int want_two = lv ? atoi(lv) == 2 : (h >= 5 && (4096ul - (H < 4096ul ? H : 4096ul)) * 4 < 4096ul * 3);
+        const int want_two = q->sw.fe_levels ? q->sw.fe_levels == 2
+                                             : (h >= 5 && (4096ul - (H < 4096ul ? H : 4096ul)) * 4 < 4096ul * 3);
         if (want_two && h >= 4) {
             int ok = 1;
-            for (unsigned e = 0; e + 3 < h; e++) if (q->fe_m[e] != 3) ok = 0;
-            if (ok) { q->fe_two = 1; q->fe_s1 = (int)h - 3; }
+            for (unsigned e = 0; e + 2 < h; e++) if (q->fe_m[e] != 3) ok = 0;
+            if (ok) { q->fe_two = 1; q->fe_s1 = (int)h - 2; }
         }
     }
     const unsigned s1 = (unsigned)q->fe_s1, D1 = 1u << s1;
@@ -288,41 +285,21 @@ static int fe_init(pmr_chain q)
         H = S;
         L = D1 > 16 ? D1 : 16;
     }
-    int nt = 0, spt_sel = 16;
+    int nt = 0;
     unsigned long T_own = 0;
     {
-        /* tile geometries (threads x 16 samples): 256 -> 4096-sample tiles; 1024 -> 16384 (deep cascades);
-         * PMR_FE_GEOM=128x16 / 192x16 / 512x8 / 256x8 select experimental ones */
-        const char *gm = getenv("PMR_FE_GEOM");
-        int first = 256;
-        if (gm && !strcmp(gm, "128x16")) first = 128;
-        if (gm && !strcmp(gm, "192x16")) first = 192;
-        if (gm && !strcmp(gm, "256x8") && !q->fe_two) {
-            const unsigned long N0c = 2048;
-            if (N0c % L == 0 && H + L <= N0c && (N0c - H) / L * L * 2 >= N0c) { nt = 256; spt_sel = 8; T_own = (N0c - H) / L * L; }
-        }
-        const int cands[4] = { first, 256, 512, 1024 };
-        for (int ci = 0; ci < 4 && !nt; ci++) {
-            const int cand = cands[ci];
-            const unsigned long N0c = (unsigned long)cand * 16;
+        /* tile geometries (threads x 16 samples): 256 -> 4096-sample tiles; 1024 -> 16384 (cascades too deep for those) */
+        const int cands[2] = { 256, 1024 };
+        for (int ci = 0; ci < 2 && !nt; ci++) {
+            const unsigned long N0c = (unsigned long)cands[ci] * 16;
             if (N0c % L || H + L > N0c) continue;
             const unsigned long t = (N0c - H) / L * L;
-            const int last = cand == 1024;
-            const int mid = cand == 512 && gm && !strcmp(gm, "512x16");       /* 8192-sample tiles, 2 WGs per CU */
-            if (cand == 512 && !mid) continue;
-            if ((!last && !mid && t * 4 >= N0c * 3) || ((last || mid) && t * 2 >= N0c) ||
-                (cand == first && first != 256 && t * 2 >= N0c)) {
-                nt = cand; T_own = t;
-            }
+            if ((cands[ci] == 256 && t * 4 >= N0c * 3) || (cands[ci] == 1024 && t * 2 >= N0c)) { nt = cands[ci]; T_own = t; }
         }
     }
     if (!nt) return PMR_OK;                      /* cascade too deep for one LDS tile: staged path */
-    const unsigned long N0 = (unsigned long)nt * spt_sel;
-    q->fe_nt = nt; q->fe_spt = spt_sel;
-    if (nt == 256 && spt_sel == 16) {            /* alternative geometry for experiments: 512 threads x 8 samples */
-        const char *g = getenv("PMR_FE_GEOM");
-        if (g && !strcmp(g, "512x8")) { q->fe_nt = 512; q->fe_spt = 8; }   /* measured slower than 256 x 16 */
-    }
+    const unsigned long N0 = (unsigned long)nt * 16;
+    q->fe_nt = nt; q->fe_spt = 16;
     q->fe_T_own = (int)T_own;
     const unsigned Dl = q->fe_two ? D1 : D;       /* decimation of the (first) level */
     q->fe_Hh = (int)(N0 - T_own);
@@ -336,9 +313,13 @@ static int fe_init(pmr_chain q)
         unsigned long S2 = 0;
         for (unsigned e = s1; e < h; e++) S2 += (unsigned long)(4 * q->fe_m[e] - 2) << (e - s1);
         const unsigned long H2 = S2 + 13ul * D2, L2 = D2 > 16 ? D2 : 16;
-        if (H2 + L2 > 4096) return PMR_OK;
-        const unsigned long t2 = (4096 - H2) / L2 * L2;
-        q->fe2_T_own = (int)t2; q->fe2_Hh = (int)(4096 - t2); q->fe2_HhQ = q->fe2_Hh / (int)D2; q->fe2_TQ = (int)(t2 / D2);
+        /* level-2 tile: 2048 ring samples for the specialised kernel (m = 5, 10: k_fe_level2), 4096 for the generic one */
+        q->fe2_fast = (h - s1 == 2 && q->fe_m[s1] == 5 && q->fe_m[s1 + 1] == 10 && !q->sw.fe_generic);
+        const unsigned long N2 = q->fe2_fast ? 2048 : 4096;
+        if (H2 + L2 > N2) return PMR_OK;
+        const unsigned long t2 = (N2 - H2) / L2 * L2;
+        q->fe2_N0 = (int)N2;
+        q->fe2_T_own = (int)t2; q->fe2_Hh = (int)(N2 - t2); q->fe2_HhQ = q->fe2_Hh / (int)D2; q->fe2_TQ = (int)(t2 / D2);
         uint64_t need = (uint64_t)q->fe2_Hh + D2 + (uint64_t)PIPE_DEPTH * ((q->cfg.max_block >> s1) + 2) + 64, cap = 1;
         while (cap < need) cap <<= 1;
         q->ring1_mask = cap - 1;
@@ -541,21 +522,32 @@ static int chain_init(pmr_chain q)
     if ((rc = dev_alloc(q, (void **)&q->d_rssi_part, q->rssi_part_cap * sizeof(float)))) return rc;
 
     if ((rc = fe_init(q))) return rc;
-    {
-        const char *env = getenv("PMR_CHANNELIZER");
-        q->chan_small = !(env && !strcmp(env, "generic")) && pmr_channelize_small_supported(M, p, d->nco_period);
-        const char *ff = getenv("PMR_DCFIX_FUSE");
-        q->fix_fused = ff ? atoi(ff) != 0 : 0;   /* default: k_fe_tilefix corrects in place right after the front end */
-        q->fix_skip = getenv("PMR_NOFIX") != NULL;      /* timing experiment only: results are wrong */
-        /* PMR_TILEFIX_STREAM=be runs the carry kernel on the back-end stream: measured slower (the back end becomes the
-         * critical path: cfg2 256 vs 269 GS/s), so the front-end stream keeps it */
-        { const char *l2 = getenv("PMR_L2_STREAM"); q->l2_on_backend = !(l2 && !strcmp(l2, "fe")); }
-        { const char *tb = getenv("PMR_TILEFIX_STREAM"); q->tilefix_on_backend = (tb && !strcmp(tb, "be")); }
-    }
+    q->chan_small = !q->sw.chan_generic && pmr_channelize_small_supported(M, p, d->nco_period);
+    q->l2_on_backend = !q->sw.l2_on_fe;
 
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "init sync");
     return PMR_OK;
+}
+
+/* The A/B switches of DESIGN.md 7a: read from the environment ONCE per handle, here; nothing on a launch path calls getenv. */
+static int env_is(const char *name, const char *val) { const char *e = getenv(name); return e && !strcmp(e, val); }
+static void read_switches(pmr_switches *w)
+{
+    memset(w, 0, sizeof(*w));
+    w->fe_staged = env_is("PMR_FRONTEND", "staged");
+    w->fe_generic = env_is("PMR_FE_KERNEL", "generic");
+    { const char *e = getenv("PMR_FE_LEVELS"); w->fe_levels = e ? atoi(e) : 0; }
+    w->l2_on_fe = env_is("PMR_L2_STREAM", "fe");
+    w->chan_generic = env_is("PMR_CHANNELIZER", "generic");
+    w->chan_pair = env_is("PMR_CHANNELIZER_SMALL", "pair");
+    { const char *e = getenv("PMR_CHAN_FT"); w->chan_ft = e ? atoi(e) : 0; }
+    w->fir_mode = env_is("PMR_FIR", "pair") ? PMR_FIR_PAIR : env_is("PMR_FIR", "lds") ? PMR_FIR_LDS
+                : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
+    w->fir_mfma_global = env_is("PMR_FIR_MFMA", "global");
+    { const char *e = getenv("PMR_FIR_TPW"); w->fir_tpw = e ? atoi(e) : 2; }
+    w->no_overlap = env_is("PMR_OVERLAP", "0");
+    w->equal_prio = env_is("PMR_STREAM_PRIO", "0");
 }
 
 static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only);
@@ -572,6 +564,7 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
     pmr_chain q = (pmr_chain)calloc(1, sizeof(*q));
     if (!q) return NULL;
     q->cfg = *cfg;
+    read_switches(&q->sw);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         fprintf(stderr, "pmr_chain_create: no HIP device (this library has no CPU path)\n");
@@ -595,7 +588,7 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
      * longer kernel -- fills every CU slot they leave. */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       /* numerically lower = higher priority */
-    { const char *pe = getenv("PMR_STREAM_PRIO"); if (pe && !strcmp(pe, "0")) prio_hi = prio_lo; }
+    if (q->sw.equal_prio) prio_hi = prio_lo;
     if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_lo) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
@@ -606,7 +599,7 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
             pmr_design_free(&q->d); free(q); return NULL;
         }
     }
-    { const char *ov = getenv("PMR_OVERLAP"); q->overlap = !(ov && !strcmp(ov, "0")); }
+    q->overlap = !q->sw.no_overlap;
     if (chain_init(q) != PMR_OK) {
         fprintf(stderr, "pmr_chain_create: %s\n", q->err);
         pmr_chain_destroy(q);
@@ -648,11 +641,13 @@ int pmr_chain_reset(pmr_chain q)
     if (!q) return PMR_EINVAL;
     const unsigned M = q->M, h = q->d.num_stages;
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    /* in-flight work of un-synchronised device calls (front end on stream_fe, back end on stream) finishes first:
+     * nothing may overwrite the zeroed state afterwards */
+    HIPCHK(hipStreamSynchronize(q->stream_fe), "reset");
+    HIPCHK(hipStreamSynchronize(q->stream), "reset");
     HIPCHK(hipMemsetAsync(q->d_dc_state, 0, sizeof(cfl), q->stream), "reset");
     for (unsigned e = 0; e <= h; e++)
         HIPCHK(hipMemsetAsync(q->d_z[e], 0, (size_t)q->keep[e] * sizeof(cfl), q->stream), "reset");
-    HIPCHK(hipStreamSynchronize(q->stream_fe), "reset");
-    HIPCHK(hipStreamSynchronize(q->stream), "reset");
     HIPCHK(hipMemsetAsync(q->d_xr, 0, (size_t)(q->xr_mask + 1) * sizeof(cfl), q->stream), "reset");
     HIPCHK(hipMemsetAsync(q->d_fm, 0, (size_t)(q->fm_mask + 1) * M * sizeof(float), q->stream), "reset");
     if (q->d_aux1) {
@@ -672,7 +667,7 @@ int pmr_chain_reset(pmr_chain q)
     }
     q->fe_sel = 0;
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
-    q->pend_l2 = 0; q->pend_tilefix = 0;
+    q->pend_l2 = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
     return PMR_OK;
 }
@@ -772,7 +767,32 @@ static void fe_fill_taps(const struct pmr_chain_s *q, pmr_fe_params *p, unsigned
     p->taps_valid = 1;
 }
 
-/* front end, fused: one pass over the raw block (pmr_frontend.hip) */
+/* carry bookkeeping shared by the fused and the two-level front end: parameters of the tile-carry sum (k_fe_tiles /
+ * k_fe_tilefix / k_fe_carry) for a launch of `ntiles` tiles whose first tile starts `pend` samples before the block */
+static void fe_carry_params(const struct pmr_chain_s *q, pmr_fe_tiles_params *t, unsigned slot, unsigned ntiles, unsigned c_end,
+                            int off_end, unsigned pend, int cur, int nxt)
+{
+    const double lam = q->d.dc_lambda;
+    memset(t, 0, sizeof(*t));
+    t->probeA = q->d_fe_probeA + (size_t)slot * q->fe_max_tiles; t->probeB = q->d_fe_probeB + (size_t)slot * q->fe_max_tiles;
+    t->probeL = q->d_fe_probeL + slot; t->probeE = q->d_fe_probeE + slot;
+    t->v_in = q->d_fe_vstate[cur]; t->v_out = q->d_fe_vstate[nxt]; t->V = q->d_fe_V[slot];
+    t->ntiles = ntiles; t->K = q->fe_K; t->c_end = c_end;
+    t->rho = (float)pow(lam, (double)q->fe_T_own);
+    t->lamHh = (float)pow(lam, (double)q->fe_Hh); t->inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
+    t->inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend)); t->lamEnd = (float)pow(lam, (double)off_end + 1.0);
+    t->rho_pow = q->d_fe_rho_pow;
+    t->tile_j = q->d_fe_tile_j + (size_t)slot * 2 * q->fe_max_tiles;
+}
+
+/* floor(2^56 / step), clamped to 32 bits: the kernels' integer ceil-division by the resampler step (no fp64 on the device) */
+static uint32_t step_rinv(uint32_t step)
+{
+    const uint64_t r = step ? (1ull << 56) / step : 0;
+    return r > 0xffffffffull ? 0xffffffffu : (uint32_t)r;
+}
+
+/* front end, fused: one pass over the raw block (pmr_fe_fast.hip / pmr_frontend.hip) */
 static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny_out)
 {
     const pmr_design *d = &q->d;
@@ -789,67 +809,41 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     const int off_end = (int)((total - 1) - (unsigned long)c_end * q->fe_T_own) + q->fe_Hh;
     if (ntiles > q->fe_max_tiles) return fail(q, PMR_ERANGE, "tile count", hipSuccess);
     const int cur = q->fe_sel, nxt = cur ^ 1;
+    const unsigned slot = (unsigned)(q->n_calls % PIPE_DEPTH);
 
+    pmr_fe_tiles_params t;
+    fe_carry_params(q, &t, slot, ntiles, c_end, off_end, pend, cur, nxt);
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
     p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr; p.out_pos0 = q->xr_abs; p.out_mask = q->xr_mask;
-    const unsigned slot = (unsigned)(q->n_calls % PIPE_DEPTH);
-    cfl *prA = q->d_fe_probeA + (size_t)slot * q->fe_max_tiles, *prB = q->d_fe_probeB + (size_t)slot * q->fe_max_tiles;
-    cfl *prL = q->d_fe_probeL + slot, *prE = q->d_fe_probeE + slot;
-    uint64_t *tj = q->d_fe_tile_j + (size_t)slot * 2 * q->fe_max_tiles;
-    p.probeA = prA; p.probeB = prB; p.probeL = prL; p.probeE = prE;
-    p.tile_j = tj;
+    p.probeA = (void *)t.probeA; p.probeB = (void *)t.probeB; p.probeL = (void *)t.probeL; p.probeE = (void *)t.probeE;
+    p.tile_j = (void *)t.tile_j;
     p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
-    p.n_in = n_in; p.ny = ny; p.Q = Q; p.phi0 = q->arb_phase; p.step = d->arb_step;
+    p.n_in = n_in; p.ny = ny; p.Q = Q; p.phi0 = q->arb_phase; p.step = d->arb_step; p.step_rinv = step_rinv(d->arb_step);
     p.h = (int)h; p.T_own = q->fe_T_own; p.Hh = q->fe_Hh; p.HhQ = q->fe_HhQ; p.TQ = q->fe_TQ;
     p.pend = (int)pend; p.hcap = q->fe_hcap; p.c_end = (int)c_end; p.off_end = off_end;
     memcpy(p.m, q->fe_m, sizeof(p.m)); memcpy(p.tap_off, q->fe_tap_off, sizeof(p.tap_off));
     p.dc_a1 = d->dc_a1; p.zeta = d->zeta; p.lam_wave = q->fe_lam_wave;
-    { const char *ab = getenv("PMR_FE_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
-    if (getenv("PMR_FE_STAMP")) {
-        if (!q->d_fe_stamps) { int rc_ = dev_alloc(q, (void **)&q->d_fe_stamps, 8 * sizeof(uint64_t)); if (rc_) return rc_; }
-        p.stamps = q->d_fe_stamps;
-    }
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     fe_fill_taps(q, &p, 0, h);
-    LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles, q->fe_nt, q->fe_spt));
+    LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic));
 
-    pmr_fe_tiles_params t;
-    memset(&t, 0, sizeof(t));
-    const double lam = d->dc_lambda;
-    const double rho = pow(lam, (double)q->fe_T_own);
-    double kterms = rho > 0.0 && rho < 1.0 ? ceil(log(1e-12) / log(rho)) : 1.0;
-    if (kterms < 1.0) kterms = 1.0;
-    if (kterms > 1e6) kterms = 1e6;
-    t.probeA = prA; t.probeB = prB; t.probeL = prL; t.probeE = prE;
-    t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V[q->n_calls % PIPE_DEPTH];
-    t.ntiles = ntiles; t.K = (unsigned)kterms; t.c_end = c_end;
-    t.rho = (float)rho; t.lamHh = (float)pow(lam, (double)q->fe_Hh); t.inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
-    t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
-    if (t.K > q->fe_K) t.K = q->fe_K;
-    t.rho_pow = q->d_fe_rho_pow; t.tile_j = tj;
     pmr_fe_fix_params f;
     memset(&f, 0, sizeof(f));
-    f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[q->n_calls % PIPE_DEPTH]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
+    f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[slot]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
     f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
     f.Kgain = q->fe_Kgain;
-    if (q->chan_small && q->fix_fused && !q->dbg_on) {
-        /* older arrangement: carries only; the small-M channelizer applies them while staging (+ a tail fix afterwards) */
-        LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
-    } else if (q->tilefix_on_backend) {
-        /* experiment: carries + correction deferred to the BACK-END stream (its first consumer step) */
-        q->pend_t = t; q->pend_f = f; q->pend_Q = Q; q->pend_tilefix = 1;
-    } else {
-        LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream_fe, &t, &f, Q));
-    }
+    LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream_fe, &t, &f, Q));
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
     *ny_out = ny;
     return PMR_OK;
 }
 
-/* front end, two levels (deep cascades): level 1 = dc-block + first s1 stages -> d_fe_ring1; level 2 = remaining
- * stages + resampler reading that ring (pmr_frontend.hip modes 1 and 2) */
+/* front end, two levels (deep cascades): level 1 = dc-block + first s1 (six-tap) stages -> d_fe_ring1 on the FRONT-END
+ * stream; then, on the back-end stream when there is one (`defer`), k_fe_carry (tile carries of level 1 + in-place dc fix of
+ * the ring tail the next call re-reads as history) and level 2 = remaining stages + resampler reading that ring with the
+ * carry applied at load (k_fe_level2, or the generic k_frontend in mode 2). */
 static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny_out)
 {
     const pmr_design *d = &q->d;
@@ -863,7 +857,7 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     unsigned ny = 0, ns_unused = 0; uint32_t new_phase = 0;
     plan_core(h, d->arb_step, q->M, q->n_raw, q->arb_phase, 0, n_in, &ny, &ns_unused, &new_phase);
     const int cur = q->fe_sel, nxt = cur ^ 1;
-    const unsigned par = (unsigned)(q->n_calls % PIPE_DEPTH);
+    const unsigned slot = (unsigned)(q->n_calls % PIPE_DEPTH);
 
     /* ---- level 1 ---- */
     const unsigned long total1 = (unsigned long)pend1 + n_in;
@@ -871,12 +865,14 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     const unsigned c_end = (unsigned)((total1 - 1) / q->fe_T_own);
     const int off_end = (int)((total1 - 1) - (unsigned long)c_end * q->fe_T_own) + q->fe_Hh;
     if (ntiles1 > q->fe_max_tiles) return fail(q, PMR_ERANGE, "tile count", hipSuccess);
+    pmr_fe_tiles_params t;
+    fe_carry_params(q, &t, slot, ntiles1, c_end, off_end, pend1, cur, nxt);
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
     p.mode = 1;
     p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt];
     p.out = q->d_fe_ring1; p.out_pos0 = A; p.out_mask = q->ring1_mask;
-    p.probeA = q->d_fe_probeA; p.probeB = q->d_fe_probeB; p.probeL = q->d_fe_probeL; p.probeE = q->d_fe_probeE;
+    p.probeA = (void *)t.probeA; p.probeB = (void *)t.probeB; p.probeL = (void *)t.probeL; p.probeE = (void *)t.probeE;
     p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
     p.n_in = n_in; p.ny = 0; p.Q = Q1; p.phi0 = 0; p.step = 1;
     p.h = (int)s1; p.T_own = q->fe_T_own; p.Hh = q->fe_Hh; p.HhQ = q->fe_HhQ; p.TQ = q->fe_TQ;
@@ -885,59 +881,43 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     p.dc_a1 = d->dc_a1; p.zeta = 1.0f; p.lam_wave = q->fe_lam_wave;
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     fe_fill_taps(q, &p, 0, s1);
-    LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles1, 256, 16));
+    LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles1, 256, 16, q->sw.fe_generic));
 
-    pmr_fe_tiles_params t;
-    memset(&t, 0, sizeof(t));
-    const double lam = d->dc_lambda;
-    const double rho = pow(lam, (double)q->fe_T_own);
-    double kterms = rho > 0.0 && rho < 1.0 ? ceil(log(1e-12) / log(rho)) : 1.0;
-    if (kterms < 1.0) kterms = 1.0;
-    if (kterms > 1e6) kterms = 1e6;
-    t.probeA = q->d_fe_probeA; t.probeB = q->d_fe_probeB; t.probeL = q->d_fe_probeL; t.probeE = q->d_fe_probeE;
-    t.v_in = q->d_fe_vstate[cur]; t.v_out = q->d_fe_vstate[nxt]; t.V = q->d_fe_V[par];
-    t.ntiles = ntiles1; t.K = (unsigned)kterms; t.c_end = c_end;
-    t.rho = (float)rho; t.lamHh = (float)pow(lam, (double)q->fe_Hh); t.inv_lamHh = (float)pow(lam, -(double)q->fe_Hh);
-    t.inv_lamL = (float)pow(lam, -(double)(q->fe_Hh + (int)pend1)); t.lamEnd = (float)pow(lam, (double)off_end + 1.0);
-    LAUNCH_FE(K_FE_TILES, pmr_launch_fe_tiles(q->stream_fe, &t));
+    /* ---- carries of level 1 + in-place fix of the ring tail: the last `keep` new samples are what the NEXT call's level 2
+     * re-reads as history; level 2 of THIS call skips them (fix_limit) and corrects everything before them at load ---- */
+    const unsigned keep = (unsigned)q->fe2_Hh + D2 + 16;
+    pmr_fe_fix_params f;
+    memset(&f, 0, sizeof(f));
+    f.xr = q->d_fe_ring1; f.pos0 = A; f.mask = q->ring1_mask; f.V = q->d_fe_V[slot]; f.GA = q->d_fe_GA;
+    f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2; f.ny = Q1; f.j0 = Q1 > keep ? Q1 - keep : 0;
+    f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = 0; f.step = 0; f.Kgain = q->fe1_K;
 
     /* ---- level 2: Q1 new samples of the decimated ring -> last h2 stages -> resampler ---- */
-    if (Q1) {
-        const unsigned pend2 = (unsigned)(A & (D2 - 1));
-        const unsigned long total2 = (unsigned long)pend2 + Q1;
-        const unsigned ntiles2 = (unsigned)((total2 + q->fe2_T_own - 1) / q->fe2_T_own);
-        pmr_fe_params p2;
-        memset(&p2, 0, sizeof(p2));
-        p2.mode = 2;
-        p2.in_ring = q->d_fe_ring1; p2.in_mask = q->ring1_mask; p2.in_abs0 = (int64_t)A;
-        p2.fixV = q->d_fe_V[par]; p2.fix_T1 = q->d_fe_T1; p2.fix_T2 = q->d_fe_T2;
-        p2.fix_TQ = (unsigned)q->fe_TQ; p2.fix_HhQ = (unsigned)q->fe_HhQ; p2.fix_K = q->fe1_K;
-        p2.out = q->d_xr; p2.out_pos0 = q->xr_abs; p2.out_mask = q->xr_mask;
-        p2.hb_taps = q->d_fe_taps; p2.arb_bank = q->d_arb_bank; p2.lam_lane_pow = q->d_fe_lam_lane;
-        p2.n_in = Q1; p2.ny = ny; p2.Q = Q; p2.phi0 = q->arb_phase; p2.step = d->arb_step;
-        p2.h = (int)h2; p2.T_own = q->fe2_T_own; p2.Hh = q->fe2_Hh; p2.HhQ = q->fe2_HhQ; p2.TQ = q->fe2_TQ;
-        p2.pend = (int)pend2; p2.hcap = 0; p2.c_end = (int)ntiles2 - 1; p2.off_end = 0;
-        for (unsigned e = 0; e < h2; e++) { p2.m[e] = q->fe_m[s1 + e]; p2.tap_off[e] = q->fe_tap_off[s1 + e]; }
-        p2.dc_a1 = d->dc_a1; p2.zeta = d->zeta; p2.lam_wave = q->fe_lam_wave;
-        memcpy(p2.lam_pow16, q->fe_lam_pow16, sizeof(p2.lam_pow16));
-        fe_fill_taps(q, &p2, s1, h2);
-        (void)D2;
-        /* Level 2 (and the ring fix-up after it) belong to the BACK-END stream when there is one: level 2 touches 1/2^s1 of
-         * the data in a few thousand tiles -- too few to fill the chip -- so it runs best under the next block's level 1
-         * instead of between two level-1 launches on the same stream. */
-        const int defer = q->l2_on_backend;
-        if (defer) { q->pend_p2 = p2; q->pend_ntiles2 = ntiles2; }
-        else LAUNCH_FE(K_FE_L2, pmr_launch_frontend(q->stream_fe, &p2, ntiles2, 256, 16));
-
-        /* level 2 corrected its private copy; what the next call re-reads as history gets its dc carry in place */
-        const unsigned keep = (unsigned)q->fe2_Hh + D2 + 16;
-        pmr_fe_fix_params f;
-        memset(&f, 0, sizeof(f));
-        f.xr = q->d_fe_ring1; f.pos0 = A; f.mask = q->ring1_mask; f.V = q->d_fe_V[par]; f.GA = q->d_fe_GA;
-        f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2; f.ny = Q1; f.j0 = Q1 > keep ? Q1 - keep : 0;
-        f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = 0; f.step = 0; f.Kgain = q->fe1_K;
-        if (defer) { q->pend_f2 = f; q->pend_l2 = 1; }
-        else LAUNCH_FE(K_FE_FIX, pmr_launch_fe_dcfix(q->stream_fe, &f));
+    const unsigned pend2 = (unsigned)(A & (D2 - 1));
+    const unsigned long total2 = (unsigned long)pend2 + Q1;
+    const unsigned ntiles2 = Q1 ? (unsigned)((total2 + q->fe2_T_own - 1) / q->fe2_T_own) : 0;
+    pmr_fe_params p2;
+    memset(&p2, 0, sizeof(p2));
+    p2.mode = 2;
+    p2.in_ring = q->d_fe_ring1; p2.in_mask = q->ring1_mask; p2.in_abs0 = (int64_t)A;
+    p2.fixV = q->d_fe_V[slot]; p2.fix_T1 = q->d_fe_T1; p2.fix_T2 = q->d_fe_T2;
+    p2.fix_TQ = (unsigned)q->fe_TQ; p2.fix_HhQ = (unsigned)q->fe_HhQ; p2.fix_K = q->fe1_K; p2.fix_limit = f.j0;
+    p2.out = q->d_xr; p2.out_pos0 = q->xr_abs; p2.out_mask = q->xr_mask;
+    p2.hb_taps = q->d_fe_taps; p2.arb_bank = q->d_arb_bank; p2.lam_lane_pow = q->d_fe_lam_lane;
+    p2.n_in = Q1; p2.ny = ny; p2.Q = Q; p2.phi0 = q->arb_phase; p2.step = d->arb_step; p2.step_rinv = step_rinv(d->arb_step);
+    p2.h = (int)h2; p2.T_own = q->fe2_T_own; p2.Hh = q->fe2_Hh; p2.HhQ = q->fe2_HhQ; p2.TQ = q->fe2_TQ;
+    p2.pend = (int)pend2; p2.hcap = 0; p2.c_end = (int)ntiles2 - 1; p2.off_end = 0;
+    for (unsigned e = 0; e < h2; e++) { p2.m[e] = q->fe_m[s1 + e]; p2.tap_off[e] = q->fe_tap_off[s1 + e]; }
+    p2.dc_a1 = d->dc_a1; p2.zeta = d->zeta; p2.lam_wave = q->fe_lam_wave;
+    memcpy(p2.lam_pow16, q->fe_lam_pow16, sizeof(p2.lam_pow16));
+    fe_fill_taps(q, &p2, s1, h2);
+    if (q->l2_on_backend) {
+        /* Level 2 touches 1/2^s1 of the data in a few thousand tiles -- too few to fill the chip -- so it runs best under the
+         * next block's level 1 instead of between two level-1 launches on the same stream. */
+        q->pend_t2 = t; q->pend_f2 = f; q->pend_p2 = p2; q->pend_ntiles2 = ntiles2; q->pend_l2 = 1;
+    } else {
+        LAUNCH_FE(K_FE_TILES, pmr_launch_fe_carry(q->stream_fe, &t, &f));
+        if (ntiles2) LAUNCH_FE(K_FE_L2, pmr_launch_frontend_l2(q->stream_fe, &p2, ntiles2, q->fe2_fast));
     }
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
@@ -955,14 +935,10 @@ int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsig
     plan_counts(q, n_in, &ny_plan, &ns_plan);
     if (ny_plan > q->res_size) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
     *xr_abs0 = q->xr_abs;
-    const int keep_dbg = q->dbg_on, keep_tb = q->tilefix_on_backend, keep_l2 = q->l2_on_backend;
-    q->dbg_on = 1;
-    q->l2_on_backend = 0;
-    q->tilefix_on_backend = 0;                    /* this entry point has no back-end stream: everything on stream_fe */                                /* forces the in-place dc fix even if a fused consumer exists */
+    const int keep_l2 = q->l2_on_backend;
+    q->l2_on_backend = 0;                         /* this entry point has no back-end stream: everything on stream_fe */
     int rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                        : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny);
-    q->dbg_on = keep_dbg;
-    q->tilefix_on_backend = keep_tb;
     q->l2_on_backend = keep_l2;
     if (rc) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
@@ -988,7 +964,7 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns)
 {
     const unsigned M = q->M, N = PMR_CT_BLOCK;
     /* tmp1 = delay188(fm) - hp(fm) (:884-889) as one FIR with taps delta_188 - h */
-    LAUNCH(K_CT_FIR, pmr_launch_fir_tm(q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
+    LAUNCH(K_CT_FIR, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
                                        0.f, 0.f, 0.f, q->d_ctlp, NULL, NULL, 0));
     const float a1 = -1.0f + 0.0005f;                              /* iirfilt_rrrf_create_dc_blocker(0.0005f), :450 */
     const double lam = -(double)a1;
@@ -1109,7 +1085,6 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
     if (q->n_calls >= PIPE_DEPTH) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
     if (!q->overlap && q->n_calls >= 1)
         HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[(q->n_calls - 1) % PIPE_DEPTH], 0), "wait back end");
-    const uint32_t phi0 = q->arb_phase;          /* resampler phase before this block (dc carry bookkeeping) */
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
     if ((rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
@@ -1124,12 +1099,8 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
     HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
     if (q->pend_l2) {
         q->pend_l2 = 0;
-        LAUNCH(K_FE_L2, pmr_launch_frontend(q->stream, &q->pend_p2, q->pend_ntiles2, 256, 16));
-        LAUNCH(K_FE_FIX, pmr_launch_fe_dcfix(q->stream, &q->pend_f2));
-    }
-    if (q->pend_tilefix) {
-        q->pend_tilefix = 0;
-        LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t, &q->pend_f, q->pend_Q));
+        LAUNCH(K_FE_TILES, pmr_launch_fe_carry(q->stream, &q->pend_t2, &q->pend_f2));
+        if (q->pend_ntiles2) LAUNCH(K_FE_L2, pmr_launch_frontend_l2(q->stream, &q->pend_p2, q->pend_ntiles2, q->fe2_fast));
     }
     if (q->dbg_on && ny)
         if ((rc = ring_to_linear(q, q->d_dbg_xr, q->d_xr, q->xr_mask, xr_abs0, ny, sizeof(cfl)))) return rc;
@@ -1149,17 +1120,8 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         c.taps_t = q->d_pfb_taps_t; c.fft_tw = q->d_fft_tw; c.nco_cs = q->d_nco_cs; c.nco_period = d->nco_period;
         c.fm_ref = d->fm_ref; c.chan_out = d_chan_out; c.chan_stride = pcm_stride;
         c.rssi_part = d_rssi_db ? q->d_rssi_part : NULL;
-        if (q->chan_small) {
-            const int fuse_fix = q->fe_on && !q->fe_two && ny && !q->dbg_on && q->fix_fused && !q->fix_skip;
-            if (fuse_fix) {                      /* deferred dc carry of the fused front end, applied while staging */
-                c.V = q->d_fe_V[par]; c.GA = q->d_fe_GA; c.T1 = q->d_fe_T1; c.T2 = q->d_fe_T2;
-                c.fix_abs0 = xr_abs0; c.fix_ny = ny; c.TQ = (unsigned)q->fe_TQ; c.HhQ = (unsigned)q->fe_HhQ;
-                c.phi0 = phi0; c.step = d->arb_step; c.Kgain = q->fe_Kgain;
-            }
-            LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles));
-        } else {
-            LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles));
-        }
+        if (q->chan_small) LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles, q->sw.chan_pair));
+        else LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles, q->sw.chan_ft));
         if (q->dbg_on) {
             /* discriminator rows of this block, time-major, linearised */
             if ((rc = ring_to_linear(q, q->d_dbg_fm, q->d_fm, q->fm_mask, (uint64_t)frame0, ns, (size_t)M * sizeof(float))))
@@ -1173,36 +1135,25 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906) */
         if (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass) {
             const int more = q->cfg.deemph_fir || q->cfg.lowpass;
-            LAUNCH(K_FIR_HP, pmr_launch_fir_tm(q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
+            LAUNCH(K_FIR_HP, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
                                                1.0f, 0, 0.f, 0.f, 0.f,      /* gain + de-emphasis are in the taps */
                                                more ? q->d_aux1 : NULL, more ? NULL : (int16_t *)d_pcm,
                                                more ? NULL : (float *)d_audio, pcm_stride));
             const float *cur = q->d_aux1;
             if (q->cfg.deemph_fir) {
                 const int last = !q->cfg.lowpass;
-                LAUNCH(K_FIR_DE, pmr_launch_fir_tm(q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
+                LAUNCH(K_FIR_DE, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
                                                    1.0f, 0, 0.f, 0.f, 0.f, last ? NULL : q->d_aux2,
                                                    last ? (int16_t *)d_pcm : NULL, last ? (float *)d_audio : NULL,
                                                    pcm_stride));
                 cur = q->d_aux2;
             }
             if (q->cfg.lowpass) {
-                LAUNCH(K_FIR_LP, pmr_launch_fir_tm(q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
+                LAUNCH(K_FIR_LP, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
                                                    1.0f, 0, 0.f, 0.f, 0.f, NULL, (int16_t *)d_pcm, (float *)d_audio,
                                                    pcm_stride));
             }
         }
-    }
-    if (q->chan_small && q->fix_fused && q->fe_on && !q->fe_two && ny && !q->dbg_on && !q->fix_skip) {
-        /* The staging pass corrected its private copy only.  What later blocks will re-read as history -- the last
-         * (p+1)*M samples -- gets its dc carry in place now (after the channelizer, same stream). */
-        const unsigned keep = (p + 1) * M;
-        pmr_fe_fix_params f;
-        memset(&f, 0, sizeof(f));
-        f.xr = q->d_xr; f.pos0 = xr_abs0; f.mask = q->xr_mask; f.V = q->d_fe_V[par]; f.GA = q->d_fe_GA;
-        f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2; f.ny = ny; f.j0 = ny > keep ? ny - keep : 0;
-        f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = phi0; f.step = d->arb_step; f.Kgain = q->fe_Kgain;
-        LAUNCH(K_FE_FIX, pmr_launch_fe_dcfix(q->stream, &f));
     }
     q->frames_done += ns;
     HIPCHK(hipEventRecord(q->ev_be[par], q->stream), "record");
@@ -1333,13 +1284,12 @@ int pmr_chain_debug_enable(pmr_chain q, int on)
 int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes, size_t *n_bytes)
 {
     if (!q) return PMR_EINVAL;
-    if (!q->dbg_on && what != 2) return fail(q, PMR_EINVAL, "debug capture not enabled", hipSuccess);
+    if (!q->dbg_on) return fail(q, PMR_EINVAL, "debug capture not enabled", hipSuccess);
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
     HIPCHK(hipStreamSynchronize(q->stream), "sync");
     const void *src = NULL; size_t n = 0;
     if (what == PMR_DEBUG_RESAMPLED) { src = q->d_dbg_xr; n = (size_t)q->last_ny * sizeof(cfl); }
     else if (what == PMR_DEBUG_FM)   { src = q->d_dbg_fm; n = (size_t)q->last_ns * q->M * sizeof(float); }
-    else if (what == 2 && q->d_fe_stamps) { src = q->d_fe_stamps; n = 8 * sizeof(uint64_t); }
     else return PMR_EINVAL;
     if (n_bytes) *n_bytes = n;
     if (n > cap_bytes) n = cap_bytes;
@@ -1380,6 +1330,7 @@ unsigned pmr_cfg_design(const pmr_chain_cfg *cfg, int what, unsigned idx, float 
 unsigned pmr_cfg_max_frames(const pmr_chain_cfg *cfg)
 {
     pmr_design d;
+    memset(&d, 0, sizeof(d));
     unsigned rs = 0, cs = 0;
     if (!cfg_design(cfg, &d)) pmr_design_buffer_sizes(&d, cfg->max_block, &rs, &cs);
     pmr_design_free(&d);
@@ -1389,6 +1340,7 @@ unsigned pmr_cfg_max_frames(const pmr_chain_cfg *cfg)
 int pmr_cfg_plan_block(const pmr_chain_cfg *cfg, pmr_plan_state *st, unsigned n_in, unsigned *ny, unsigned *ns)
 {
     pmr_design d;
+    memset(&d, 0, sizeof(d));
     if (!st || cfg_design(cfg, &d)) { pmr_design_free(&d); return PMR_EINVAL; }
     unsigned ny_ = 0, ns_ = 0; uint32_t ph = 0;
     plan_core(d.num_stages, d.arb_step, d.M, st->n_raw, st->arb_phase, st->leftover, n_in, &ny_, &ns_, &ph);

@@ -79,35 +79,7 @@ static __device__ __forceinline__ void fft_dit(cf (&x)[M], const cf *__restrict_
 #ifndef CS_NT
 #define CS_NT 256
 #endif
-#ifndef CS_ABL
-#define CS_ABL 0                         /* timing experiments only: 1 no staging, 2 no filter bank, 4 no FFT, 8 no discriminator */
-#endif
 #define CS_FPT 2                          /* frames per thread */
-
-// Deferred dc carry of the fused front end (pmr_frontend.hip, k_fe_dcfix): resampled sample j of this call gets
-//   x -= V_c * K * mu^q' * GA[idx],   ph = phi0 + j*step,  qd = ph >> 24,  c = qd / TQ,  q' = qd - c*TQ + HhQ.
-// A thread walks j in increasing order, so (ph, qd, c, q') are carried and advanced incrementally: one 64-bit
-// multiply-add and a compare/subtract per step instead of a 32-bit division per sample.
-struct dc_track { unsigned long long ph, j; unsigned qd, c, ql; bool init; };
-
-// advance the tracker to sample j (>= the tracker's current sample) and return its (c, ql, ph)
-static __device__ __forceinline__ void dc_seek(dc_track &t, unsigned long long j, const pmr_chan_params &q)
-{
-    if (!t.init) {
-        t.ph = (unsigned long long)q.phi0 + j * q.step;
-        t.qd = (unsigned)(t.ph >> 24);
-        t.c = t.qd / q.TQ;
-        t.ql = t.qd - t.c * q.TQ;
-        t.init = true;
-    } else {
-        t.ph += (j - t.j) * q.step;
-        const unsigned qn = (unsigned)(t.ph >> 24);
-        t.ql += qn - t.qd;
-        t.qd = qn;
-        while (t.ql >= q.TQ) { t.ql -= q.TQ; t.c++; }
-    }
-    t.j = j;
-}
 
 template <int M>
 __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
@@ -133,23 +105,18 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
     const unsigned nfl = NFT + p - 1;                     // frames staged
     const long long s_base = ((long long)q.frame0 + t0 - (long long)p) * M;   // absolute index of the first staged sample
 
-    // ---- stage: HBM ring -> (dc carry) -> NCO mix -> LDS (two samples per lane per load) ----
+    // ---- stage: HBM ring -> NCO mix -> LDS (two samples per lane per load) ----
     {
         const unsigned units = nfl * (M / 2);
         // NCO phase index of a lane's sample pair is the same for every iteration: 2*CS_NT is a multiple of the period
         const unsigned i0 = ((unsigned)s_base + 2u * tid) & nco_mask;
         const cf c0 = nco_cs[i0], c1 = nco_cs[(i0 + 1) & nco_mask];
-        const long long xr_end = (long long)q.xr_end, fix0 = (long long)q.fix_abs0;
-        dc_track trk;
-        trk.init = false; trk.ph = 0; trk.j = 0; trk.qd = trk.c = trk.ql = 0;
-        // Batches of CS_SB units per thread: all ring loads of a batch are issued before anything consumes them, then all
-        // table look-ups of the dc carry, then the arithmetic -- a plain one-unit-per-iteration loop pays the full L2
-        // latency of its load 17 times in a row.
+        const long long xr_end = (long long)q.xr_end;
+        // Batches of CS_SB units per thread: all ring loads of a batch are issued before anything consumes them -- a plain
+        // one-unit-per-iteration loop pays the full L2 latency of its load 17 times in a row.
         constexpr int CS_SB = 6;
-        for (unsigned u0 = tid; u0 < ((CS_ABL & 1) ? 0u : units); u0 += CS_SB * CS_NT) {
+        for (unsigned u0 = tid; u0 < units; u0 += CS_SB * CS_NT) {
             float4 v[CS_SB];
-            float g0[CS_SB], g1[CS_SB];
-            cf V0[CS_SB], V1[CS_SB];
 #pragma unroll
             for (int k = 0; k < CS_SB; k++) {
                 const unsigned u = u0 + k * CS_NT;
@@ -163,31 +130,8 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 #pragma unroll
             for (int k = 0; k < CS_SB; k++) {
                 const unsigned u = u0 + k * CS_NT;
-                const long long a = s_base + 2 * (long long)u;
-                g0[k] = g1[k] = 0.f; V0[k] = V1[k] = cfm(0.f, 0.f);
-                if (q.V && u < units && a + 1 >= fix0) {      // samples produced by THIS call still miss their dc carry
-                    if (a >= fix0 && a < xr_end) {
-                        dc_seek(trk, (unsigned long long)(a - fix0), q);
-                        const unsigned e = trk.ql + q.HhQ;
-                        g0[k] = q.GA[(unsigned)(trk.ph & 0xffffffu) >> 16] * (q.T1[e >> 5] * q.T2[e & 31]);
-                        V0[k] = ((const cf *)q.V)[trk.c];
-                    }
-                    if (a + 1 < xr_end) {
-                        dc_seek(trk, (unsigned long long)(a + 1 - fix0), q);
-                        const unsigned e = trk.ql + q.HhQ;
-                        g1[k] = q.GA[(unsigned)(trk.ph & 0xffffffu) >> 16] * (q.T1[e >> 5] * q.T2[e & 31]);
-                        V1[k] = ((const cf *)q.V)[trk.c];
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < CS_SB; k++) {
-                const unsigned u = u0 + k * CS_NT;
                 if (u < units) {
-                    float4 w = v[k];
-                    const float ga = q.Kgain * g0[k], gb = q.Kgain * g1[k];
-                    w.x = fmaf(-V0[k].x, ga, w.x); w.y = fmaf(-V0[k].y, ga, w.y);
-                    w.z = fmaf(-V1[k].x, gb, w.z); w.w = fmaf(-V1[k].y, gb, w.w);
+                    const float4 w = v[k];
                     float4 o;
                     o.x = fmaf(w.x, c0.x, w.y * c0.y);        // x * conj(e^{j theta})
                     o.y = fmaf(w.y, c0.x, -(w.x * c0.y));
@@ -207,7 +151,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
     for (int c = 0; c < M; c++) { XA[c] = cfm(0.f, 0.f); XB[c] = cfm(0.f, 0.f); }
     {
         const cf *row = xs + (size_t)(CS_FPT * tid) * FS;
-        for (unsigned j = 0; j <= ((CS_ABL & 2) ? 1u : p); j++) {   // buffer frame (local 2*tid + j) feeds A with tap j, B with tap j-1
+        for (unsigned j = 0; j <= p; j++) {   // buffer frame (local 2*tid + j) feeds A with tap j, B with tap j-1
             cf s[M];
 #pragma unroll
             for (int c = 0; c < M; c += 2) {
@@ -231,10 +175,8 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
     cf YA[M], YB[M];
 #pragma unroll
     for (int c = 0; c < M; c++) { YA[brev_c(c, L2M)] = XA[c]; YB[brev_c(c, L2M)] = XB[c]; }
-    if (!(CS_ABL & 4)) {
-        fft_dit<M>(YA, fft_tw);
-        fft_dit<M>(YB, fft_tw);
-    }
+    fft_dit<M>(YA, fft_tw);
+    fft_dit<M>(YB, fft_tw);
 
     // ---- previous frame for frame A: neighbour thread's frame B, through LDS ----
     __syncthreads();                                      // everyone is done reading the staged samples
@@ -271,7 +213,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const cf pv = PV[k + i], cu = YA[k + i];
-                rr[i] = (CS_ABL & 8) ? pv.x + cu.y : atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
+                rr[i] = atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
             }
             *reinterpret_cast<float4 *>(o + k) = r;
         }
@@ -285,7 +227,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const cf pv = YA[k + i], cu = YB[k + i];
-                rr[i] = (CS_ABL & 8) ? pv.x + cu.y : atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
+                rr[i] = atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
             }
             *reinterpret_cast<float4 *>(o + k) = r;
         }
@@ -459,23 +401,16 @@ __global__ __launch_bounds__(CW_NT, 4) void k_channelize_win(pmr_chan_params q)
     }
 }
 
-static int cs_use_win()
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PMR_CHANNELIZER_SMALL"); v = !(e && !strcmp(e, "pair")); }   /* pair = two frames per thread */
-    return v;
-}
-
-extern "C" unsigned pmr_channelize_small_tiles(unsigned ns) { return (ns + CS_NT * CS_FPT - 2) / (CS_NT * CS_FPT - 1); }   /* pair kernel */
+static unsigned pmr_channelize_small_tiles(unsigned ns) { return (ns + CS_NT * CS_FPT - 2) / (CS_NT * CS_FPT - 1); }   /* pair kernel */
 
 extern "C" int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned nco_period)
 {
     return M == 16 && p >= 2 && p <= 64 && nco_period && (2u * CS_NT) % nco_period == 0;
 }
 
-extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out)
+extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int pair)
 {
-    const bool win = cs_use_win() && p->p == 26 && !p->V;      /* the windowed kernel does not apply a deferred dc carry */
+    const bool win = !pair && p->p == 26;                       /* pair = two frames per thread (PMR_CHANNELIZER_SMALL=pair) */
     const unsigned ntiles = win ? (p->ns + CW_NT - 2) / (CW_NT - 1) : pmr_channelize_small_tiles(p->ns);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;

@@ -1,0 +1,171 @@
+// pmr_fe_common.hpp -- device helpers shared by the front-end kernels (pmr_frontend.hip: run-time-parameterised tile
+// kernel + carry kernels; pmr_fe_fast.hip: the specialised kernels for the cascades the As = 60 dB design produces).
+// Reference stage: dc-block + msresamp_crcf, src/sdr_pmr446.c:795-796.
+#ifndef PMR_FE_COMMON_HPP
+#define PMR_FE_COMMON_HPP
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmr_kernels.h"
+
+// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
+// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
+static inline bool pmr_attr_needed(unsigned long long &mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if (mask >> dev & 1ull) return false;
+    mask |= 1ull << dev;
+    return true;
+}
+
+// complex sample = clang ext-vector pair: (re, im) arithmetic with a real scalar tap maps onto v_pk_fma_f32 with the tap
+// broadcast from one SGPR.  Measured on MI355X (tools/ubench/valu_rate.hip): v_fma_f32 peaks at ~67 TFLOP/s,
+// v_pk_fma_f32 at ~115-120 TFLOP/s, so packed math is worth ~1.8x wherever the kernel is VALU-bound.
+typedef float cf __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ cf cfm(float r, float i) { return cf{r, i}; }
+static __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+static __device__ __forceinline__ cf cadd_scale(cf a, cf b, float s) { return (a + b) * cf{s, s}; }
+static __device__ __forceinline__ cf cfma(float h, cf x, cf acc) { return __builtin_elementwise_fma(cf{h, h}, x, acc); }
+
+// Cross-lane moves on the VALU (DPP), not through the LDS crossbar: the kernel is LDS-instruction-bound.
+//   row_shr:n (0x110+n) shift inside a 16-lane row; wave_shr:1 (0x138) shift across the whole wave;
+//   row_bcast:15 / row_bcast:31 (0x142 / 0x143) lane 15 / 31 of a row to every lane of the next row(s).
+// Lanes without a source (or masked rows) receive `old` = 0.
+template <int CTRL, int ROW_MASK = 0xF>
+static __device__ __forceinline__ float dpp0(float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+static __device__ __forceinline__ cf dpp0c(cf v) { return cf{dpp0<CTRL, ROW_MASK>(v.x), dpp0<CTRL, ROW_MASK>(v.y)}; }
+
+// LDS layout L(G): element e lives at e + e/G (one 8-byte pad per G elements) so that threads whose chunks
+// are G elements apart hit distinct banks with ds_read_b64 / ds_write_b64 (stride 2G+2 dwords, gcd with 64 = 2).
+template <int G> static __device__ __forceinline__ int lidx(int e) { return e + e / G; }
+static __device__ __forceinline__ int lidx_rt(int e, int g_shift) { return e + (e >> g_shift); }
+
+#define FE_PAD 64      /* elements in front of the tile buffer; >= (4*10-2) * (1 + 1/2) */
+
+static constexpr int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+template <int G> static constexpr int loff(int e) { return e + fdiv(e, G); }   // layout offset of a constant index
+
+// ceil(num / den) for num < 2^56 and den in [2^24, 2^25] (the resampler step) in INTEGER arithmetic: rinv = floor(2^56 / den)
+// clamped to 32 bits (host).  q0 = ((num >> 24) * rinv) >> 32 never exceeds floor(num / den) and is short of it by at most 3
+// (truncation of num by < 2^24, of rinv by < 1, of the product by < 1), so the fix-up loop runs <= 3 times.  Every operand is
+// wave-uniform where this is used (tile bookkeeping), so the whole thing stays on the scalar unit -- the fp64 division it
+// replaces was ~100 vector instructions per thread.
+static __device__ __forceinline__ unsigned long long ceil_div_step(unsigned long long num, unsigned den, unsigned rinv)
+{
+    unsigned long long q = ((num >> 24) * (unsigned long long)rinv) >> 32;
+    while ((q + 1) * den <= num) q++;                     // q = floor(num / den)
+    return q * den == num ? q : q + 1;
+}
+
+// one half-band stage, ping-pong form: reads layout L(2P) from `src`, writes layout L(max(P, 2)) to `dst`, ONE barrier.
+//   z1[o] = z0[2o+1-2m] + sum_j h1[j] * z0[2o - 2(2m-1-j)]            (resamp2 decimator)
+// Every LDS address is thread base + compile-time constant (floor division keeps that true left of the tile, where the
+// reads land in the zero pad / the previous region and only feed outputs inside the halo).
+template <int P, int MM>
+static __device__ __forceinline__ void hb_stage_pp(const cf *__restrict__ src, cf *__restrict__ dst, int tid,
+                                                   int n_threads, const float *h1, float scale)
+{
+    constexpr int NE = P + 2 * MM - 1, G = 2 * P;
+    if (tid < n_threads) {
+        const cf *w = src + tid * (G + 1);
+        cf we[NE], wd[P];
+#pragma unroll
+        for (int i = 0; i < NE; i++) we[i] = w[loff<G>(2 * i - (4 * MM - 2))];
+#pragma unroll
+        for (int p = 0; p < P; p++) wd[p] = w[loff<G>(2 * p + 1 - 2 * MM)];
+        cf y[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            cf a = cfm(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 2 * MM; j++) a = cfma(h1[j], we[p + j], a);
+            y[p] = cadd_scale(wd[p], a, scale);
+        }
+        if constexpr (P >= 2) {
+            cf *o = dst + tid * (P + 1);               // L(P)
+#pragma unroll
+            for (int p = 0; p < P; p++) o[p] = y[p];
+        } else {
+            dst[tid + (tid >> 1)] = y[0];              // L(2)
+        }
+    }
+    __syncthreads();
+}
+
+// Resampler bookkeeping of one tile (wave-uniform): the tile owns decimated samples [qa, qb) and therefore the resampler
+// outputs j in [ja, jb) whose input index (phi0 + j*step) >> 24 falls in that range (resamp_crcf phase rule).
+struct fe_jrange { unsigned long long ja, jb; };
+static __device__ __forceinline__ fe_jrange fe_tile_outputs(const pmr_fe_params &p, unsigned long long qa)
+{
+    fe_jrange r = {0ull, 0ull};
+    unsigned long long qb = qa + (unsigned)p.TQ;
+    if (qb > p.Q) qb = p.Q;
+    if (qa < qb) {
+        const unsigned long long sa = qa << 24, sb = qb << 24;
+        r.ja = sa <= p.phi0 ? 0ull : ceil_div_step(sa - p.phi0, p.step, p.step_rinv);
+        r.jb = sb <= p.phi0 ? 0ull : ceil_div_step(sb - p.phi0, p.step, p.step_rinv);
+        if (r.jb > p.ny) r.jb = p.ny;
+        if (r.ja > r.jb) r.ja = r.jb;
+    }
+    return r;
+}
+
+// Phase D of the specialised kernels: arbitrary resampler (firpfb of 256 x 14 taps, closed-form 24-bit phase) out of the last
+// stage's output `fin` (layout L(1 << GS)), ring store.  A thread owns the PAIR of adjacent outputs jh + 2 tid, + 1 (jh = ja
+// rounded up to an even ring position; the odd head sample, if any, is thread 0's extra job): one 16-byte store per thread
+// instead of two 8-byte ones -- only when the tile has more outputs than threads, otherwise one output per thread is the
+// shorter phase.  fe_arb_prefetch requests the polyphase taps (two rows of the bank) long before fe_arb_store uses them.
+struct fe_arb_plan { unsigned long long ja, jb, jh, j0; bool pairs; const float *b0p, *b1p; };
+template <int NT>
+static __device__ __forceinline__ fe_arb_plan fe_arb_prepare(const pmr_fe_params &p, unsigned long long qa, int tid)
+{
+    fe_arb_plan a;
+    const fe_jrange r = fe_tile_outputs(p, qa);
+    a.ja = r.ja; a.jb = r.jb;
+    a.pairs = a.jb - a.ja > (unsigned long long)NT;
+    a.jh = a.pairs ? a.ja + ((p.out_pos0 + a.ja) & 1ull) : a.ja;
+    a.j0 = a.pairs ? a.jh + 2ull * tid : a.ja + tid;
+    const unsigned long long j1 = a.pairs ? a.j0 + 1 : a.jb;
+    const unsigned ph0 = p.phi0 + (unsigned)a.j0 * p.step, ph1 = ph0 + p.step;      // low 32 bits are all the bank index needs
+    a.b0p = p.arb_bank + (a.j0 < a.jb ? (ph0 & 0xffffffu) >> 16 : 0u) * 14u;
+    a.b1p = p.arb_bank + (j1 < a.jb ? (ph1 & 0xffffffu) >> 16 : 0u) * 14u;
+    return a;
+}
+
+template <int NT, int GS>
+static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, const fe_arb_plan &a, unsigned long long qa,
+                                                    const cf *fin, const float (&bk0)[14], const float (&bk1)[14], int tid)
+{
+    cf *__restrict__ out = (cf *)p.out;
+    const auto resamp = [&](unsigned long long j, const float *bk) {
+        const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
+        const int ql = (int)((ph >> 24) - qa) + p.HhQ - 13;
+        cf y = cfm(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 14; k++) y = cfma(bk[k], fin[(ql + k) + ((ql + k) >> GS)], y);
+        return y;
+    };
+    if (a.pairs && a.j0 + 1 < a.jb) {
+        const cf y0 = resamp(a.j0, bk0), y1 = resamp(a.j0 + 1, bk1);
+        *reinterpret_cast<float4 *>(out + ((p.out_pos0 + a.j0) & p.out_mask)) = make_float4(y0.x, y0.y, y1.x, y1.y);
+    } else if (a.j0 < a.jb) {
+        out[(p.out_pos0 + a.j0) & p.out_mask] = resamp(a.j0, bk0);
+    }
+    // rare leftovers, taps fetched on the spot: the odd head sample, and anything beyond 2 NT outputs per tile
+    if (tid == 0 && a.jh > a.ja && a.ja < a.jb) {
+        const unsigned long long ph = (unsigned long long)p.phi0 + a.ja * p.step;
+        out[(p.out_pos0 + a.ja) & p.out_mask] = resamp(a.ja, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
+    }
+    for (unsigned long long j = (a.pairs ? a.jh + 2ull * NT : a.ja + NT) + tid; j < a.jb; j += NT) {
+        const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
+        out[(p.out_pos0 + j) & p.out_mask] = resamp(j, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
+    }
+}
+
+#endif

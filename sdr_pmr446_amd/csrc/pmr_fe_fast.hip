@@ -1,0 +1,330 @@
+// pmr_fe_fast.hip -- the SPECIALISED front-end kernels for gfx950: dc-block -> half-band cascade -> arbitrary resampler
+// (reference src/sdr_pmr446.c:795-796: iirfilt_crcf_execute_block + msresamp_crcf_execute) for the cascades liquid's
+// As = 60 dB design produces: N3 six-tap stages (m = 3), then the m = 5 and m = 10 stages, then the 256 x 14 polyphase bank.
+//
+//   k_fe_fast<FE_FULL, N3, 1>   whole front end in one pass over the raw block (cfg2: N3 = 1, cfg3: N3 = 2)
+//   k_fe_fast<FE_L1,  N3, 0>    level 1 of a deep cascade (cfg5 / dsd_in: N3 = 4): dc-block + N3 six-tap stages -> decimated ring
+//   k_fe_level2                 level 2: ring in (level 1's dc carry applied at load) -> m = 5 -> m = 10 -> resampler
+//
+// Same arithmetic and the same order of operations as the run-time-parameterised k_frontend (pmr_frontend.hip); what is
+// specialised is WHEN things are fetched and how much instruction overhead surrounds the ~13 packed MACs per sample:
+//   * the raw tile goes HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).  The DMA's
+//     LDS image is lane-linear, so the bank-conflict-free layout is obtained by permuting the SOURCE addresses: 16-byte chunk
+//     g of the tile lands in slot (g & ~7) | ((g & 7) ^ ((g >> 4) & 7)), and thread t reads its eight chunks 8t..8t+7 with
+//     ds_read_b128 from slots 8t + (j ^ ((t >> 1) & 7)) -- 16 consecutive lanes then touch 16 distinct 16-byte bank groups.
+//     Each 128-byte line is still fetched by 8 adjacent lanes of one instruction (the permutation stays inside a line);
+//   * stage count, per-stage outputs per thread and LDS layouts are compile-time: every LDS address is thread base + immediate,
+//     branch taps arrive as scalars from the kernel-argument segment;
+//   * tile bookkeeping (which resampler outputs a tile owns) is wave-uniform INTEGER arithmetic on the scalar unit
+//     (ceil_div_step) instead of an fp64 division in every lane;
+//   * the cascade ping-pongs between two LDS regions (one barrier per stage); z1 / z2 reuse the raw tile's 32 KB.
+#include <stdlib.h>
+#include <string.h>
+
+#include "pmr_fe_common.hpp"
+
+enum { FE_FULL = 0, FE_L1 = 1 };
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// slot of 16-byte chunk g (and chunk of slot g: the map is an involution)
+static __device__ __forceinline__ int fe_swz(int g) { return (g & ~7) | ((g & 7) ^ ((g >> 4) & 7)); }
+
+template <int MODE, int N3, int TAIL>
+__global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 256, SPT = 16, N0 = NT * SPT;
+    constexpr int H = N3 + 2 * TAIL;
+    constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;         // z1 (2048 samples, layout L(8)) fills [0, R1_OFF) of the tile area
+    // LDS: [FE_PAD zero pad | raw tile, 4096 samples = 2048 swizzled 16-byte chunks; afterwards R0 (z1, 2304 slots) and
+    // R1 (z2, 1280 slots) | scan scratch] = 33.6 KB -> four tiles per CU
+    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
+    cf *wagg = buf + N0;
+    cf *bnd = wagg + NT / 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const cf *__restrict__ x = (const cf *)p.x;
+    const cf *__restrict__ hist = (const cf *)p.hist;
+    const float lam = -p.dc_a1;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so give every XCD a
+    // CONTIGUOUS range of tiles -- a tile's halo is its left neighbour's tail and can then be an L2 hit instead of a second
+    // HBM read (PMC: 8 % extra fetch without it).  Placement only affects speed, never results.
+    int c = blockIdx.x;
+    {
+        const int nt_all = gridDim.x, per = nt_all >> 3, main = per << 3;
+        if (c < main) c = (c & 7) * per + (c >> 3);
+    }
+    const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // block-relative index of tile sample 0
+
+    // ---- phase A: raw tile -> LDS ----
+    if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
+    const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
+    if (fast) {
+        const float4 *__restrict__ src = reinterpret_cast<const float4 *>(x + b0);
+#pragma unroll
+        for (int i = 0; i < N0 / 2 / NT; i++) {
+            const int s0 = wave * (N0 / 8) + i * 64;                       // first slot of this wave-instruction (1 KiB)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(src + fe_swz(s0 + lane)), (lptr_t *)(reinterpret_cast<float4 *>(buf) + s0),
+                                             16, 0, 0);
+        }
+    } else {
+        // edge tiles (history before the block, zeros beyond it, or an unaligned block): plain loads into the same image
+#pragma unroll 4
+        for (int i = tid; i < N0; i += NT) {
+            const long b = b0 + i;
+            cf w = cfm(0.f, 0.f);
+            if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) w = hist[hi]; }
+            else if (b < (long)p.n_in) w = x[b];
+            buf[2 * fe_swz(i >> 1) + (i & 1)] = w;
+        }
+    }
+
+    // ---- everything that comes from tables, requested while the tile streams in ----
+    const unsigned long long qa = (unsigned long long)c * p.TQ;
+    fe_arb_plan ap;
+    float bk0[14], bk1[14];
+    if constexpr (MODE == FE_FULL) {
+        ap = fe_arb_prepare<NT>(p, qa, tid);
+        if (p.tile_j && tid == 0) { ((unsigned long long *)p.tile_j)[2 * c] = ap.ja; ((unsigned long long *)p.tile_j)[2 * c + 1] = ap.jb; }
+#pragma unroll
+        for (int k = 0; k < 14; k++) { bk0[k] = ap.b0p[k]; bk1[k] = ap.b1p[k]; }
+    }
+    const float lp = p.lam_lane_pow[lane], l15 = p.lam_lane_pow[(lane & 15) + 1], l31 = p.lam_lane_pow[(lane & 31) + 1];
+    __syncthreads();                                       // (the compiler drains the DMA before the barrier)
+
+    cf xs[SPT];
+    {
+        const float4 *rb = reinterpret_cast<const float4 *>(buf) + 8 * tid;
+        const int sw = (tid >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float4 v = rb[j ^ sw];
+            xs[2 * j] = cfm(v.x, v.y); xs[2 * j + 1] = cfm(v.z, v.w);
+        }
+    }
+
+    // ---- phase B: dc blocker (:795) from ZERO state + first (six-tap) stage straight from registers ----
+    {
+        cf yb[SPT];
+        cf v = cfm(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) v = cfma(lam, v, xs[j]);             // v0 = x - a1 v1
+        // inclusive decayed scan across the wave (DPP): inc_l = sum_{s<=l} lambda^(SPT (l-s)) agg_s
+        v = cfma(p.lam_pow16[0], dpp0c<0x111>(v), v);                      // row_shr:1
+        v = cfma(p.lam_pow16[1], dpp0c<0x112>(v), v);                      // row_shr:2
+        v = cfma(p.lam_pow16[2], dpp0c<0x114>(v), v);                      // row_shr:4
+        v = cfma(p.lam_pow16[3], dpp0c<0x118>(v), v);                      // row_shr:8
+        v = cfma(l15, dpp0c<0x142, 0xA>(v), v);                            // row_bcast:15 -> rows 1, 3
+        v = cfma(l31, dpp0c<0x143, 0xC>(v), v);                            // row_bcast:31 -> rows 2, 3
+        if (lane == 63) wagg[wave] = v;
+        const cf ex = dpp0c<0x138>(v);                                     // wave_shr:1 (lane 0 <- 0)
+        __syncthreads();                                                   // also: every thread holds its raw samples
+        cf cw = cfm(0.f, 0.f);                                             // v (local) at the end of the previous wave
+        for (int w = 0; w < wave; w++) cw = cfma(p.lam_wave, cw, wagg[w]);
+        cf v1 = cfma(lp, cw, ex);
+        // stray probes (block start - 1 in tile 0, block end in the last tile) sit at arbitrary offsets
+        const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
+        const int pE = (c == p.c_end) ? p.off_end : -1;
+        const bool stray = (pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const cf v0 = cfma(lam, v1, xs[j]);
+            yb[j] = csub(v0, v1);                                          // y = v0 - v1
+            v1 = v0;
+            if (stray) {
+                if (SPT * tid + j == pL) ((cf *)p.probeL)[0] = v0;
+                if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = v0;
+            }
+        }
+        if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;               // local v at tile offset Hh-1
+        if (tid == NT - 1) ((cf *)p.probeB)[c] = v1;                       // local v at tile offset N0-1
+        // halo of stage 0: the previous thread's yb[6..15] (lane 0: previous wave's lane 63, through LDS)
+        cf W[26];
+#pragma unroll
+        for (int i = 0; i < 10; i++) W[i] = dpp0c<0x138>(yb[6 + i]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) W[10 + i] = yb[i];
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) bnd[wave * 10 + i] = yb[6 + i];
+        }
+        __syncthreads();
+        if (lane == 0 && wave > 0) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * 10 + i];
+        }
+        // z1[8 tid + q] = W[2q + 5] + sum_j h1[j] W[2q + 2j]   (window offset 0 <-> sample 16 tid - 10)
+        const float scale0 = H == 1 ? p.zeta : 1.0f;
+        cf *o = buf + tid * 9;                             // z1 in layout L(8), region R0 (over the raw tile)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            cf a = cfm(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 6; j++) a = cfma(p.taps_k[j], W[2 * q + 2 * j], a);
+            o[q] = cadd_scale(W[2 * q + 5], a, scale0);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: remaining stages, ping-pong R0 <-> R1; stage e (execution index) has 2048 >> e outputs ----
+    cf *R0 = buf, *R1 = buf + R1_OFF;
+#define FE_STAGE(E, MM, TOFF) do { constexpr int NOUT = (N0 / 2) >> (E); constexpr int PP = NOUT >= NT ? NOUT / NT : 1;          \
+        hb_stage_pp<PP, MM>(((E) & 1) ? R0 : R1, ((E) & 1) ? R1 : R0, tid, NOUT / PP, p.taps_k + (TOFF),                         \
+                            (E) == H - 1 ? p.zeta : 1.0f); } while (0)
+    // six-tap stages 1 .. N3-1 (taps at 6 e), then the m = 5 and m = 10 stages
+    if constexpr (N3 >= 2) FE_STAGE(1, 3, 6);
+    if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
+    if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
+    if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
+    if constexpr (TAIL) { FE_STAGE(N3, 5, 6 * N3); FE_STAGE(N3 + 1, 10, 6 * N3 + 10); }
+#undef FE_STAGE
+    constexpr int NLAST = (N0 / 2) >> (H - 1);
+    constexpr int PLAST = H == 1 ? 8 : (NLAST >= NT ? NLAST / NT : 1);
+    constexpr int GS = PLAST >= 8 ? 3 : (PLAST == 4 ? 2 : 1);                   // final layout L(1 << GS)
+    const cf *fin = ((H - 1) & 1) ? R1 : R0;                                      // stage e writes R1 when e is odd
+
+    if constexpr (MODE == FE_L1) {
+        // pairs of adjacent samples per lane through 16-byte stores (8-byte stores run at ~0.6x the rate); pairs start at
+        // even ring positions, so they are aligned and never straddle the ring end
+        cf *__restrict__ out = (cf *)p.out;
+        const int nown = (int)((qa + p.TQ <= p.Q) ? p.TQ : (p.Q > qa ? p.Q - qa : 0));   // samples this tile stores
+        const auto ld = [&](int i) { return fin[(p.HhQ + i) + ((p.HhQ + i) >> GS)]; };
+        const int head = (int)((p.out_pos0 + qa) & 1ull) && nown > 0;
+        if (head && tid == 0) out[(p.out_pos0 + qa) & p.out_mask] = ld(0);
+        const int npair = (nown - head) >> 1;
+        for (int t = tid; t < npair; t += NT) {
+            const int i = head + 2 * t;
+            const cf a = ld(i), b = ld(i + 1);
+            *reinterpret_cast<float4 *>(out + ((p.out_pos0 + qa + i) & p.out_mask)) = make_float4(a.x, a.y, b.x, b.y);
+        }
+        if (((nown - head) & 1) && tid == 0) out[(p.out_pos0 + qa + nown - 1) & p.out_mask] = ld(nown - 1);
+    } else {
+        fe_arb_store<NT, GS>(p, ap, qa, fin, bk0, bk1, tid);
+    }
+    // ---- raw history for the next call (last hcap samples of old history || block), by tile 0 ----
+    if (c == 0 && p.new_hist) {
+        cf *__restrict__ nh = (cf *)p.new_hist;
+        for (int i = tid; i < p.hcap; i += NT) {
+            const long sb = (long)i + (long)p.n_in - (long)p.hcap;      // block-relative index
+            nh[i] = sb < 0 ? hist[(long)i + p.n_in] : x[sb];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level 2 of the two-level front end: 2048 samples of the decimated ring per tile -> m = 5 stage -> m = 10 stage -> resampler.
+// The ring samples produced by THIS call still miss level 1's dc carry, V_c1 * K1 * mu^i' (k_fe_carry computed the V_c1 and
+// already fixed the last few in place: index >= fix_limit); it is subtracted here while loading.  A tile starts at a multiple
+// of 4 in absolute ring index, so samples are loaded as 16-byte pairs.  1/16 of the raw rate flows through here (cfg5).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void k_fe_level2(pmr_fe_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 256, N0 = 2048;
+    constexpr int R1_OFF = N0 + N0 / 8;                    // input (layout L(8)) fills [0, R1_OFF); z1 (1024, L(4)) behind it
+    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
+    cf *R0 = buf, *R1 = buf + R1_OFF;
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x;
+    const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // index of tile sample 0 among this call's new ring samples
+
+    const unsigned long long qa = (unsigned long long)c * p.TQ;
+    const fe_arb_plan ap = fe_arb_prepare<NT>(p, qa, tid);
+    float bk0[14], bk1[14];
+
+    if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
+    {
+        const cf *__restrict__ ring = (const cf *)p.in_ring;
+        const cf *__restrict__ V1 = (const cf *)p.fixV;
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 2 * (tid + NT * k);                              // tile-local index of the pair's first sample
+            const long long a = (long long)p.in_abs0 + b0 + i, jn = b0 + i;
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a >= 0 && jn < (long long)p.n_in) v[k] = *reinterpret_cast<const float4 *>(ring + ((unsigned long long)a & p.in_mask));
+        }
+#pragma unroll
+        for (int k = 0; k < 14; k++) { bk0[k] = ap.b0p[k]; bk1[k] = ap.b1p[k]; }
+        // level-1 tile index and tile-local offset of a sample advance incrementally over the four pairs (+2 NT samples each):
+        // one 32-bit division per thread
+        unsigned c1 = 0, ql = 0; bool trk = false;
+        const auto fix = [&](long long j, float &re, float &im) {          // j: index among this call's new ring samples
+            if (!V1 || j < 0 || j >= (long long)p.fix_limit) return;
+            if (!trk) { c1 = (unsigned)j / p.fix_TQ; ql = (unsigned)j - c1 * p.fix_TQ; trk = true; }
+            while (ql >= p.fix_TQ) { ql -= p.fix_TQ; c1++; }
+            const unsigned e = ql + p.fix_HhQ;
+            const float g = p.fix_K * (p.fix_T1[e >> 5] * p.fix_T2[e & 31]);
+            const cf Vc = V1[c1];
+            re = fmaf(-Vc.x, g, re); im = fmaf(-Vc.y, g, im);
+        };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 2 * (tid + NT * k);
+            const long long jn = b0 + i;
+            float4 w = v[k];
+            if (jn + 1 >= (long long)p.n_in) { w.z = 0.f; w.w = 0.f; }    // the pair's second sample lies beyond the block
+            fix(jn, w.x, w.y);
+            if (trk) ql += 1;
+            fix(jn + 1, w.z, w.w);
+            if (trk) ql += 2 * NT - 1;
+            cf *d = R0 + lidx<8>(i);                                       // the pair never straddles an 8-sample chunk
+            d[0] = cfm(w.x, w.y);
+            d[1] = cfm(w.z, w.w);
+        }
+    }
+    __syncthreads();
+    hb_stage_pp<4, 5>(R0, R1, tid, NT, p.taps_k, 1.0f);                    // 1024 outputs, L(8) -> L(4)
+    hb_stage_pp<2, 10>(R1, R0, tid, NT, p.taps_k + 10, p.zeta);            //  512 outputs, L(4) -> L(2)
+    fe_arb_store<NT, 1>(p, ap, qa, R0, bk0, bk1, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int N3, int TAIL>
+static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
+{
+    const size_t lds = (FE_PAD + 4096 + 4 + 44) * sizeof(cf);
+    auto kern = k_fe_fast<MODE, N3, TAIL>;
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st, *p);
+    return (int)hipGetLastError();
+}
+
+/* the specialised kernels cover: N3 six-tap stages, then optionally (m = 5, m = 10); 256 x 16 tiles */
+static int fast_pattern(const pmr_fe_params *p, int *n3, int *tail)
+{
+    int k = 0;
+    while (k < p->h && p->m[k] == 3) k++;
+    *n3 = k;
+    if (k == p->h) { *tail = 0; return k >= 1; }
+    if (k >= 1 && k + 2 == p->h && p->m[k] == 5 && p->m[k + 1] == 10) { *tail = 1; return 1; }
+    return 0;
+}
+
+extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles)
+{
+    hipStream_t st = (hipStream_t)s;
+    int n3 = 0, tail = 0;
+    if (!p->taps_valid || !fast_pattern(p, &n3, &tail)) return -1;
+    if (p->mode == FE_FULL && tail) {
+        if (n3 == 1) return launch_fast<FE_FULL, 1, 1>(st, p, ntiles);
+        if (n3 == 2) return launch_fast<FE_FULL, 2, 1>(st, p, ntiles);
+        if (n3 == 3) return launch_fast<FE_FULL, 3, 1>(st, p, ntiles);
+    }
+    if (p->mode == FE_L1 && !tail) {
+        if (n3 == 2) return launch_fast<FE_L1, 2, 0>(st, p, ntiles);
+        if (n3 == 3) return launch_fast<FE_L1, 3, 0>(st, p, ntiles);
+        if (n3 == 4) return launch_fast<FE_L1, 4, 0>(st, p, ntiles);
+        if (n3 == 5) return launch_fast<FE_L1, 5, 0>(st, p, ntiles);
+    }
+    return -1;
+}
+
+extern "C" int pmr_launch_fe_level2_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles)
+{
+    if (!ntiles) return 0;
+    const size_t lds = (FE_PAD + (2048 + 256) + (1024 + 256)) * sizeof(cf);
+    hipLaunchKernelGGL(k_fe_level2, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p);
+    return (int)hipGetLastError();
+}

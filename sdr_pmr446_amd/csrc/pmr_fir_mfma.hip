@@ -57,7 +57,7 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
                                                       long long row0, unsigned ns, const float *__restrict__ taps_c,
                                                       unsigned ntaps, float *__restrict__ out_tm,
                                                       int16_t *__restrict__ pcm, float *__restrict__ audio,
-                                                      unsigned stride, int ablate, unsigned M /*row width, multiple of 16*/)
+                                                      unsigned stride, unsigned M /*row width, multiple of 16*/)
 {
     // blockIdx.y selects a group of 16 channels: the tile is 16 channels wide whatever M is
     const unsigned cg0 = blockIdx.y * 16u;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
             const unsigned u = tid + FM_NT * i, r = u >> 2, q4 = (u & 3) * 4;
             const long t = T0 - (long)(ntaps - 1) + r;
             pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < nrows * 4 && t < (long)ns && !(ablate & 1))
+            if (u < nrows * 4 && t < (long)ns)
                 pre[i] = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + q4);
         }
     };
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
     //                                  so a group of 16 steps advances the base by 16*32 + 16 floats.
     // Explicit two-set software pipeline (no register copies): the 32 operands of group g+1 are in flight from LDS while
     // the 16 MFMAs of group g issue back to back; each set is waited for only right before its first use.
-    const unsigned groups = ((ntaps + 31 + 31) / 32) >> ((ablate >> 1) & 1);
+    const unsigned groups = (ntaps + 31 + 31) / 32;
     const float *q0 = Qs + PMR_TAP_PAD + (ntaps - 1) + (lane & 31) - kk - 30;      // group 0, step 15; step s at q[2*(15-s)]
     const float *x0 = Xs + (Tj + kk) * 16 + 16 * ((Tj + kk) >> 5) + ch;            // group 0, step 0;  step s at x[32*s]
     const long long rb0 = row0 + T0 + Tj + kk - (long long)(ntaps - 1);            // GLB: ring row of group 0, step 0
@@ -151,7 +151,6 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
 #undef FM_LOAD
 #undef FM_MMA
 
-    if (!(ablate & 4)) {
     if constexpr (SWAP) {
         // Operands exchanged => D' = D^T (same products, same k order): lane = frame (column lane & 31), register 4g + q =
         // row 8g + 4kk + q = (channel, time block).  A half-wave then stores 32 CONSECUTIVE frames of one channel row: 64
@@ -208,7 +207,6 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
         }
     }
     }
-    } else if (acc[0] == 123.456f) pcm[0] = 1;
     }   // active
     if (more) {                                                      // uniform
         __syncthreads();                                             // every wave is done with this tile's window
@@ -223,8 +221,8 @@ extern "C" int pmr_fir_mfma_supported(unsigned M, unsigned ntaps)
     return M >= 16 && M % 16 == 0 && M <= 16 * 65535u && ntaps >= 2 && (FM_TILE + ntaps + 31) * 4 <= FM_PRE * FM_NT;
 }
 
-extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
-                                   unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm,
+extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
+                                   unsigned ns, unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm,
                                    float *audio, unsigned stride)
 {
     if (!ns) return 0;
@@ -246,34 +244,30 @@ extern "C" int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row
     /* PMR_FIR_MFMA=global: B operand straight from the ring (no LDS window; co-resides with front-end tiles).  Measured
      * on MI355X: slower in isolation (0.082 vs 0.066 ms at cfg2) and equal within noise inside the pipelined chain, so the
      * LDS-window kernel stays the default. */
-    static int glb = -1;
-    if (glb < 0) { const char *e = getenv("PMR_FIR_MFMA"); glb = (e && !strcmp(e, "global")); }
-    const int ablate = []{ const char *e = getenv("PMR_FIR_ABLATE"); return e ? atoi(e) : 0; }();
-    if (glb) {
+    if (sw->fir_mfma_global) {
         const size_t lds_g = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float);
         hipLaunchKernelGGL((k_fir_mfma16<true, 1, false>), dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds_g, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
         return (int)hipGetLastError();
     }
     const unsigned tiles = (ns + FM_TILE - 1) / FM_TILE;
-    static int tpw = -1;                          /* PMR_FIR_TPW=1: one tile per workgroup, no window prefetch */
-    if (tpw < 0) { const char *e = getenv("PMR_FIR_TPW"); tpw = e ? atoi(e) : 2; }
+    const int tpw = sw->fir_tpw;                  /* PMR_FIR_TPW=1: one tile per workgroup, no window prefetch */
     /* two tiles per workgroup only while that still leaves enough workgroups to fill the chip (3 per CU fit) */
     if (tpw == 2 && nrows * 4 <= FM_PRE * FM_NT && (size_t)((tiles + 1) / 2) * (M / 16) >= 384) {
         if (!out_tm)
             hipLaunchKernelGGL((k_fir_mfma16<false, 2, true>), dim3((tiles + 1) / 2, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                               (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+                               (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
         else
             hipLaunchKernelGGL((k_fir_mfma16<false, 2, false>), dim3((tiles + 1) / 2, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                               (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+                               (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
         return (int)hipGetLastError();
     }
     if (nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
     if (!out_tm)
         hipLaunchKernelGGL((k_fir_mfma16<false, 1, true>), dim3(tiles, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
     else
         hipLaunchKernelGGL((k_fir_mfma16<false, 1, false>), dim3(tiles, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, ablate, M);
+                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
     return (int)hipGetLastError();
 }

@@ -14,6 +14,24 @@ extern "C" {
 
 typedef void *pmr_stream_t;     /* hipStream_t */
 
+/* A/B switches: read from the environment ONCE per handle by pmr_chain_create and handed to the launchers;
+ * nothing on a launch path calls getenv.  All zero = the product. */
+enum { PMR_FIR_MFMA = 0, PMR_FIR_PAIR = 1, PMR_FIR_LDS = 2, PMR_FIR_TM = 3 };
+typedef struct {
+    int fe_staged;          /* PMR_FRONTEND=staged: one kernel per front-end stage                         */
+    int fe_generic;         /* PMR_FE_KERNEL=generic: run-time-parameterised k_frontend                     */
+    int fe_levels;          /* PMR_FE_LEVELS=1|2: force the one- / two-level front end (0 = automatic)      */
+    int l2_on_fe;           /* PMR_L2_STREAM=fe: level 2 on the front-end stream                            */
+    int chan_generic;       /* PMR_CHANNELIZER=generic: k_channelize for M = 16 too                         */
+    int chan_pair;          /* PMR_CHANNELIZER_SMALL=pair: two-frames-per-thread small-M channelizer        */
+    int chan_ft;            /* PMR_CHAN_FT=n: tile height of the generic channelizer (0 = automatic)        */
+    int fir_mode;           /* PMR_FIR=pair|lds|global: VALU versions of the audio FIR (PMR_FIR_*)          */
+    int fir_mfma_global;    /* PMR_FIR_MFMA=global: MFMA FIR without the LDS sample window                  */
+    int fir_tpw;            /* PMR_FIR_TPW=1: one tile per workgroup in the MFMA FIR (default 2)            */
+    int no_overlap;         /* PMR_OVERLAP=0                                                                */
+    int equal_prio;         /* PMR_STREAM_PRIO=0                                                            */
+} pmr_switches;
+
 #define PMR_DC_TILE 4096u       /* raw samples per dc-block tile (256 threads x 16) */
 #define PMR_DC_SCAN_THREADS 1024u
 #define PMR_TAP_PAD 64u         /* zeros on both sides of every FIR tap table handed to the FIR kernels */
@@ -62,22 +80,17 @@ typedef struct {
     float fm_ref;
     void *chan_out; unsigned chan_stride;   /* nullable, channel-major [M][chan_stride], frame index relative */
     float *rssi_part;                       /* nullable, [ntiles][M] partial sums of |y|                      */
-    /* deferred dc carry of the fused front end, applied while staging (small-M kernel only); V == NULL: none */
-    const void *V; const float *GA, *T1, *T2;
-    uint64_t fix_abs0; unsigned fix_ny, TQ, HhQ; uint32_t phi0, step; float Kgain;
 } pmr_chan_params;
 
 /* NCO shift + polyphase analysis bank + M-point FFT + discriminator (:808-821, :881), any power-of-two M */
-int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out);
-unsigned pmr_channelize_tiles(unsigned ns, unsigned M);
+int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int ft_forced /*0 = automatic*/);
 int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntiles, unsigned M, unsigned ns,
                            float *rssi_db);
 
 /* small-M specialisation (pmr_channelize_small.hip): thread-per-frame-pair, FFT in registers.  n_valid = valid
  * samples in xr (zeros are read beyond).  Same outputs as pmr_launch_channelize.                       */
 int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned nco_period);
-unsigned pmr_channelize_small_tiles(unsigned ns);
-int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out);
+int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int pair /*two frames per thread*/);
 
 /* time-major real FIR with optional epilogue (:882-904).
  *  in        time-major, in[(t)*M + k], t = 0 first new frame (history at negative t)
@@ -89,14 +102,14 @@ int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsign
  *  pcm/audio nullable channel-major [M][stride] final outputs                                          */
 /*  in / out_tm are row rings: frame t (absolute) at ring[(t & row_mask) * M + k]; row0 = absolute index of the
  *  first new frame.  pcm / audio are the caller's channel-major buffers, frame index relative to row0.          */
-int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                       const float *taps_pad, unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                       float *out_tm, int16_t *pcm, float *audio, unsigned stride);
 
 /* M = 16 audio FIR on the matrix pipe (pmr_fir_mfma.hip): banded-Toeplitz x data with v_mfma_f32_32x32x2_f32 */
 int pmr_fir_mfma_supported(unsigned M, unsigned ntaps);
-int pmr_launch_fir_mfma(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
-                        const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio,
+int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
+                        unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio,
                         unsigned stride);
 
 /* ---- CTCSS branch (pmr_ctcss.hip) ---- */
@@ -139,9 +152,9 @@ typedef struct {
      * of level-1 tile c1 = j / fix_TQ is subtracted at load: V[c1] * fix_K * mu^(j - c1 fix_TQ + fix_HhQ)       */
     const void *in_ring; uint64_t in_mask; int64_t in_abs0;
     const void *fixV; const float *fix_T1, *fix_T2; unsigned fix_TQ, fix_HhQ; float fix_K;
+    unsigned fix_limit;         /* new samples with index >= fix_limit were already corrected in place (k_fe_carry)   */
+    uint32_t step_rinv;         /* floor(2^56 / step) clamped to 32 bits: integer ceil-division by the resampler step */
     void *tile_j;               /* nullable [ntiles][2] u64: the tile's resampler output range [ja, jb), for k_fe_tilefix */
-    void *stamps;               /* diagnostic: 8 x u64 per-phase cycle sums (PMR_FE_STAMP), else NULL  */
-    int ablate;                 /* timing experiments only (PMR_FE_ABLATE): bit0 skip load, 1 dc, 2 cascade, 3 resampler */
     int m[PMR_FE_MAX_STAGES], tap_off[PMR_FE_MAX_STAGES];
     float dc_a1, zeta, lam_wave;
     float lam_pow16[6];         /* lambda^(spt * 2^j)                                                */
@@ -168,13 +181,16 @@ typedef struct {
     float Kgain;
 } pmr_fe_fix_params;
 
-int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt);
-int pmr_launch_fe_tiles(pmr_stream_t s, const pmr_fe_tiles_params *p);
-int pmr_launch_fe_dcfix(pmr_stream_t s, const pmr_fe_fix_params *p);
+int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt, int generic);
+/* level 2 of the two-level front end: the specialised k_fe_level2 (m = 5, 10 + resampler, 2048-sample tiles) or the generic
+ * k_frontend in mode 2 (4096-sample tiles) */
+int pmr_launch_frontend_l2(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int fast);
+/* specialised kernels of pmr_fe_fast.hip; return -1 when the cascade is not one they cover */
+int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles);
+/* tile carries of a level-1 launch (V[c], next call's dc state) + in-place dc fix of the ring samples [f->j0, f->ny) */
+int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f);
 /* both of the above in one launch (one wave per tile): carries, then the whole block's correction in place */
 int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q);
-int pmr_launch_fe_hist(pmr_stream_t s, const void *old_hist, const void *x, unsigned n_in, void *new_hist,
-                       unsigned hcap);
 
 #ifdef __cplusplus
 }

@@ -200,11 +200,9 @@ static __host__ __device__ inline unsigned chan_ft_auto(unsigned M, unsigned ns)
     if (want < 2u) want = 2u;
     return want < cap ? want : cap;
 }
-// the tile height is chosen on the host (PMR_CHAN_FT overrides it for experiments) and handed to the kernel
-static unsigned chan_ft(unsigned M, unsigned ns)
+// the tile height is chosen on the host (`forced` = PMR_CHAN_FT, for experiments) and handed to the kernel
+static unsigned chan_ft(unsigned M, unsigned ns, int forced)
 {
-    static int forced = -1;
-    if (forced < 0) { const char *e = getenv("PMR_CHAN_FT"); forced = e ? atoi(e) : 0; }
     if (forced >= 2) { unsigned cap = 8192u / M; if (cap < 2u) cap = 2u; return (unsigned)forced < cap ? (unsigned)forced : cap; }
     return chan_ft_auto(M, ns);
 }
@@ -706,18 +704,12 @@ extern "C" int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out_ring, u
     return (int)hipGetLastError();
 }
 
-extern "C" unsigned pmr_channelize_tiles(unsigned ns, unsigned M)
+extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int ft_forced)
 {
-    const unsigned tfn = chan_ft(M, ns) - 1;
-    return (ns + tfn - 1) / tfn;
-}
-
-extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out)
-{
-    const unsigned ntiles = pmr_channelize_tiles(p->ns, p->M);
+    const unsigned ft = chan_ft(p->M, p->ns, ft_forced);
+    const unsigned ntiles = (p->ns + ft - 2) / (ft - 1);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
-    const unsigned ft = chan_ft(p->M, p->ns);
     const size_t lds = ((size_t)ft * p->M + p->M / 2) * sizeof(cf);
     static unsigned long long attr_set = 0;
     if (pmr_attr_needed(attr_set)) {
@@ -736,19 +728,15 @@ extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, un
     return (int)hipGetLastError();
 }
 
-extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
-                                 unsigned M, const float *taps_pad, unsigned ntaps, float gain, int iir, float b0,
+extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
+                                 unsigned ns, unsigned M, const float *taps_pad, unsigned ntaps, float gain, int iir, float b0,
                                  float b1, float a1, float *out_tm, int16_t *pcm, float *audio, unsigned stride)
 {
     if (!ns) return 0;
-    static int mode = -1;                    /* 3 = mfma (default where supported), 0 = pair, 1 = lds, 2 = global */
-    if (mode < 0) {
-        const char *e = getenv("PMR_FIR");
-        mode = (e && !strcmp(e, "lds")) ? 1 : (e && !strcmp(e, "global")) ? 2 : (e && !strcmp(e, "pair")) ? 0 : 3;
-    }
-    if (mode == 3 && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
-        return pmr_launch_fir_mfma(s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride);
-    if ((mode == 0 || mode == 3) && M >= 2) {
+    const int mode = sw->fir_mode;           /* PMR_FIR_MFMA (default where supported), _PAIR, _LDS, _TM */
+    if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
+        return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride);
+    if ((mode == PMR_FIR_PAIR || mode == PMR_FIR_MFMA) && M >= 2) {
         const unsigned segs = (ns + FP_R - 1) / FP_R;
         const size_t threads = (size_t)segs * (M >> 1);
         hipLaunchKernelGGL(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
@@ -756,7 +744,7 @@ extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_m
                            ilog2(M >> 1), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
         return (int)hipGetLastError();
     }
-    if (mode == 1 && M >= 16 && ntaps <= 512) {
+    if (mode == PMR_FIR_LDS && M >= 16 && ntaps <= 512) {
         const unsigned rows = FL_T + PMR_AUDIO_J + ntaps - 1;
         const size_t lds = ((size_t)rows * 16 + 16 * ((rows >> 5) + 1)) * sizeof(float);
         static unsigned long long attr_set = 0;

@@ -27,6 +27,22 @@ def channel_kind(k):
     return "fm"
 
 
+def dc_block_gain(k, num_channels, fs_in, alpha=0.0005):
+    """|H(f_k)| of the chain's own dc blocker (reference src/sdr_pmr446.c:422, H(z) = (1 - z^-1)/(1 - (1-alpha) z^-1)) at the
+    centre of channel k.  At GS/s input rates the notch (~alpha fs / 2 pi wide) swallows the channels next to band centre."""
+    w = 2.0 * np.pi * (k - (num_channels - 1) / 2.0) * CHANNEL_WIDTH_HZ / fs_in
+    z = np.exp(-1j * w)
+    return float(abs(1.0 - z) / abs(1.0 - (1.0 - alpha) * z))
+
+
+def signal_channels(num_channels, fs_in=None, synthesized=None, min_dc_gain=0.5):
+    """Channels whose PCM is compared: they carry a signal (not 'empty': the discriminator of pure noise is ill-conditioned,
+    SURVEY s7) and, when fs_in is given, the chain's dc-block notch leaves them within 6 dB of nominal (same reason)."""
+    ks = range(num_channels) if synthesized is None else synthesized
+    return [k for k in ks if channel_kind(k) != "empty" and
+            (fs_in is None or dc_block_gain(k, num_channels, fs_in) >= min_dc_gain)]
+
+
 def audio_tone_hz(k):
     return 400.0 + 37.0 * (k % 64)
 

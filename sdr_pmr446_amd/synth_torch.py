@@ -12,9 +12,12 @@ from .synth import CHANNEL_WIDTH_HZ, CTCSS_FREQS, SEED_BASE, audio_tone_hz, chan
 
 
 def synth_iq_torch(n, fs_in, num_channels, device, stream_id=0, snr_db=30.0, dev_hz=2500.0, ctcss_dev_hz=300.0,
-                   chunk_elems=1 << 24, channels=None):
+                   chunk_elems=1 << 24, channels=None, periodic=False):
     """complex64 tensor [n] on `device` (viewable as float32 [n, 2], i.e. interleaved cf32).
-    channels: channel indices to synthesise (default all M); amplitudes / noise do not depend on it."""
+    channels: channel indices to synthesise (default all M); amplitudes / noise do not depend on it.
+    periodic: snap every carrier / tone frequency to the grid fs_in / n (< fs_in / 2n off, i.e. a few Hz), so that the block
+    REPEATED back to back is one phase-continuous stream (bench.py feeds the same block every step; without this every block
+    boundary is a phase jump in all carriers -- a click the discriminator sees)."""
     M = num_channels
     g = torch.Generator(device=device)
     g.manual_seed((SEED_BASE + stream_id) & 0x7FFFFFFFFFFFFFFF)
@@ -25,6 +28,9 @@ def synth_iq_torch(n, fs_in, num_channels, device, stream_id=0, snr_db=30.0, dev
     fm_on = torch.tensor([1.0 if channel_kind(k) == "fm" else 0.0 for k in ks], dtype=torch.float64, device=device)
     fa = torch.tensor([audio_tone_hz(k) for k in ks], dtype=torch.float64, device=device)
     fc = torch.tensor([float(CTCSS_FREQS[k % 38]) for k in ks], dtype=torch.float64, device=device)
+    if periodic:
+        grid = fs_in / n
+        fk, fa, fc = (torch.round(v / grid) * grid for v in (fk, fa, fc))
     ph0 = torch.rand(len(ks), generator=g, device=device, dtype=torch.float64) * (2 * math.pi)
     out = torch.empty(n, dtype=torch.complex64, device=device)
     chunk = max(1024, chunk_elems // max(1, len(ks)))

@@ -10,9 +10,10 @@ CFG3 = (61.44e6, 256)       # configs[2]/[3]
 CFG5 = (1.0e9, 1024)        # configs[4]
 
 
-def active_channels(M, synthesized=None):
-    ks = range(M) if synthesized is None else synthesized
-    return [k for k in ks if synth.channel_kind(k) != "empty"]
+def active_channels(M, synthesized=None, fs=None):
+    """Channels compared against the oracle (synth.signal_channels): not empty, and -- when fs is given -- not inside the
+    chain's own dc-block notch (at 1 GS/s the 80 kHz notch attenuates the ~8 channels around band centre by > 6 dB)."""
+    return synth.signal_channels(M, fs, synthesized)
 
 
 def run_blocks(chain, x, splits, want):

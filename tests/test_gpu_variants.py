@@ -40,8 +40,8 @@ VARIANTS = [
     ({"PMR_FE_KERNEL": "generic"}, CFG2),
     ({"PMR_FE_LEVELS": "2"}, CFG3),
     ({"PMR_L2_STREAM": "fe"}, CFG5),
-    ({"PMR_TILEFIX_STREAM": "be"}, CFG2),
-    ({"PMR_DCFIX_FUSE": "1"}, CFG2),
+    ({"PMR_FE_KERNEL": "generic"}, CFG5),
+    ({"PMR_FE_LEVELS": "1"}, CFG5),
     ({"PMR_CHANNELIZER": "generic"}, CFG2),
     ({"PMR_CHANNELIZER_SMALL": "pair"}, CFG2),
     ({"PMR_CHAN_FT": "7"}, CFG3),
