@@ -80,6 +80,8 @@ struct pmr_chain_s {
     /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
     pmr_switches sw;                 /* A/B switches, read once from the environment at create */
     int chan_small;                  /* small-M channelizer (pmr_channelize_small.hip) selected       */
+    int chan_wide;                   /* wide-bank channelizer (pmr_channelize_wide.hip: filter bank + radix-4 FFT kernels) */
+    cfl *d_chan_x;                   /* its scratch: polyphase bank outputs [chan_size + 1][M]         */
     int fe_on, fe_nt, fe_spt;        /* fused path selected; threads per tile workgroup, samples per thread */
     int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
     int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
@@ -523,6 +525,8 @@ static int chain_init(pmr_chain q)
 
     if ((rc = fe_init(q))) return rc;
     q->chan_small = !q->sw.chan_generic && pmr_channelize_small_supported(M, p, d->nco_period);
+    q->chan_wide = !q->sw.chan_generic && !q->chan_small && pmr_channelize_wide_supported(M, p, d->nco_period);
+    if (q->chan_wide && (rc = dev_alloc(q, (void **)&q->d_chan_x, ((size_t)q->chan_size + 2) * M * sizeof(cfl)))) return rc;
     q->l2_on_backend = !q->sw.l2_on_fe;
 
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0;
@@ -624,7 +628,7 @@ int pmr_chain_destroy(pmr_chain q)
     void *bufs[] = { q->d_arb_bank, q->d_pfb_taps_t, q->d_fft_tw, q->d_nco_cs, q->d_lam_thread_pow,
                      q->d_lam_tile_idx_pow, q->d_hp_pad, q->d_lp_pad, q->d_de_pad, q->d_in, q->d_dc_state,
                      q->d_dc_agg, q->d_dc_W, q->d_xr, q->d_fm, q->d_aux1, q->d_aux2, q->d_scratch, q->d_pcm,
-                     q->d_audio, q->d_chan, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
+                     q->d_audio, q->d_chan, q->d_chan_x, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
                      q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
@@ -1121,6 +1125,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         c.fm_ref = d->fm_ref; c.chan_out = d_chan_out; c.chan_stride = pcm_stride;
         c.rssi_part = d_rssi_db ? q->d_rssi_part : NULL;
         if (q->chan_small) LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles, q->sw.chan_pair));
+        else if (q->chan_wide) LAUNCH(K_CHANNELIZE, pmr_launch_channelize_wide(q->stream, &c, q->d_chan_x, &ntiles));
         else LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles, q->sw.chan_ft));
         if (q->dbg_on) {
             /* discriminator rows of this block, time-major, linearised */

@@ -1,0 +1,192 @@
+// pmr_channelize_wide.hip -- channelizer + discriminator for WIDE banks (M = 64, 256, 1024, 4096: powers of four) on gfx950.
+//
+// reference: NCO shift src/sdr_pmr446.c:808-812, firpfbch_crcf_analyzer_execute :814, transpose :819-821, freqdem :881.
+// Sums: tests/chain_model.py  (X_c[t] = sum_k taps_t[k][c] * xm[(t - (p-1) + k) * M + c],  y[t] = FFT_M(X[t])).
+//
+// A block holds few frames when M is large (cfg5: 838 frames of 1024 channels), so a frame-tiled kernel yields a few hundred
+// workgroups that each walk filter bank -> log2(M) barrier passes of a radix-2 FFT -> discriminator: latency, not work, set its
+// time.  Here the two halves get the parallelism each one has:
+//   k_pfb_wide   filter bank only, parallel over CHANNELS x frame groups: thread = (channel, F = 8 consecutive frames); the 26
+//                branch taps sit in registers, the group's F + 25 input rows come straight from the resampled ring (a wave
+//                reads 512 contiguous bytes per row), every sample is loaded and NCO-mixed once and feeds up to F frames.
+//                X goes to a scratch array [ns + 1][M] (row 0 = the frame before the block, recomputed from the ring so calls
+//                stay independent); it is 8 * rate bytes per input sample and lives in L2 / Infinity Cache.
+//   k_fft_disc   FFT + discriminator, parallel over FRAMES: a workgroup owns FPW consecutive rows of X (the first is the
+//                previous frame), runs FPW radix-4 Stockham FFTs side by side in LDS (log4(M) passes instead of log2(M),
+//                natural order in and out, twiddles from an LDS copy of the table) and writes the FPW - 1 new
+//                discriminator rows, the channel-major tap-off and the RSSI partial sums.
+// The FFT's butterfly order differs from the oracle's radix-2 DIT; the difference is float32 rounding (~1e-7 of the frame's
+// RMS), far inside the 1e-5 / +-1 LSB parity tolerances (tests/test_gpu_parity.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmr_kernels.h"
+
+typedef float cf __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ cf cfm(float r, float i) { return cf{r, i}; }
+static __device__ __forceinline__ cf cmul(cf a, cf w) { return __builtin_elementwise_fma(cf{a.x, a.x}, w, cf{a.y, a.y} * cf{-w.y, w.x}); }
+
+#define PW_F 8          /* frames per (channel, group) work item of the filter bank */
+#define PW_P 26         /* branch taps (2 m, m = 13: reference :437) */
+
+__global__ __launch_bounds__(256) void k_pfb_wide(pmr_chan_params q, unsigned log2M, cf *__restrict__ Xg)
+{
+    const unsigned M = q.M, nrows = q.ns + 1;                    // row r of Xg <-> frame (frame0 - 1 + r)
+    const unsigned w = blockIdx.x * 256u + threadIdx.x;
+    const unsigned c = w & (M - 1), r0 = (w >> log2M) * PW_F;
+    if (r0 >= nrows) return;
+    const cf *__restrict__ xr = (const cf *)q.xr;
+    const cf *__restrict__ nco_cs = (const cf *)q.nco_cs;
+    const unsigned nco_mask = q.nco_period - 1, xr_mask32 = (unsigned)q.xr_mask;
+    float h[PW_P];
+#pragma unroll
+    for (int k = 0; k < PW_P; k++) h[k] = q.taps_t[k * M + c];
+    cf acc[PW_F];
+#pragma unroll
+    for (int f = 0; f < PW_F; f++) acc[f] = cfm(0.f, 0.f);
+    // low 32 bits of the absolute sample index are all the ring / NCO masks need (indices before the stream start wrap into
+    // the zero-initialised top of the ring, as in k_channelize)
+    const long long fbase = (long long)q.frame0 - 1 + r0 - (PW_P - 1);      // absolute frame of (f = 0, k = 0)
+    const unsigned a0 = (unsigned)((unsigned long long)fbase * (unsigned long long)M) + c;
+    // the NCO table has period 2 M (reference :432-434: d theta = -2 pi (M-1)/(2M)), so a thread meets only two factors: one on
+    // even rows of its window, one on odd rows
+    const cf cs_e = nco_cs[a0 & nco_mask], cs_o = nco_cs[(a0 + M) & nco_mask];
+    constexpr int RB = 11;                                       // rows per batch: loads first, then the MACs
+#pragma unroll
+    for (int rr0 = 0; rr0 < PW_F + PW_P - 1; rr0 += RB) {
+        cf xm[RB];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const int r = rr0 + u;
+            if (r < PW_F + PW_P - 1) {
+                const unsigned a = a0 + (unsigned)r * M;
+                const cf x = xr[a & xr_mask32];
+                const cf cs = (r & 1) ? cs_o : cs_e;
+                xm[u] = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));   // x * conj(e^{j theta})
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const int r = rr0 + u;
+            if (r < PW_F + PW_P - 1) {
+#pragma unroll
+                for (int f = (r - PW_P + 1 > 0 ? r - PW_P + 1 : 0); f <= (r < PW_F - 1 ? r : PW_F - 1); f++)
+                    acc[f] = __builtin_elementwise_fma(cf{h[r - f], h[r - f]}, xm[u], acc[f]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int f = 0; f < PW_F; f++)
+        if (r0 + f < nrows) Xg[(size_t)(r0 + f) * M + c] = acc[f];
+}
+
+// M-point forward FFTs of FPW rows, radix-4 Stockham (natural order in and out), ping-pong between two LDS arrays.
+//   pass Ns = 1, 4, 16, ...:  butterfly j of an FFT reads in[j + r M/4] (r = 0..3), multiplies by W_{4 Ns}^{r (j mod Ns)}, takes the
+//   4-point DFT and writes out[(j / Ns) 4 Ns + (j mod Ns) + r Ns].
+template <int M, int FPW>
+__global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *__restrict__ Xg)
+{
+    constexpr int NB = FPW * (M / 4), NPT = NB / 256;            // butterflies per pass; per thread
+    static_assert(NB % 256 == 0 && NPT >= 1, "butterflies must tile the workgroup");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf *A = reinterpret_cast<cf *>(smem), *B = A + FPW * M, *tw = B + FPW * M;      // [FPW][M] x 2, [M/2]
+    const int tid = threadIdx.x;
+    const unsigned ns = q.ns;
+    const unsigned row0 = blockIdx.x * (FPW - 1);                // first row of Xg this workgroup reads (= previous frame)
+    const unsigned nrow = min((unsigned)FPW, ns + 1 - row0);     // valid rows; new frames: nrow - 1
+
+    for (int k = tid; k < M / 2; k += 256) tw[k] = ((const cf *)q.fft_tw)[k];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(Xg + (size_t)row0 * M);
+        float4 *dst = reinterpret_cast<float4 *>(A);
+        for (int i = tid; i < FPW * M / 2; i += 256) dst[i] = (unsigned)(2 * i) < nrow * M ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const auto twid = [&](int i) {                                // e^{-2 pi j i / M}, i in [0, M)
+        const cf w = tw[i & (M / 2 - 1)];
+        return i >= M / 2 ? -w : w;
+    };
+    cf *in = A, *out = B;
+#pragma unroll
+    for (int Ns = 1; Ns < M; Ns *= 4) {
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int idx = tid + 256 * u, f = idx / (M / 4), j = idx % (M / 4), k = j & (Ns - 1);
+            const cf *x = in + f * M + j;
+            cf v0 = x[0], v1 = x[M / 4], v2 = x[M / 2], v3 = x[3 * M / 4];
+            if (Ns > 1) {
+                const int ti = k * (M / (4 * Ns));
+                v1 = cmul(v1, twid(ti)); v2 = cmul(v2, twid(2 * ti)); v3 = cmul(v3, twid(3 * ti));
+            }
+            const cf t0 = v0 + v2, t1 = v0 - v2, t2 = v1 + v3, d = v1 - v3, t3 = cfm(d.y, -d.x);     // t3 = -j (v1 - v3)
+            cf *y = out + f * M + (j - k) * 4 + k;
+            y[0] = t0 + t2; y[Ns] = t1 + t3; y[2 * Ns] = t0 - t2; y[3 * Ns] = t1 - t3;
+        }
+        __syncthreads();
+        cf *tmp = in; in = out; out = tmp;
+    }
+    // ---- discriminator (:881) m = arg(conj(prev) cur) / (2 pi kf) for the new frames, tap-off, RSSI partial sums ----
+    const cf *Y = in;
+    cf *__restrict__ chan_out = (cf *)q.chan_out;
+    const unsigned nnew = nrow - 1;
+    for (unsigned wi = tid; wi < nnew * M; wi += 256) {
+        const unsigned f = wi / M, k = wi % M;
+        const cf pv = Y[f * M + k], cu = Y[(f + 1) * M + k];
+        const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
+        const unsigned t = row0 + f;                             // frame relative to frame0
+        q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = atan2f(im, re) * q.fm_ref;
+        if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
+    }
+    if (q.rssi_part) {
+        for (unsigned k = tid; k < M; k += 256) {
+            float a = 0.f;
+            for (unsigned f = 0; f < nnew; f++) { const cf cu = Y[(f + 1) * M + k]; a += hypotf(cu.x, cu.y); }
+            q.rssi_part[(size_t)blockIdx.x * M + k] = a;
+        }
+    }
+}
+
+template <int M, int FPW>
+static int launch_fft_disc(hipStream_t st, const pmr_chan_params *p, const cf *Xg, unsigned *ntiles_out)
+{
+    const unsigned ntiles = (p->ns + FPW - 2) / (FPW - 1);
+    if (ntiles_out) *ntiles_out = ntiles;
+    const size_t lds = ((size_t)2 * FPW * M + M / 2) * sizeof(cf);
+    static unsigned long long attr_set = 0;
+    int dev = 0;
+    if (lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(attr_set >> dev & 1ull)) {
+        attr_set |= 1ull << dev;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_disc<M, FPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    hipLaunchKernelGGL((k_fft_disc<M, FPW>), dim3(ntiles), dim3(256), lds, st, *p, Xg);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_channelize_wide_supported(unsigned M, unsigned p, unsigned nco_period)
+{
+    /* the filter-bank kernel keeps two NCO factors per thread: the table's period must divide 2 M (it is exactly 2 M) */
+    return p == PW_P && (M == 64 || M == 256 || M == 1024 || M == 4096) && nco_period && (2 * M) % nco_period == 0;
+}
+
+/* scratch: (ns_max + 1) * M complex floats */
+extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out)
+{
+    if (ntiles_out) *ntiles_out = 0;
+    if (!p->ns) return 0;
+    hipStream_t st = (hipStream_t)s;
+    unsigned log2M = 0;
+    while ((1u << log2M) < p->M) log2M++;
+    const unsigned groups = (p->ns + 1 + PW_F - 1) / PW_F;
+    const size_t threads = (size_t)groups * p->M;
+    hipLaunchKernelGGL(k_pfb_wide, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, *p, log2M, (cf *)x_scratch);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    switch (p->M) {
+    case 64:   return launch_fft_disc<64, 32>(st, p, (const cf *)x_scratch, ntiles_out);
+    case 256:  return launch_fft_disc<256, 8>(st, p, (const cf *)x_scratch, ntiles_out);
+    case 1024: return launch_fft_disc<1024, 2>(st, p, (const cf *)x_scratch, ntiles_out);
+    case 4096: return launch_fft_disc<4096, 2>(st, p, (const cf *)x_scratch, ntiles_out);
+    }
+    return (int)hipErrorInvalidValue;
+}

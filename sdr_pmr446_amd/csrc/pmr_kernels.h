@@ -87,6 +87,11 @@ int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *nt
 int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntiles, unsigned M, unsigned ns,
                            float *rssi_db);
 
+/* wide banks (pmr_channelize_wide.hip, M = 64 / 256 / 1024 / 4096): filter-bank kernel parallel over channels, then radix-4
+ * FFT + discriminator kernel parallel over frames; x_scratch holds (ns + 1) * M complex floats.  Same outputs. */
+int pmr_channelize_wide_supported(unsigned M, unsigned p, unsigned nco_period);
+int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out);
+
 /* small-M specialisation (pmr_channelize_small.hip): thread-per-frame-pair, FFT in registers.  n_valid = valid
  * samples in xr (zeros are read beyond).  Same outputs as pmr_launch_channelize.                       */
 int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned nco_period);

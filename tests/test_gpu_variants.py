@@ -43,8 +43,9 @@ VARIANTS = [
     ({"PMR_FE_KERNEL": "generic"}, CFG5),
     ({"PMR_FE_LEVELS": "1"}, CFG5),
     ({"PMR_CHANNELIZER": "generic"}, CFG2),
+    ({"PMR_CHANNELIZER": "generic"}, CFG5),
+    ({"PMR_CHANNELIZER": "generic", "PMR_CHAN_FT": "7"}, CFG3),
     ({"PMR_CHANNELIZER_SMALL": "pair"}, CFG2),
-    ({"PMR_CHAN_FT": "7"}, CFG3),
     ({"PMR_FIR": "pair"}, CFG2),
     ({"PMR_FIR_MFMA": "global"}, CFG2),
     ({"PMR_FIR_TPW": "1"}, CFG2),

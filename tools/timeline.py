@@ -6,7 +6,7 @@ rows = []
 with open(path) as f:
     for r in csv.DictReader(f):
         n = r["Kernel_Name"]
-        if not any(k in n for k in ("k_frontend", "k_channelize", "k_fir", "k_fe_", "k_rssi", "k_ct_")):
+        if not any(k in n for k in ("k_frontend", "k_channelize", "k_fir", "k_fe_", "k_rssi", "k_ct_", "k_pfb", "k_fft")):
             continue
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n.split("(")[0][:40]))
 rows.sort()
