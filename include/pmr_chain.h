@@ -91,6 +91,16 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
                                    void *d_pcm, void *d_audio, unsigned pcm_stride, unsigned *n_frames,
                                    void *d_chan_out, void *d_rssi_db);
 int   pmr_chain_synchronize(pmr_chain q);
+
+/* ---- SURVEY s8 row f1, second half: demodulate only the OPEN channels (the reference's own semantics, src/sdr_pmr446.c:876-877;
+ * the squelch state machine hands over the active channel, :834-839).  mask_words: bit (k & 63) of word k >> 6 enables
+ * channel k, n_words * 64 >= M; NULL = every channel (the default).  Channelizer, RSSI and the discriminator keep running for
+ * every channel, so a channel that is opened later starts with current filter history; the audio FIR / PCM / CTCSS branch
+ * run for the enabled channels only and the pcm / audio rows of disabled channels are left untouched.
+ * pmr_chain_reset_channel = freqdem_reset + ctcss_detector_reset of one channel (what the reference does when the squelch
+ * detunes, :866-867): the channel's first discriminator output of the next block is arg(0) = 0. ---- */
+int   pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned n_words);
+int   pmr_chain_reset_channel(pmr_chain q, unsigned channel);
 /* Consecutive blocks pipeline on two HIP streams (front end of block b+1 under the back end of block b); 0 runs
  * every block start-to-finish before the next one (kernel timings then are uncontended).  Default: on.          */
 int   pmr_chain_set_overlap(pmr_chain q, int on);

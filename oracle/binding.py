@@ -65,6 +65,7 @@ def lib():
         L.orc_chain_create.restype = C.c_void_p
         L.orc_chain_reset.argtypes = [C.c_void_p]
         L.orc_chain_destroy.argtypes = [C.c_void_p]
+        L.orc_chain_reset_channel.argtypes = [C.c_void_p, C.c_uint]
         L.orc_chain_max_frames.argtypes = [C.c_void_p]
         L.orc_chain_max_frames.restype = C.c_uint
         L.orc_chain_max_resampled.argtypes = [C.c_void_p]
@@ -162,6 +163,9 @@ class OracleChain:
 
     def reset(self):
         lib().orc_chain_reset(self.h)
+
+    def reset_channel(self, k):
+        lib().orc_chain_reset_channel(self.h, k)
 
     def info(self, what, idx=0):
         return lib().orc_chain_info(self.h, what, idx)

@@ -171,6 +171,15 @@ int orc_chain_reset(orc_chain *q)
     return 0;
 }
 
+/* what the reference does to its single demodulator when the squelch detunes, src/sdr_pmr446.c:866-867 */
+int orc_chain_reset_channel(orc_chain *q, unsigned channel)
+{
+    if (!q || channel >= q->M) return 1;
+    orc_freqdem_reset(&q->ch[channel].fm_demod);          /* :866 */
+    ctcss_detector_reset(&q->ch[channel].ctcss);          /* :867 */
+    return 0;
+}
+
 int orc_chain_destroy(orc_chain *q)
 {
     if (!q) return 0;

@@ -77,6 +77,7 @@ typedef struct {
 void       orc_chain_default_cfg(orc_chain_cfg *cfg);
 orc_chain *orc_chain_create(const orc_chain_cfg *cfg);
 int        orc_chain_reset(orc_chain *q);
+int        orc_chain_reset_channel(orc_chain *q, unsigned channel);   /* freqdem_reset + ctcss_detector_reset, :866-867 */
 int        orc_chain_destroy(orc_chain *q);
 unsigned   orc_chain_max_frames(const orc_chain *q);
 unsigned   orc_chain_max_resampled(const orc_chain *q);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read",
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
-    "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read",
+    "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read", "pmr_chain_set_channel_mask", "pmr_chain_reset_channel",
     # include/pmr_dsd.h
     "pmr_dsd_default_cfg", "pmr_dsd_create", "pmr_dsd_reset", "pmr_dsd_destroy", "pmr_dsd_max_out",
     "pmr_dsd_last_error", "pmr_dsd_process_block", "pmr_dsd_process_block_device", "pmr_dsd_synchronize",
@@ -135,6 +135,10 @@ def load(build_if_missing=True):
     L.pmr_chain_debug_enable.restype = i
     L.pmr_chain_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pmr_chain_debug_read.restype = i
+    L.pmr_chain_set_channel_mask.argtypes = [vp, vp, u]
+    L.pmr_chain_set_channel_mask.restype = i
+    L.pmr_chain_reset_channel.argtypes = [vp, u]
+    L.pmr_chain_reset_channel.restype = i
     L.pmr_chain_ctcss_enable.argtypes = [vp, i]
     L.pmr_chain_ctcss_enable.restype = i
     L.pmr_chain_ctcss_read.argtypes = [vp, vp, u, C.POINTER(u)]
@@ -282,6 +286,20 @@ class PmrChain:
 
     def synchronize(self):
         self._check(self._L.pmr_chain_synchronize(self.h))
+
+    def set_channel_mask(self, channels=None):
+        """Demodulate only `channels` (iterable of indices; None = all): reference semantics, src/sdr_pmr446.c:876-877."""
+        if channels is None:
+            self._check(self._L.pmr_chain_set_channel_mask(self.h, None, 0))
+            return
+        words = np.zeros((self.M + 63) // 64, dtype=np.uint64)
+        for k in channels:
+            words[k >> 6] |= np.uint64(1) << np.uint64(k & 63)
+        self._check(self._L.pmr_chain_set_channel_mask(self.h, words.ctypes.data, len(words)))
+
+    def reset_channel(self, k):
+        """freqdem_reset + ctcss_detector_reset of channel k (src/sdr_pmr446.c:866-867)."""
+        self._check(self._L.pmr_chain_reset_channel(self.h, k))
 
     def set_overlap(self, on=True):
         self._check(self._L.pmr_chain_set_overlap(self.h, int(on)))

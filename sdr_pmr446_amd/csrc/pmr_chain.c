@@ -71,6 +71,10 @@ struct pmr_chain_s {
     int16_t *d_pcm; float *d_audio; cfl *d_chan; float *d_rssi, *d_rssi_part;
     size_t rssi_part_cap;
 
+    /* open-channel mask (reference :876-877) and per-channel discriminator reset (:866) */
+    unsigned *d_chan_list; unsigned n_enabled; int mask_on;
+    uint8_t *d_reset_flags, *h_reset_flags; int reset_pending;
+
     /* CTCSS branch (pmr_ctcss.hip), allocated by pmr_chain_ctcss_enable */
     int ct_on; unsigned ct_max_ev, ct_nev_last; int ct_sel;
     float *d_ctlp, *d_ct_taps, *d_ct_agg, *d_ct_W, *d_ct_dcstate, *d_ct_U, *d_ct_coef, *d_ct_part, *d_ct_carry[2];
@@ -523,6 +527,11 @@ static int chain_init(pmr_chain q)
     q->rssi_part_cap = ((size_t)q->chan_size + 2) * M;   /* worst case: one new frame per channelizer tile */
     if ((rc = dev_alloc(q, (void **)&q->d_rssi_part, q->rssi_part_cap * sizeof(float)))) return rc;
 
+    if ((rc = dev_alloc(q, (void **)&q->d_chan_list, (size_t)M * sizeof(unsigned)))) return rc;
+    if ((rc = dev_alloc(q, (void **)&q->d_reset_flags, M))) return rc;
+    if (!(q->h_reset_flags = (uint8_t *)calloc(M, 1))) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+    q->n_enabled = M; q->mask_on = 0; q->reset_pending = 0;
+
     if ((rc = fe_init(q))) return rc;
     q->chan_small = !q->sw.chan_generic && pmr_channelize_small_supported(M, p, d->nco_period);
     q->chan_wide = !q->sw.chan_generic && !q->chan_small && pmr_channelize_wide_supported(M, p, d->nco_period);
@@ -628,7 +637,7 @@ int pmr_chain_destroy(pmr_chain q)
     void *bufs[] = { q->d_arb_bank, q->d_pfb_taps_t, q->d_fft_tw, q->d_nco_cs, q->d_lam_thread_pow,
                      q->d_lam_tile_idx_pow, q->d_hp_pad, q->d_lp_pad, q->d_de_pad, q->d_in, q->d_dc_state,
                      q->d_dc_agg, q->d_dc_W, q->d_xr, q->d_fm, q->d_aux1, q->d_aux2, q->d_scratch, q->d_pcm,
-                     q->d_audio, q->d_chan, q->d_chan_x, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
+                     q->d_audio, q->d_chan, q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
                      q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
@@ -636,6 +645,7 @@ int pmr_chain_destroy(pmr_chain q)
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     if (q->stream) hipStreamDestroy(q->stream);
     pmr_design_free(&q->d);
+    free(q->h_reset_flags);
     free(q);
     return PMR_OK;
 }
@@ -672,6 +682,7 @@ int pmr_chain_reset(pmr_chain q)
     q->fe_sel = 0;
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
     q->pend_l2 = 0;
+    q->reset_pending = 0; memset(q->h_reset_flags, 0, M);
     HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
     return PMR_OK;
 }
@@ -969,7 +980,7 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns)
     const unsigned M = q->M, N = PMR_CT_BLOCK;
     /* tmp1 = delay188(fm) - hp(fm) (:884-889) as one FIR with taps delta_188 - h */
     LAUNCH(K_CT_FIR, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
-                                       0.f, 0.f, 0.f, q->d_ctlp, NULL, NULL, 0));
+                                       0.f, 0.f, 0.f, q->d_ctlp, NULL, NULL, 0, q->mask_on ? q->d_chan_list : NULL, q->n_enabled));
     const float a1 = -1.0f + 0.0005f;                              /* iirfilt_rrrf_create_dc_blocker(0.0005f), :450 */
     const double lam = -(double)a1;
     const unsigned nchunks = (ns + 255) / 256, len_last = ns - (nchunks - 1) * 256;
@@ -1124,9 +1135,14 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         c.taps_t = q->d_pfb_taps_t; c.fft_tw = q->d_fft_tw; c.nco_cs = q->d_nco_cs; c.nco_period = d->nco_period;
         c.fm_ref = d->fm_ref; c.chan_out = d_chan_out; c.chan_stride = pcm_stride;
         c.rssi_part = d_rssi_db ? q->d_rssi_part : NULL;
+        if (q->reset_pending) {                       /* freqdem_reset (:866) of the flagged channels: takes effect on this call's first frame */
+            HIPCHK(hipMemcpyAsync(q->d_reset_flags, q->h_reset_flags, M, hipMemcpyHostToDevice, q->stream), "reset flags");
+            c.reset_flags = q->d_reset_flags;
+        }
         if (q->chan_small) LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles, q->sw.chan_pair));
         else if (q->chan_wide) LAUNCH(K_CHANNELIZE, pmr_launch_channelize_wide(q->stream, &c, q->d_chan_x, &ntiles));
         else LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles, q->sw.chan_ft));
+        if (q->reset_pending) { q->reset_pending = 0; memset(q->h_reset_flags, 0, M); }
         if (q->dbg_on) {
             /* discriminator rows of this block, time-major, linearised */
             if ((rc = ring_to_linear(q, q->d_dbg_fm, q->d_fm, q->fm_mask, (uint64_t)frame0, ns, (size_t)M * sizeof(float))))
@@ -1140,23 +1156,27 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906) */
         if (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass) {
             const int more = q->cfg.deemph_fir || q->cfg.lowpass;
+            /* only the open channels are demodulated to audio.  With follow-on FIR passes (deemph_fir / lowpass) the mask
+             * applies to the LAST pass only: the intermediate rings must keep every channel's history current, or a channel
+             * opened later would start from a cold filter */
+            const unsigned *sel = q->mask_on ? q->d_chan_list : NULL;
             LAUNCH(K_FIR_HP, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
                                                1.0f, 0, 0.f, 0.f, 0.f,      /* gain + de-emphasis are in the taps */
                                                more ? q->d_aux1 : NULL, more ? NULL : (int16_t *)d_pcm,
-                                               more ? NULL : (float *)d_audio, pcm_stride));
+                                               more ? NULL : (float *)d_audio, pcm_stride, more ? NULL : sel, q->n_enabled));
             const float *cur = q->d_aux1;
             if (q->cfg.deemph_fir) {
                 const int last = !q->cfg.lowpass;
                 LAUNCH(K_FIR_DE, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
                                                    1.0f, 0, 0.f, 0.f, 0.f, last ? NULL : q->d_aux2,
                                                    last ? (int16_t *)d_pcm : NULL, last ? (float *)d_audio : NULL,
-                                                   pcm_stride));
+                                                   pcm_stride, last ? sel : NULL, q->n_enabled));
                 cur = q->d_aux2;
             }
             if (q->cfg.lowpass) {
                 LAUNCH(K_FIR_LP, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
                                                    1.0f, 0, 0.f, 0.f, 0.f, NULL, (int16_t *)d_pcm, (float *)d_audio,
-                                                   pcm_stride));
+                                                   pcm_stride, sel, q->n_enabled));
             }
         }
     }
@@ -1208,6 +1228,50 @@ int pmr_chain_process_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, int1
 }
 
 /* ------------------------------------------------------------------------------------------- */
+
+/* Open-channel mask: the reference demodulates only the squelch-selected channel (src/sdr_pmr446.c:876-877, hand-off from the
+ * squelch state machine :834-839).  Channelizer, RSSI and the discriminator keep running for EVERY channel (their state and the
+ * audio filters' history therefore stay current for a channel that is opened later); the audio FIR / PCM / CTCSS branch run for
+ * the enabled channels only. */
+int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned n_words)
+{
+    if (!q) return PMR_EINVAL;
+    const unsigned M = q->M;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    if (!mask_words) { q->mask_on = 0; q->n_enabled = M; return PMR_OK; }
+    if ((uint64_t)n_words * 64 < M) return fail(q, PMR_EINVAL, "channel mask shorter than num_channels", hipSuccess);
+    unsigned *list = (unsigned *)malloc((size_t)M * sizeof(unsigned));
+    if (!list) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
+    unsigned n = 0;
+    for (unsigned k = 0; k < M; k++) if (mask_words[k >> 6] >> (k & 63) & 1ull) list[n++] = k;
+    /* the list is read by kernels of calls already queued: let them finish before it changes */
+    hipError_t e = hipStreamSynchronize(q->stream);
+    if (e == hipSuccess && n) e = hipMemcpy(q->d_chan_list, list, (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice);
+    free(list);
+    if (e != hipSuccess) return fail(q, PMR_EHIP, "channel mask upload", e);
+    q->n_enabled = n;
+    q->mask_on = n < M;
+    return PMR_OK;
+}
+
+/* freqdem_reset + ctcss_detector_reset of ONE channel (the reference resets its single demodulator when the squelch detunes,
+ * src/sdr_pmr446.c:866-867).  The discriminator's previous sample becomes zero, so the channel's first output of the next call
+ * is arg(0) = 0; the channel's partial Goertzel sums restart from zero (the 2441-frame block grid itself stays
+ * aligned to the stream: every channel shares it here).  Takes effect on the next process_block call that yields a frame. */
+int pmr_chain_reset_channel(pmr_chain q, unsigned channel)
+{
+    if (!q || channel >= q->M) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    q->h_reset_flags[channel] = 1;
+    q->reset_pending = 1;
+    if (q->d_ct_carry[0]) {
+        HIPCHK(hipStreamSynchronize(q->stream), "reset channel");
+        for (int i = 0; i < 2; i++)
+            HIPCHK(hipMemset((char *)q->d_ct_carry[i] + (size_t)channel * PMR_CT_TONES * 2 * sizeof(float), 0,
+                             (size_t)PMR_CT_TONES * 2 * sizeof(float)), "reset channel");
+    }
+    return PMR_OK;
+}
 
 int pmr_chain_profile_enable(pmr_chain q, int on) { if (!q) return PMR_EINVAL; q->prof_on = on; return PMR_OK; }
 

@@ -24,17 +24,6 @@
 
 #include "pmr_kernels.h"
 
-// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
-// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
-static inline bool pmr_attr_needed(unsigned long long &mask)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    if (mask >> dev & 1ull) return false;
-    mask |= 1ull << dev;
-    return true;
-}
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FM_NT 256
@@ -51,20 +40,37 @@ static __device__ __forceinline__ int16_t pcm16(float y)
 
 #define FM_PRE 11                                /* float4 prefetch registers per thread: windows up to 704 rows */
 
+// GATHER (open-channel mask, reference src/sdr_pmr446.c:876-877: only the squelch-selected channels are demodulated): the 16
+// columns of a tile are 16 arbitrary (channel, 256-frame segment) UNITS instead of 16 adjacent channels at one time -- unit u
+// = (enabled channel u / nseg, segment u % nseg) -- so one enabled channel costs 1/16 of a tile row, not a whole tile.  Only the
+// window staging (4-byte gathers instead of 64-byte rows) and the store addresses differ; the MFMA loop is the same.
 template <bool GLB, int TPW /*tiles per workgroup: 2 = the second tile's window is prefetched under the first tile's MFMAs*/,
-          bool SWAP /*operands exchanged: the accumulators hold the TRANSPOSED tile (lane = frame), see the epilogue*/>
+          bool SWAP /*operands exchanged: the accumulators hold the TRANSPOSED tile (lane = frame), see the epilogue*/,
+          bool GATHER = false>
 __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict__ in, unsigned long long row_mask,
                                                       long long row0, unsigned ns, const float *__restrict__ taps_c,
                                                       unsigned ntaps, float *__restrict__ out_tm,
                                                       int16_t *__restrict__ pcm, float *__restrict__ audio,
-                                                      unsigned stride, unsigned M /*row width, multiple of 16*/)
+                                                      unsigned stride, unsigned M /*row width, multiple of 16*/,
+                                                      const unsigned *__restrict__ chan_list, unsigned n_units, unsigned nseg)
 {
-    // blockIdx.y selects a group of 16 channels: the tile is 16 channels wide whatever M is
-    const unsigned cg0 = blockIdx.y * 16u;
-    in += cg0;
-    if (out_tm) out_tm += cg0;
-    if (pcm) pcm += (size_t)cg0 * stride;
-    if (audio) audio += (size_t)cg0 * stride;
+    static_assert(!GATHER || (TPW == 1 && !GLB), "gathered units: one tile per workgroup, LDS window");
+    __shared__ unsigned s_ch[16];                                    // channel of column slot s (relative to the pointers below)
+    __shared__ long s_t0[16];                                        // first frame of slot s
+    if constexpr (GATHER) {
+        if (threadIdx.x < 16) {
+            const unsigned u = blockIdx.x * 16u + threadIdx.x;
+            s_ch[threadIdx.x] = chan_list[u < n_units ? u / nseg : 0];
+            s_t0[threadIdx.x] = u < n_units ? (long)(u % nseg) * FM_TILE : (long)ns;      // beyond the block: nothing stored
+        }
+    } else {
+        // blockIdx.y selects a group of 16 channels: the tile is 16 channels wide whatever M is
+        const unsigned cg0 = blockIdx.y * 16u;
+        in += cg0;
+        if (out_tm) out_tm += cg0;
+        if (pcm) pcm += (size_t)cg0 * stride;
+        if (audio) audio += (size_t)cg0 * stride;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
     float *Qs = reinterpret_cast<float *>(smem_m);                   // [ntaps + 2*PMR_TAP_PAD] padded taps
     const unsigned qlen = ntaps + 2 * PMR_TAP_PAD;
@@ -95,20 +101,40 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
             if (u < nrows * 4) *reinterpret_cast<float4 *>(Xs + r * 16 + 16 * (r >> 5) + q4) = pre[i];
         }
     };
+    // GATHER staging: element (row r, slot s) = in[frame s_t0[s] - (ntaps-1) + r][s_ch[s]]: 4-byte loads, 42 per thread
+    constexpr int FM_PRE_G = GATHER ? 4 * FM_PRE : 1;
+    float preg[FM_PRE_G];
+    auto issue_g = [&]() {
+#pragma unroll
+        for (int i = 0; i < FM_PRE_G; i++) {
+            const unsigned e = tid + FM_NT * i, r = e >> 4, sl = e & 15;
+            const long t = s_t0[sl] - (long)(ntaps - 1) + r;
+            preg[i] = 0.f;
+            if (e < nrows * 16 && t < (long)ns) preg[i] = in[((unsigned long long)(row0 + t) & row_mask) * M + s_ch[sl]];
+        }
+    };
+    auto commit_g = [&]() {
+#pragma unroll
+        for (int i = 0; i < FM_PRE_G; i++) {
+            const unsigned e = tid + FM_NT * i, r = e >> 4, sl = e & 15;
+            if (e < nrows * 16) Xs[r * 16 + 16 * (r >> 5) + sl] = preg[i];
+        }
+    };
     // GLB: no sample window in LDS at all -- the B operand comes straight from the time-major ring through the vector L1
     // (a wave-instruction touches four 64-byte rows).  With ~2 KB of LDS and < 128 registers a workgroup of this kernel
     // fits NEXT TO the front end's tiles on a CU.
     const long tile0 = (long)blockIdx.x * TPW;
-    if constexpr (!GLB) { issue(tile0 * FM_TILE); commit(); }
+    if constexpr (GATHER) { __syncthreads(); issue_g(); commit_g(); }
+    else if constexpr (!GLB) { issue(tile0 * FM_TILE); commit(); }
     __syncthreads();
 
 #pragma unroll
     for (int it = 0; it < TPW; it++) {
-    const long T0 = (tile0 + it) * FM_TILE;                          // first frame of this tile (relative to row0)
+    const long T0 = GATHER ? 0 : (tile0 + it) * FM_TILE;             // first frame of this tile (relative to row0)
     if (T0 >= (long)ns) break;                                       // uniform
-    const bool more = !GLB && it + 1 < TPW && T0 + FM_TILE < (long)ns;
+    const bool more = !GLB && !GATHER && it + 1 < TPW && T0 + FM_TILE < (long)ns;
     if (more) issue(T0 + FM_TILE);                                   // in flight during this tile's MFMAs
-    const bool active = T0 + 64 * wave < (long)ns;                   // else: whole wave beyond the block
+    const bool active = GATHER || T0 + 64 * wave < (long)ns;         // else: whole wave beyond the block
 
     if (active) {
     f32x16 acc;
@@ -159,8 +185,9 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int i2 = 8 * (r >> 2) + 4 * kk + (r & 3);
-            const int ch2 = i2 & 15, blk2 = i2 >> 4;
-            const long t = T0 + 64 * wave + 32 * blk2 + (lane & 31);
+            const int sl2 = i2 & 15, blk2 = i2 >> 4;
+            const unsigned ch2 = GATHER ? s_ch[sl2] : (unsigned)sl2;
+            const long t = (GATHER ? s_t0[sl2] : T0) + 64 * wave + 32 * blk2 + (lane & 31);
             if (t < (long)ns) {
                 if (pcm) pcm[(size_t)ch2 * stride + t] = pcm16(acc[r]);
                 if (audio) audio[(size_t)ch2 * stride + t] = acc[r];
@@ -171,22 +198,23 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
     const bool vec_ok = ((stride & 3) == 0);
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++) {
-        const long t = T0 + Tj + 8 * g4 + 4 * kk;                    // frame of register 4g (relative to row0)
+        const long t = (GATHER ? s_t0[ch] : T0) + Tj + 8 * g4 + 4 * kk;      // frame of register 4g (relative to row0)
+        const unsigned chs = GATHER ? s_ch[ch] : (unsigned)ch;
         const float y0 = acc[4 * g4], y1 = acc[4 * g4 + 1], y2 = acc[4 * g4 + 2], y3 = acc[4 * g4 + 3];
         if (t + 3 < (long)ns && vec_ok) {
             if (pcm && ((reinterpret_cast<uintptr_t>(pcm) & 7) == 0)) {
                 uint2 w;
                 w.x = (unsigned)(uint16_t)pcm16(y0) | ((unsigned)(uint16_t)pcm16(y1) << 16);
                 w.y = (unsigned)(uint16_t)pcm16(y2) | ((unsigned)(uint16_t)pcm16(y3) << 16);
-                *reinterpret_cast<uint2 *>(pcm + (size_t)ch * stride + t) = w;
+                *reinterpret_cast<uint2 *>(pcm + (size_t)chs * stride + t) = w;
             } else if (pcm) {
-                int16_t *o = pcm + (size_t)ch * stride + t;
+                int16_t *o = pcm + (size_t)chs * stride + t;
                 o[0] = pcm16(y0); o[1] = pcm16(y1); o[2] = pcm16(y2); o[3] = pcm16(y3);
             }
             if (audio && ((reinterpret_cast<uintptr_t>(audio) & 15) == 0))
-                *reinterpret_cast<float4 *>(audio + (size_t)ch * stride + t) = make_float4(y0, y1, y2, y3);
+                *reinterpret_cast<float4 *>(audio + (size_t)chs * stride + t) = make_float4(y0, y1, y2, y3);
             else if (audio) {
-                float *o = audio + (size_t)ch * stride + t;
+                float *o = audio + (size_t)chs * stride + t;
                 o[0] = y0; o[1] = y1; o[2] = y2; o[3] = y3;
             }
         } else {
@@ -194,8 +222,8 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (t + q < (long)ns) {
-                    if (pcm) pcm[(size_t)ch * stride + t + q] = pcm16(yy[q]);
-                    if (audio) audio[(size_t)ch * stride + t + q] = yy[q];
+                    if (pcm) pcm[(size_t)chs * stride + t + q] = pcm16(yy[q]);
+                    if (audio) audio[(size_t)chs * stride + t + q] = yy[q];
                 }
             }
         }
@@ -203,7 +231,7 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
             const float yy[4] = {y0, y1, y2, y3};
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (t + q < (long)ns) out_tm[((unsigned long long)(row0 + t + q) & row_mask) * M + ch] = yy[q];
+                if (t + q < (long)ns) out_tm[((unsigned long long)(row0 + t + q) & row_mask) * M + chs] = yy[q];
         }
     }
     }
@@ -223,51 +251,49 @@ extern "C" int pmr_fir_mfma_supported(unsigned M, unsigned ntaps)
 
 extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
                                    unsigned ns, unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm,
-                                   float *audio, unsigned stride)
+                                   float *audio, unsigned stride, const unsigned *chan_list, unsigned n_chan)
 {
     if (!ns) return 0;
     if (!pmr_fir_mfma_supported(M, ntaps)) return (int)hipErrorInvalidValue;
     const unsigned qlen = ntaps + 2 * PMR_TAP_PAD, nrows = FM_TILE + ntaps + 31;
     const size_t lds = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float) +
                        ((size_t)nrows * 16 + 16 * ((nrows >> 5) + 1)) * sizeof(float);
-    static unsigned long long attr_set = 0;
-    if (pmr_attr_needed(attr_set)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 1, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 1, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 2, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_mfma16<false, 2, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    /* <= 47 KB of dynamic LDS (window of at most 704 rows x 16 columns + taps): inside the 64 KB default limit */
+    hipStream_t st = (hipStream_t)s;
+    const unsigned long long rm = (unsigned long long)row_mask;
+    const long long r0 = (long long)row0;
+    const unsigned tiles = (ns + FM_TILE - 1) / FM_TILE;
+    if (chan_list) {
+        /* open-channel mask: 16 (channel, segment) units per workgroup */
+        if (!n_chan) return 0;
+        if (nrows * 16 > 4 * FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
+        const unsigned n_units = n_chan * tiles;
+        const dim3 grid((n_units + 15) / 16);
+        if (!out_tm)
+            hipLaunchKernelGGL((k_fir_mfma16<false, 1, true, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
+                               out_tm, pcm, audio, stride, M, chan_list, n_units, tiles);
+        else
+            hipLaunchKernelGGL((k_fir_mfma16<false, 1, false, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
+                               out_tm, pcm, audio, stride, M, chan_list, n_units, tiles);
+        return (int)hipGetLastError();
     }
     /* PMR_FIR_MFMA=global: B operand straight from the ring (no LDS window; co-resides with front-end tiles).  Measured
      * on MI355X: slower in isolation (0.082 vs 0.066 ms at cfg2) and equal within noise inside the pipelined chain, so the
      * LDS-window kernel stays the default. */
     if (sw->fir_mfma_global) {
         const size_t lds_g = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float);
-        hipLaunchKernelGGL((k_fir_mfma16<true, 1, false>), dim3((ns + FM_TILE - 1) / FM_TILE, M / 16), dim3(FM_NT), lds_g, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
+        hipLaunchKernelGGL((k_fir_mfma16<true, 1, false>), dim3(tiles, M / 16), dim3(FM_NT), lds_g, st, in, rm, r0, ns, taps_pad,
+                           ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u);
         return (int)hipGetLastError();
     }
-    const unsigned tiles = (ns + FM_TILE - 1) / FM_TILE;
-    const int tpw = sw->fir_tpw;                  /* PMR_FIR_TPW=1: one tile per workgroup, no window prefetch */
     /* two tiles per workgroup only while that still leaves enough workgroups to fill the chip (3 per CU fit) */
-    if (tpw == 2 && nrows * 4 <= FM_PRE * FM_NT && (size_t)((tiles + 1) / 2) * (M / 16) >= 384) {
-        if (!out_tm)
-            hipLaunchKernelGGL((k_fir_mfma16<false, 2, true>), dim3((tiles + 1) / 2, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                               (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
-        else
-            hipLaunchKernelGGL((k_fir_mfma16<false, 2, false>), dim3((tiles + 1) / 2, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                               (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
-        return (int)hipGetLastError();
-    }
-    if (nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
-    if (!out_tm)
-        hipLaunchKernelGGL((k_fir_mfma16<false, 1, true>), dim3(tiles, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
-    else
-        hipLaunchKernelGGL((k_fir_mfma16<false, 1, false>), dim3(tiles, M / 16), dim3(FM_NT), lds, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, taps_pad, ntaps, out_tm, pcm, audio, stride, M);
+    const bool two = sw->fir_tpw == 2 && nrows * 4 <= FM_PRE * FM_NT && (size_t)((tiles + 1) / 2) * (M / 16) >= 384;
+    if (!two && nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
+    const dim3 grid(two ? (tiles + 1) / 2 : tiles, M / 16);
+#define FM_GO(TPW_, SWAP_) hipLaunchKernelGGL((k_fir_mfma16<false, TPW_, SWAP_>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, \
+                                              ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u)
+    if (two) { if (!out_tm) FM_GO(2, true); else FM_GO(2, false); }
+    else     { if (!out_tm) FM_GO(1, true); else FM_GO(1, false); }
+#undef FM_GO
     return (int)hipGetLastError();
 }

@@ -80,6 +80,8 @@ typedef struct {
     float fm_ref;
     void *chan_out; unsigned chan_stride;   /* nullable, channel-major [M][chan_stride], frame index relative */
     float *rssi_part;                       /* nullable, [ntiles][M] partial sums of |y|                      */
+    const uint8_t *reset_flags;             /* nullable, [M]: non-zero = freqdem_reset (:866) before this call's first frame,
+                                               i.e. the channel's first discriminator output is arg(0) = 0   */
 } pmr_chan_params;
 
 /* NCO shift + polyphase analysis bank + M-point FFT + discriminator (:808-821, :881), any power-of-two M */
@@ -107,15 +109,17 @@ int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsign
  *  pcm/audio nullable channel-major [M][stride] final outputs                                          */
 /*  in / out_tm are row rings: frame t (absolute) at ring[(t & row_mask) * M + k]; row0 = absolute index of the
  *  first new frame.  pcm / audio are the caller's channel-major buffers, frame index relative to row0.          */
+/*  chan_list / n_chan: open-channel mask (device array of enabled channel indices; NULL = every channel).  Honoured by the
+ *  MFMA kernel; the VALU A/B versions compute every channel (rows of disabled channels are then written too).   */
 int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                       const float *taps_pad, unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
-                      float *out_tm, int16_t *pcm, float *audio, unsigned stride);
+                      float *out_tm, int16_t *pcm, float *audio, unsigned stride, const unsigned *chan_list, unsigned n_chan);
 
 /* M = 16 audio FIR on the matrix pipe (pmr_fir_mfma.hip): banded-Toeplitz x data with v_mfma_f32_32x32x2_f32 */
 int pmr_fir_mfma_supported(unsigned M, unsigned ntaps);
 int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
                         unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio,
-                        unsigned stride);
+                        unsigned stride, const unsigned *chan_list /*nullable: enabled channels (device)*/, unsigned n_chan);
 
 /* ---- CTCSS branch (pmr_ctcss.hip) ---- */
 #define PMR_CT_TONES 38u

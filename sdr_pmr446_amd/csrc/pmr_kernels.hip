@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned 
         const float re = fmaf(pv.x, cu.x, pv.y * cu.y);
         const float im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
         const unsigned long long row = (unsigned long long)(q.frame0 + t0 + f) & q.fm_mask;
-        q.fm[row * M + k] = atan2f(im, re) * q.fm_ref;
+        const bool rst = t0 + f == 0 && q.reset_flags && q.reset_flags[k];   // freqdem_reset: previous sample = 0 -> arg(0) = 0
+        q.fm[row * M + k] = rst ? 0.f : atan2f(im, re) * q.fm_ref;
         if (chan_out) chan_out[(size_t)k * q.chan_stride + t0 + f] = cu;
     }
     if (q.rssi_part) {
@@ -730,12 +731,13 @@ extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, un
 
 extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
                                  unsigned ns, unsigned M, const float *taps_pad, unsigned ntaps, float gain, int iir, float b0,
-                                 float b1, float a1, float *out_tm, int16_t *pcm, float *audio, unsigned stride)
+                                 float b1, float a1, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
+                                 const unsigned *chan_list, unsigned n_chan)
 {
     if (!ns) return 0;
     const int mode = sw->fir_mode;           /* PMR_FIR_MFMA (default where supported), _PAIR, _LDS, _TM */
     if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
-        return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride);
+        return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan);
     if ((mode == PMR_FIR_PAIR || mode == PMR_FIR_MFMA) && M >= 2) {
         const unsigned segs = (ns + FP_R - 1) / FP_R;
         const size_t threads = (size_t)segs * (M >> 1);
