@@ -84,6 +84,26 @@ int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in,
                                 int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames,
                                 pmr_cf32 *chan_out, float *rssi_db);
 
+/* Asynchronous host-buffer pair: the call pattern of the reference's loop (one readStream block per iteration,
+ * src/sdr_pmr446.c:789-796) with the sink one or two blocks behind.  submit queues H2D copy -> chain -> D2H copy of one block
+ * and returns at once; collect waits for the OLDEST submitted block and hands over its outputs (arguments as for
+ * pmr_chain_process_block_f32; outputs that were not requested in `want` are left untouched).  Up to
+ * pmr_chain_max_in_flight() blocks may sit between the two, so the transfers of one block overlap the kernels of its
+ * neighbours.  `iq` must stay valid and unchanged until the block has been collected; the copies are truly asynchronous only
+ * from pinned memory -- pmr_host_alloc() returns memory pinned in THIS library's HIP runtime. */
+enum { PMR_WANT_PCM = 1, PMR_WANT_AUDIO = 2, PMR_WANT_RSSI = 4, PMR_WANT_CHAN = 8 };
+int      pmr_chain_submit_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, unsigned want /*PMR_WANT_*; 0 = PCM*/);
+/* the same for the other ingest formats of include/pmr_io.h (iq_format: 0 = cf32, 1 = interleaved int16 / 32768, 2 = interleaved
+ * uint8 as (x - 127.5) / 127.5, the rtl_sdr format): the samples cross PCIe as they come from the receiver and are converted
+ * on the device -- 2 or 4 bytes per sample on the host link instead of 8 */
+int      pmr_chain_submit_block_fmt(pmr_chain q, const void *iq, int iq_format, unsigned n_in, unsigned want);
+int      pmr_chain_collect_block(pmr_chain q, int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames,
+                                 pmr_cf32 *chan_out, float *rssi_db);
+unsigned pmr_chain_blocks_in_flight(pmr_chain q);
+unsigned pmr_chain_max_in_flight(pmr_chain q);
+void    *pmr_host_alloc(size_t bytes);                     /* NULL on failure */
+void     pmr_host_free(void *p);
+
 /* Device-resident variant: every pointer is a HIP device pointer on the chain's device; work is queued on
  * the chain's stream and NOT synchronised (call pmr_chain_synchronize).  n_frames is a host pointer and is
  * valid on return (frame counts are closed-form in n_in).                                            */

@@ -26,6 +26,8 @@ ABI_SYMBOLS = [
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
     "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read", "pmr_chain_set_channel_mask", "pmr_chain_reset_channel",
+    "pmr_chain_submit_block", "pmr_chain_submit_block_fmt", "pmr_chain_collect_block", "pmr_chain_blocks_in_flight", "pmr_chain_max_in_flight",
+    "pmr_host_alloc", "pmr_host_free",
     # include/pmr_dsd.h
     "pmr_dsd_default_cfg", "pmr_dsd_create", "pmr_dsd_reset", "pmr_dsd_destroy", "pmr_dsd_max_out",
     "pmr_dsd_last_error", "pmr_dsd_process_block", "pmr_dsd_process_block_device", "pmr_dsd_synchronize",
@@ -34,6 +36,8 @@ ABI_SYMBOLS = [
     "pmr_iq_reader_open", "pmr_iq_reader_read", "pmr_iq_reader_close",
     "pmr_wav_writer_open", "pmr_wav_writer_write_f32", "pmr_wav_writer_write_s16", "pmr_wav_writer_close",
 ]
+
+IQ_CF32, IQ_CS16, IQ_CU8 = 0, 1, 2      # include/pmr_io.h ingest formats
 
 CTCSS_EVENT = np.dtype([("index", np.int32), ("detected", np.int32), ("max_power", np.float32),
                         ("avg_power", np.float32)])
@@ -135,6 +139,19 @@ def load(build_if_missing=True):
     L.pmr_chain_debug_enable.restype = i
     L.pmr_chain_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pmr_chain_debug_read.restype = i
+    L.pmr_chain_submit_block.argtypes = [vp, vp, u, u]
+    L.pmr_chain_submit_block.restype = i
+    L.pmr_chain_submit_block_fmt.argtypes = [vp, vp, i, u, u]
+    L.pmr_chain_submit_block_fmt.restype = i
+    L.pmr_chain_collect_block.argtypes = [vp, vp, vp, u, C.POINTER(u), vp, vp]
+    L.pmr_chain_collect_block.restype = i
+    for name in ("pmr_chain_blocks_in_flight", "pmr_chain_max_in_flight"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = u
+    L.pmr_host_alloc.argtypes = [C.c_size_t]
+    L.pmr_host_alloc.restype = vp
+    L.pmr_host_free.argtypes = [vp]
+    L.pmr_host_free.restype = None
     L.pmr_chain_set_channel_mask.argtypes = [vp, vp, u]
     L.pmr_chain_set_channel_mask.restype = i
     L.pmr_chain_reset_channel.argtypes = [vp, u]
@@ -277,6 +294,9 @@ class PmrChain:
         if getattr(self, "h", None):
             self._L.pmr_chain_destroy(self.h)
             self.h = None
+            for p in getattr(self, "_pinned", []):
+                self._L.pmr_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -345,6 +365,51 @@ class PmrChain:
             fm = self.debug_read(DEBUG_FM, np.float32)
             out["fm"] = fm.reshape(-1, M).T.copy() if len(fm) else np.zeros((M, 0), np.float32)
         return out
+
+    # -- asynchronous host-buffer pair ------------------------------------------------------------
+    WANT = {"pcm": 1, "audio": 2, "rssi": 4, "chan": 8}
+
+    def submit_block(self, iq, want=("pcm",), fmt=IQ_CF32):
+        """Queue one block.  iq: complex64 array (fmt IQ_CF32), or int16 / uint8 array of interleaved I/Q (IQ_CS16 / IQ_CU8,
+        converted on the device); it must stay alive until collected (pinned_array() makes the copy asynchronous)."""
+        if fmt == IQ_CF32:
+            iq = np.ascontiguousarray(iq, dtype=np.complex64); n = len(iq)
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.int16 if fmt == IQ_CS16 else np.uint8).reshape(-1); n = len(iq) // 2
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append((iq, set(want)))
+        w = sum(self.WANT[k] for k in want)
+        self._check(self._L.pmr_chain_submit_block_fmt(self.h, iq.ctypes.data if n else None, fmt, n, w))
+
+    def collect_block(self):
+        """Outputs of the oldest submitted block: dict like process_block."""
+        iq, want = self._pending.pop(0)
+        M, S = self.M, self.max_frames
+        pcm = np.zeros((M, S), dtype=np.int16) if "pcm" in want else None
+        audio = np.zeros((M, S), dtype=np.float32) if "audio" in want else None
+        chan = np.zeros((M, S), dtype=np.complex64) if "chan" in want else None
+        rssi = np.zeros(M, dtype=np.float32) if "rssi" in want else None
+        ns = C.c_uint(0)
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        self._check(self._L.pmr_chain_collect_block(self.h, ptr(pcm), ptr(audio), S, C.byref(ns), ptr(chan), ptr(rssi)))
+        n = ns.value
+        out = {"n_frames": n}
+        for k, v in (("pcm", pcm), ("audio", audio), ("chan", chan)):
+            if v is not None:
+                out[k] = v[:, :n].copy()
+        if rssi is not None:
+            out["rssi"] = rssi
+        return out
+
+    def pinned_array(self, n, dtype=np.complex64):
+        """numpy view of n elements of memory pinned in the library's HIP runtime (pmr_host_alloc); freed with the chain."""
+        nbytes = int(n) * np.dtype(dtype).itemsize
+        p = self._L.pmr_host_alloc(nbytes)
+        if not p:
+            raise PmrError("pmr_host_alloc failed")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        return np.frombuffer((C.c_char * nbytes).from_address(p), dtype=dtype)
 
     # -- device-buffer entry point (bench / zero-copy callers) ----------------------------------
     def process_block_device(self, d_iq, n_in, d_pcm=None, d_audio=None, stride=None, d_chan=None, d_rssi=None):
@@ -470,7 +535,6 @@ class PmrDsd:
         return buf
 
 
-IQ_CF32, IQ_CS16, IQ_CU8 = 0, 1, 2
 WAV_F32, WAV_S16, RAW_S16 = 0, 1, 2
 
 

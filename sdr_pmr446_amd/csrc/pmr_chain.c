@@ -40,12 +40,27 @@ static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcbloc
 
 typedef struct { hipEvent_t a, b; int slot; } prof_pending;
 
+/* one block in flight between host buffers (pmr_chain_submit_block / _collect_block; the synchronous entry points use slot 0) */
+typedef struct {
+    cfl *d_in; char *d_out; cfl *d_chan;         /* device: input staging; [rssi | pcm | audio], compact [M][stride]; tap-off */
+    void *d_raw;                                 /* device: int16 / uint8 input before conversion (submit_block_fmt)           */
+    hipEvent_t in_ready; int used; unsigned par; /* input copy finished; pipeline parity of the block that last used the slot  */
+    char *h_out; cfl *h_chan;                    /* pinned host copies of the outputs                                         */
+    size_t out_bytes, off_pcm, off_audio;
+    hipEvent_t done; unsigned ns, stride, want;
+} pmr_slot;
+
 struct pmr_chain_s {
     pmr_chain_cfg cfg;
     pmr_design d;
     int device;
     hipStream_t stream;              /* back-end stream (channelizer, audio, outputs): what callers synchronise on */
     hipStream_t stream_fe;           /* front-end stream: block b+1's front end overlaps block b's back end        */
+    hipStream_t sfe;                 /* stream the CURRENT call's front end is queued on: stream_fe (pipelined) or stream (single-stream
+                                        calls: the synchronous host entry point and set_overlap(0) -- no cross-stream events at all)   */
+    int last_single;                 /* the previous call was a single-stream one                                   */
+    hipEvent_t ev_switch;            /* orders stream_fe behind stream when a pipelined call follows a single-stream one */
+    hipStream_t stream_h2d;          /* input copies of the asynchronous host-buffer pair: H2D of block b+1 under the kernels of block b */
     hipEvent_t ev_fe[PIPE_DEPTH], ev_be[PIPE_DEPTH];   /* front end / back end of block (n mod PIPE_DEPTH) finished     */
     int overlap;                     /* two-stream pipelining enabled (PMR_OVERLAP=0 disables)                     */
     uint64_t n_calls;
@@ -68,8 +83,9 @@ struct pmr_chain_s {
     float *d_fm, *d_aux1, *d_aux2;   /* row rings, frame t at ring[(t & fm_mask) * M + k]             */
     uint64_t fm_mask;
     void *d_scratch; size_t scratch_bytes;
-    int16_t *d_pcm; float *d_audio; cfl *d_chan; float *d_rssi, *d_rssi_part;
+    float *d_rssi_part;
     size_t rssi_part_cap;
+    pmr_slot slot[PIPE_DEPTH]; unsigned slot_head, n_inflight;
 
     /* open-channel mask (reference :876-877) and per-channel discriminator reset (:866) */
     unsigned *d_chan_list; unsigned n_enabled; int mask_on;
@@ -215,7 +231,7 @@ static void prof_resolve(pmr_chain q)
 #define LAUNCH_ON(st, slot, expr) do { prof_pending pp_; prof_begin(q, (slot), &pp_, (st)); int rc_ = (expr); \
         prof_end(q, &pp_, (st)); if (rc_) return fail(q, PMR_EHIP, k_names[slot], (hipError_t)rc_); } while (0)
 #define LAUNCH(slot, expr) LAUNCH_ON(q->stream, slot, expr)
-#define LAUNCH_FE(slot, expr) LAUNCH_ON(q->stream_fe, slot, expr)
+#define LAUNCH_FE(slot, expr) LAUNCH_ON(q->sfe, slot, expr)
 
 /* keep the last `keep` elements of a [src+keep]-element buffer at its front (history for the next call) */
 static int shift_front(pmr_chain q, hipStream_t st, void *buf, size_t elem, size_t src, size_t keep)
@@ -519,11 +535,6 @@ static int chain_init(pmr_chain q)
     }
     q->scratch_bytes = 4096;         /* history shifts of the staged front end only (<= 40 samples each) */
     if ((rc = dev_alloc(q, &q->d_scratch, q->scratch_bytes))) return rc;
-    const size_t out_n = (size_t)M * q->chan_size;
-    if ((rc = dev_alloc(q, (void **)&q->d_pcm, out_n * sizeof(int16_t)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_audio, out_n * sizeof(float)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_chan, out_n * sizeof(cfl)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_rssi, (size_t)M * sizeof(float)))) return rc;
     q->rssi_part_cap = ((size_t)q->chan_size + 2) * M;   /* worst case: one new frame per channelizer tile */
     if ((rc = dev_alloc(q, (void **)&q->d_rssi_part, q->rssi_part_cap * sizeof(float)))) return rc;
 
@@ -606,6 +617,9 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
         hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_lo) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
     }
+    if (hipEventCreateWithFlags(&q->ev_switch, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&q->stream_h2d, hipStreamNonBlocking) != hipSuccess) { pmr_design_free(&q->d); free(q); return NULL; }
+    q->sfe = q->stream_fe;
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
         if (hipEventCreateWithFlags(&q->ev_fe[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q->ev_be[i], hipEventDisableTiming) != hipSuccess) {
@@ -629,6 +643,8 @@ int pmr_chain_destroy(pmr_chain q)
     if (q->stream) hipStreamSynchronize(q->stream);
     prof_resolve(q);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) { if (q->ev_fe[i]) hipEventDestroy(q->ev_fe[i]); if (q->ev_be[i]) hipEventDestroy(q->ev_be[i]); }
+    if (q->ev_switch) hipEventDestroy(q->ev_switch);
+    if (q->stream_h2d) { hipStreamSynchronize(q->stream_h2d); hipStreamDestroy(q->stream_h2d); }
     if (q->stream_fe) hipStreamDestroy(q->stream_fe);
     for (unsigned i = 0; i < q->npool; i++) hipEventDestroy(q->pool[i]);
     free(q->pool); free(q->pend);
@@ -636,13 +652,23 @@ int pmr_chain_destroy(pmr_chain q)
     for (unsigned e = 0; e <= PMR_MAX_STAGES; e++) if (q->d_z[e]) hipFree(q->d_z[e]);
     void *bufs[] = { q->d_arb_bank, q->d_pfb_taps_t, q->d_fft_tw, q->d_nco_cs, q->d_lam_thread_pow,
                      q->d_lam_tile_idx_pow, q->d_hp_pad, q->d_lp_pad, q->d_de_pad, q->d_in, q->d_dc_state,
-                     q->d_dc_agg, q->d_dc_W, q->d_xr, q->d_fm, q->d_aux1, q->d_aux2, q->d_scratch, q->d_pcm,
-                     q->d_audio, q->d_chan, q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
+                     q->d_dc_agg, q->d_dc_W, q->d_xr, q->d_fm, q->d_aux1, q->d_aux2, q->d_scratch,
+                     q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
                      q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
+    for (unsigned i = 0; i < PIPE_DEPTH; i++) {
+        pmr_slot *sl = &q->slot[i];
+        void *dv[] = { i ? (void *)sl->d_in : NULL, sl->d_out, sl->d_chan };
+        void *hv[] = { sl->h_out, sl->h_chan };
+        for (size_t j = 0; j < sizeof(dv) / sizeof(dv[0]); j++) if (dv[j]) hipFree(dv[j]);
+        for (size_t j = 0; j < sizeof(hv) / sizeof(hv[0]); j++) if (hv[j]) hipHostFree(hv[j]);
+        if (sl->d_raw) hipFree(sl->d_raw);
+        if (sl->done) hipEventDestroy(sl->done);
+        if (sl->in_ready) hipEventDestroy(sl->in_ready);
+    }
     if (q->stream) hipStreamDestroy(q->stream);
     pmr_design_free(&q->d);
     free(q->h_reset_flags);
@@ -683,6 +709,9 @@ int pmr_chain_reset(pmr_chain q)
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
     q->pend_l2 = 0;
     q->reset_pending = 0; memset(q->h_reset_flags, 0, M);
+    HIPCHK(hipStreamSynchronize(q->stream_h2d), "reset");
+    q->slot_head = 0; q->n_inflight = 0;                   /* blocks submitted but not collected are dropped */
+    for (unsigned i = 0; i < PIPE_DEPTH; i++) q->slot[i].used = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
     return PMR_OK;
 }
@@ -738,10 +767,10 @@ static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigne
     const unsigned l_last = n_in - (ntiles - 1) * PMR_DC_TILE;
     const float lam_last = (float)pow(d->dc_lambda, (double)l_last);
     const float inv_last = (float)pow(d->dc_lambda, -(double)(PMR_DC_TILE - l_last));
-    LAUNCH_FE(K_DC_AGG, pmr_launch_dc_agg(q->stream_fe, d_iq, n_in, q->d_dc_agg, &q->dcc, q->d_lam_thread_pow));
-    LAUNCH_FE(K_DC_SCAN, pmr_launch_dc_scan(q->stream_fe, q->d_dc_agg, ntiles, q->d_dc_W, q->d_dc_state, &q->dcc,
+    LAUNCH_FE(K_DC_AGG, pmr_launch_dc_agg(q->sfe, d_iq, n_in, q->d_dc_agg, &q->dcc, q->d_lam_thread_pow));
+    LAUNCH_FE(K_DC_SCAN, pmr_launch_dc_scan(q->sfe, q->d_dc_agg, ntiles, q->d_dc_W, q->d_dc_state, &q->dcc,
                                          q->d_lam_tile_idx_pow, lam_last, inv_last));
-    LAUNCH_FE(K_DC_APPLY, pmr_launch_dc_apply(q->stream_fe, d_iq, n_in, q->d_dc_W, q->d_z[0] + q->keep[0], &q->dcc,
+    LAUNCH_FE(K_DC_APPLY, pmr_launch_dc_apply(q->sfe, d_iq, n_in, q->d_dc_W, q->d_z[0] + q->keep[0], &q->dcc,
                                            q->d_lam_thread_pow));
 
     uint64_t c_e = q->n_raw;         /* absolute count of z_e samples before this call */
@@ -750,10 +779,10 @@ static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigne
         const unsigned g = h - 1 - e;
         const unsigned n_out = (unsigned)(((c_e + n_e) >> 1) - (c_e >> 1));
         const int par = (int)(c_e & 1u);
-        LAUNCH_FE(K_HALFBAND, pmr_launch_halfband(q->stream_fe, q->d_z[e], q->d_z[e + 1] + q->keep[e + 1], n_out,
+        LAUNCH_FE(K_HALFBAND, pmr_launch_halfband(q->sfe, q->d_z[e], q->d_z[e + 1] + q->keep[e + 1], n_out,
                                                (int)q->keep[e], par, (int)d->m_stage[g], q->d_hb_h1[g],
                                                e == h - 1 ? d->zeta : 1.0f));
-        int rc = shift_front(q, q->stream_fe, q->d_z[e], sizeof(cfl), n_e, q->keep[e]);
+        int rc = shift_front(q, q->sfe, q->d_z[e], sizeof(cfl), n_e, q->keep[e]);
         if (rc) return rc;
         c_e >>= 1; n_e = n_out;
     }
@@ -762,10 +791,10 @@ static int frontend_staged(pmr_chain q, const void *d_iq, unsigned n_in, unsigne
     unsigned ny = 0;
     if (n_e && (uint64_t)q->arb_phase < span)
         ny = (unsigned)((span - q->arb_phase + d->arb_step - 1) / d->arb_step);
-    LAUNCH_FE(K_ARB, pmr_launch_arb(q->stream_fe, q->d_z[h], q->d_xr, q->xr_abs, q->xr_mask, ny, q->arb_phase,
+    LAUNCH_FE(K_ARB, pmr_launch_arb(q->sfe, q->d_z[h], q->d_xr, q->xr_abs, q->xr_mask, ny, q->arb_phase,
                                     d->arb_step, q->d_arb_bank, (int)q->keep[h]));
     q->arb_phase = (uint32_t)((uint64_t)q->arb_phase + (uint64_t)ny * d->arb_step - span);
-    int rc = shift_front(q, q->stream_fe, q->d_z[h], sizeof(cfl), n_e, q->keep[h]);
+    int rc = shift_front(q, q->sfe, q->d_z[h], sizeof(cfl), n_e, q->keep[h]);
     if (rc) return rc;
     *ny_out = ny;
     return PMR_OK;
@@ -841,14 +870,14 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     p.dc_a1 = d->dc_a1; p.zeta = d->zeta; p.lam_wave = q->fe_lam_wave;
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     fe_fill_taps(q, &p, 0, h);
-    LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic));
+    LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic));
 
     pmr_fe_fix_params f;
     memset(&f, 0, sizeof(f));
     f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[slot]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
     f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
     f.Kgain = q->fe_Kgain;
-    LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream_fe, &t, &f, Q));
+    LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q));
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
     *ny_out = ny;
@@ -896,7 +925,7 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     p.dc_a1 = d->dc_a1; p.zeta = 1.0f; p.lam_wave = q->fe_lam_wave;
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     fe_fill_taps(q, &p, 0, s1);
-    LAUNCH_FE(K_FE, pmr_launch_frontend(q->stream_fe, &p, ntiles1, 256, 16, q->sw.fe_generic));
+    LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles1, 256, 16, q->sw.fe_generic));
 
     /* ---- carries of level 1 + in-place fix of the ring tail: the last `keep` new samples are what the NEXT call's level 2
      * re-reads as history; level 2 of THIS call skips them (fix_limit) and corrects everything before them at load ---- */
@@ -931,8 +960,8 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
          * next block's level 1 instead of between two level-1 launches on the same stream. */
         q->pend_t2 = t; q->pend_f2 = f; q->pend_p2 = p2; q->pend_ntiles2 = ntiles2; q->pend_l2 = 1;
     } else {
-        LAUNCH_FE(K_FE_TILES, pmr_launch_fe_carry(q->stream_fe, &t, &f));
-        if (ntiles2) LAUNCH_FE(K_FE_L2, pmr_launch_frontend_l2(q->stream_fe, &p2, ntiles2, q->fe2_fast));
+        LAUNCH_FE(K_FE_TILES, pmr_launch_fe_carry(q->sfe, &t, &f));
+        if (ntiles2) LAUNCH_FE(K_FE_L2, pmr_launch_frontend_l2(q->sfe, &p2, ntiles2, q->fe2_fast));
     }
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
@@ -952,6 +981,7 @@ int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsig
     *xr_abs0 = q->xr_abs;
     const int keep_l2 = q->l2_on_backend;
     q->l2_on_backend = 0;                         /* this entry point has no back-end stream: everything on stream_fe */
+    q->sfe = q->stream_fe;
     int rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                        : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny);
     q->l2_on_backend = keep_l2;
@@ -964,6 +994,13 @@ int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsig
     q->n_calls++;
     *ny_out = ny;
     return PMR_OK;
+}
+
+unsigned pmr_chain_plan_resampled(pmr_chain q, unsigned n_in)
+{
+    unsigned ny = 0, ns = 0;
+    plan_counts(q, n_in, &ny, &ns);
+    return ny;
 }
 
 void pmr_chain_frontend_view(pmr_chain q, pmr_fe_view *v)
@@ -1074,8 +1111,10 @@ static int ring_to_linear(pmr_chain q, void *dst, const void *ring, uint64_t mas
     return PMR_OK;
 }
 
-int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
-                                   unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db)
+/* `single`: queue the whole block on ONE stream (no cross-stream events): what a caller that synchronises after every
+ * block wants -- the two-stream pipeline only pays when consecutive blocks are in flight together. */
+static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
+                                     unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db, int single)
 {
     if (!q) return PMR_EINVAL;
     if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
@@ -1097,21 +1136,27 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
      * busy on q->stream; it must not start before the back end of the block before that has released its part
      * of the rings (they hold history + PIPE_DEPTH blocks). ---- */
     const unsigned par = (unsigned)(q->n_calls % PIPE_DEPTH);
-    if (q->n_calls >= PIPE_DEPTH) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
-    if (!q->overlap && q->n_calls >= 1)
-        HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[(q->n_calls - 1) % PIPE_DEPTH], 0), "wait back end");
+    q->sfe = single ? q->stream : q->stream_fe;
+    if (!single) {
+        if (q->last_single && q->n_calls) {      /* everything the single-stream calls queued on q->stream comes first */
+            HIPCHK(hipEventRecord(q->ev_switch, q->stream), "record");
+            HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_switch, 0), "wait single-stream calls");
+        }
+        if (q->n_calls >= PIPE_DEPTH) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
+    }
+    q->last_single = single;
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
     if ((rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                         : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny))) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
-    HIPCHK(hipEventRecord(q->ev_fe[par], q->stream_fe), "record");
+    if (!single) HIPCHK(hipEventRecord(q->ev_fe[par], q->stream_fe), "record");
     q->n_raw += n_in;
     q->xr_abs += ny;
     q->last_ny = ny;
 
     /* ---- back end on q->stream ---- */
-    HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
+    if (!single) HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
     if (q->pend_l2) {
         q->pend_l2 = 0;
         LAUNCH(K_FE_TILES, pmr_launch_fe_carry(q->stream, &q->pend_t2, &q->pend_f2));
@@ -1181,8 +1226,122 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
         }
     }
     q->frames_done += ns;
-    HIPCHK(hipEventRecord(q->ev_be[par], q->stream), "record");
+    if (!single) HIPCHK(hipEventRecord(q->ev_be[par], q->stream), "record");
     q->n_calls++;
+    return PMR_OK;
+}
+
+int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
+                                   unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db)
+{
+    return process_block_device_impl(q, d_iq, n_in, d_pcm, d_audio, pcm_stride, n_frames, d_chan_out, d_rssi_db,
+                                     q ? !q->overlap : 0);
+}
+
+/* ---- host-buffer entry points ---------------------------------------------------------------------------------
+ * A SLOT is one block in flight between host buffers: its own device input staging, device outputs and pinned host outputs.
+ * The synchronous pmr_chain_process_block* use slot 0 on one stream (no cross-stream events: nothing overlaps anyway);
+ * pmr_chain_submit_block / pmr_chain_collect_block cycle through PIPE_DEPTH slots so that the H2D copy, the kernels and the
+ * D2H copy of consecutive blocks overlap (the call pattern of the reference's loop, one readStream block per iteration,
+ * src/sdr_pmr446.c:789-796, with the sink one block behind).  Device outputs of a slot are COMPACT -- [M][stride] with
+ * stride = frames of this block rounded up to 8 -- so the D2H copy is one contiguous transfer whatever M is (a 2-D copy of
+ * 1024 rows of 100 bytes runs at a few hundred MB/s); the rows are then spread into the caller's [M][pcm_stride] layout by
+ * the CPU. */
+/* Outputs of a slot live in ONE device block and ONE pinned host block, laid out per call as [rssi | pcm | audio] (each part
+ * 256-byte aligned, compact stride), so whatever subset was asked for comes back in a single D2H copy. */
+#define SLOT_ALIGN(x) (((x) + 255u) & ~(size_t)255u)
+static int slot_prepare(pmr_chain q, unsigned i, int want_chan)
+{
+    pmr_slot *sl = &q->slot[i];
+    const size_t out_n = (size_t)q->M * ((q->chan_size + 7u) & ~7u);
+    int rc;
+    if (!sl->d_in) {
+        if (i == 0) sl->d_in = q->d_in;
+        else if ((rc = dev_alloc(q, (void **)&sl->d_in, (size_t)q->cfg.max_block * sizeof(cfl)))) return rc;
+        sl->out_bytes = SLOT_ALIGN((size_t)q->M * sizeof(float)) + SLOT_ALIGN(out_n * sizeof(int16_t)) + SLOT_ALIGN(out_n * sizeof(float));
+        if ((rc = dev_alloc(q, (void **)&sl->d_out, sl->out_bytes))) return rc;
+        if (hipHostMalloc((void **)&sl->h_out, sl->out_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sl->in_ready, hipEventDisableTiming) != hipSuccess)
+            return fail(q, PMR_ENOMEM, "pinned slot buffers", hipSuccess);
+        HIPCHK(hipStreamSynchronize(q->stream), "slot init");
+    }
+    if (want_chan && !sl->d_chan) {
+        if ((rc = dev_alloc(q, (void **)&sl->d_chan, out_n * sizeof(cfl)))) return rc;
+        if (hipHostMalloc((void **)&sl->h_chan, out_n * sizeof(cfl), hipHostMallocDefault) != hipSuccess)
+            return fail(q, PMR_ENOMEM, "pinned slot buffers", hipSuccess);
+        HIPCHK(hipStreamSynchronize(q->stream), "slot init");
+    }
+    return PMR_OK;
+}
+
+/* queue one block: H2D -> chain -> D2H into the slot's pinned buffers; nothing is waited for */
+static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigned n_in, unsigned want, int single)
+{
+    pmr_slot *sl = &q->slot[i];
+    int rc = slot_prepare(q, i, (want & PMR_WANT_CHAN) != 0);
+    if (rc) return rc;
+    if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
+    if (n_in && !iq) return fail(q, PMR_EINVAL, "null input", hipSuccess);
+    if (fmt < 0 || fmt > 2) return fail(q, PMR_EINVAL, "unknown IQ format", hipSuccess);
+    if (fmt && !sl->d_raw && (rc = dev_alloc(q, &sl->d_raw, (size_t)q->cfg.max_block * 4))) return rc;
+    unsigned ny_plan = 0, ns_plan = 0;
+    plan_counts(q, n_in, &ny_plan, &ns_plan);
+    const unsigned stride = ns_plan ? (ns_plan + 7u) & ~7u : 8u;
+    const size_t n = (size_t)q->M * stride;
+    sl->off_pcm = SLOT_ALIGN((size_t)q->M * sizeof(float));
+    sl->off_audio = sl->off_pcm + SLOT_ALIGN(n * sizeof(int16_t));
+    /* input: H2D (+ int16 / uint8 -> cf32 on the device).  Pipelined calls copy on their own stream, so the copy of block b+1
+     * runs under the kernels of block b; it may not overwrite the slot's staging before the front end that last read it is done */
+    hipStream_t s_in = single ? q->stream : q->stream_h2d;
+    if (n_in) {
+        if (!single && sl->used) HIPCHK(hipStreamWaitEvent(s_in, q->ev_fe[sl->par], 0), "wait front end");
+        const size_t bytes = (size_t)n_in * (fmt == 0 ? 8 : fmt == 1 ? 4 : 2);
+        HIPCHK(hipMemcpyAsync(fmt ? sl->d_raw : (void *)sl->d_in, iq, bytes, hipMemcpyHostToDevice, s_in), "H2D");
+        if (fmt && (rc = pmr_launch_iq_convert(s_in, sl->d_raw, sl->d_in, n_in, fmt))) return fail(q, PMR_EHIP, "k_iq_convert", (hipError_t)rc);
+        if (!single) {
+            HIPCHK(hipEventRecord(sl->in_ready, s_in), "record");
+            HIPCHK(hipStreamWaitEvent(q->stream_fe, sl->in_ready, 0), "wait input");
+        }
+    }
+    sl->used = !single; sl->par = (unsigned)(q->n_calls % PIPE_DEPTH);
+    unsigned ns = 0;
+    rc = process_block_device_impl(q, sl->d_in, n_in, (want & PMR_WANT_PCM) ? sl->d_out + sl->off_pcm : NULL,
+                                   (want & PMR_WANT_AUDIO) ? sl->d_out + sl->off_audio : NULL, stride, &ns,
+                                   (want & PMR_WANT_CHAN) ? sl->d_chan : NULL, (want & PMR_WANT_RSSI) ? sl->d_out : NULL, single);
+    if (rc) return rc;
+    sl->ns = ns; sl->stride = stride; sl->want = want;
+    if (ns) {
+        const size_t lo = (want & PMR_WANT_RSSI) ? 0 : (want & PMR_WANT_PCM) ? sl->off_pcm : sl->off_audio;
+        const size_t hi = (want & PMR_WANT_AUDIO) ? sl->off_audio + n * sizeof(float)
+                        : (want & PMR_WANT_PCM) ? sl->off_pcm + n * sizeof(int16_t) : (size_t)q->M * sizeof(float);
+        if (hi > lo && (want & (PMR_WANT_RSSI | PMR_WANT_PCM | PMR_WANT_AUDIO)))
+            HIPCHK(hipMemcpyAsync(sl->h_out + lo, sl->d_out + lo, hi - lo, hipMemcpyDeviceToHost, q->stream), "D2H");
+        if (want & PMR_WANT_CHAN) HIPCHK(hipMemcpyAsync(sl->h_chan, sl->d_chan, n * sizeof(cfl), hipMemcpyDeviceToHost, q->stream), "D2H chan");
+    }
+    HIPCHK(hipEventRecord(sl->done, q->stream), "record");
+    return PMR_OK;
+}
+
+/* wait for the slot's block and spread its compact rows into the caller's [M][pcm_stride] arrays */
+static int slot_collect(pmr_chain q, unsigned i, int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames,
+                        pmr_cf32 *chan_out, float *rssi_db)
+{
+    pmr_slot *sl = &q->slot[i];
+    HIPCHK(hipEventSynchronize(sl->done), "wait block");
+    const unsigned ns = sl->ns, M = q->M;
+    if (n_frames) *n_frames = ns;
+    if (ns > pcm_stride && (pcm || audio || chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
+    if (ns) {
+        const int16_t *hp = (const int16_t *)(sl->h_out + sl->off_pcm);
+        const float *ha = (const float *)(sl->h_out + sl->off_audio);
+        for (unsigned k = 0; k < M; k++) {
+            if (pcm && (sl->want & PMR_WANT_PCM)) memcpy(pcm + (size_t)k * pcm_stride, hp + (size_t)k * sl->stride, (size_t)ns * sizeof(int16_t));
+            if (audio && (sl->want & PMR_WANT_AUDIO)) memcpy(audio + (size_t)k * pcm_stride, ha + (size_t)k * sl->stride, (size_t)ns * sizeof(float));
+            if (chan_out && (sl->want & PMR_WANT_CHAN)) memcpy((cfl *)chan_out + (size_t)k * pcm_stride, sl->h_chan + (size_t)k * sl->stride, (size_t)ns * sizeof(cfl));
+        }
+        if (rssi_db && (sl->want & PMR_WANT_RSSI)) memcpy(rssi_db, sl->h_out, (size_t)M * sizeof(float));
+    }
     return PMR_OK;
 }
 
@@ -1190,36 +1349,64 @@ int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, 
                                 unsigned pcm_stride, unsigned *n_frames, pmr_cf32 *chan_out, float *rssi_db)
 {
     if (!q) return PMR_EINVAL;
-    if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
-    if (n_in) {
-        /* d_in is re-used every call: the previous block's front end (same stream) has consumed it by then */
-        HIPCHK(hipMemcpyAsync(q->d_in, iq, (size_t)n_in * sizeof(cfl), hipMemcpyHostToDevice, q->stream_fe), "H2D");
-    }
-    unsigned ns = 0;
-    const unsigned S = q->chan_size;
-    int rc = pmr_chain_process_block_device(q, q->d_in, n_in, (pcm || audio) ? q->d_pcm : NULL,
-                                            audio ? q->d_audio : NULL, S, &ns, chan_out ? q->d_chan : NULL,
-                                            rssi_db ? q->d_rssi : NULL);
+    if (q->n_inflight) return fail(q, PMR_EINVAL, "collect the submitted blocks first", hipSuccess);
+    /* capacity is checked against the closed-form plan BEFORE any state is advanced */
+    unsigned ny_plan = 0, ns_plan = 0;
+    plan_counts(q, n_in, &ny_plan, &ns_plan);
+    if (n_frames) *n_frames = ns_plan;
+    if (ns_plan > pcm_stride && (pcm || audio || chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
+    const unsigned want = ((pcm || audio) ? PMR_WANT_PCM : 0) | (audio ? PMR_WANT_AUDIO : 0) | (chan_out ? PMR_WANT_CHAN : 0) |
+                          (rssi_db ? PMR_WANT_RSSI : 0);
+    int rc = slot_submit(q, 0, iq, 0, n_in, want, 1);
     if (rc) return rc;
-    if (n_frames) *n_frames = ns;
-    if (ns > pcm_stride && (pcm || audio || chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
-    if (ns) {
-        if (pcm)
-            HIPCHK(hipMemcpy2DAsync(pcm, (size_t)pcm_stride * sizeof(int16_t), q->d_pcm, (size_t)S * sizeof(int16_t),
-                                    (size_t)ns * sizeof(int16_t), q->M, hipMemcpyDeviceToHost, q->stream), "D2H pcm");
-        if (audio)
-            HIPCHK(hipMemcpy2DAsync(audio, (size_t)pcm_stride * sizeof(float), q->d_audio, (size_t)S * sizeof(float),
-                                    (size_t)ns * sizeof(float), q->M, hipMemcpyDeviceToHost, q->stream), "D2H audio");
-        if (chan_out)
-            HIPCHK(hipMemcpy2DAsync(chan_out, (size_t)pcm_stride * sizeof(cfl), q->d_chan, (size_t)S * sizeof(cfl),
-                                    (size_t)ns * sizeof(cfl), q->M, hipMemcpyDeviceToHost, q->stream), "D2H chan");
-        if (rssi_db)
-            HIPCHK(hipMemcpyAsync(rssi_db, q->d_rssi, (size_t)q->M * sizeof(float), hipMemcpyDeviceToHost, q->stream),
-                   "D2H rssi");
-    }
-    return pmr_chain_synchronize(q);
+    rc = slot_collect(q, 0, pcm, audio, pcm_stride, n_frames, chan_out, rssi_db);      /* waits for the block's last copy */
+    if (rc) return rc;
+    if (q->prof_on) prof_resolve(q);
+    return PMR_OK;
 }
+
+/* asynchronous pair: up to PIPE_DEPTH blocks between submit and collect */
+int pmr_chain_submit_block_fmt(pmr_chain q, const void *iq, int iq_format, unsigned n_in, unsigned want)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    if (q->n_inflight >= PIPE_DEPTH) return fail(q, PMR_ERANGE, "PIPE_DEPTH blocks already in flight: collect one first", hipSuccess);
+    const unsigned i = (q->slot_head + q->n_inflight) % PIPE_DEPTH;
+    int rc = slot_submit(q, i, iq, iq_format, n_in, want ? want : PMR_WANT_PCM, !q->overlap);
+    if (rc) return rc;
+    q->n_inflight++;
+    return PMR_OK;
+}
+
+int pmr_chain_submit_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, unsigned want)
+{
+    return pmr_chain_submit_block_fmt(q, iq, 0, n_in, want);
+}
+
+int pmr_chain_collect_block(pmr_chain q, int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames,
+                            pmr_cf32 *chan_out, float *rssi_db)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    if (!q->n_inflight) return fail(q, PMR_EINVAL, "no block in flight", hipSuccess);
+    int rc = slot_collect(q, q->slot_head, pcm, audio, pcm_stride, n_frames, chan_out, rssi_db);
+    if (rc == PMR_ERANGE) return rc;                       /* caller may retry with a larger stride: the block stays queued */
+    q->slot_head = (q->slot_head + 1) % PIPE_DEPTH;
+    q->n_inflight--;
+    return rc;
+}
+
+unsigned pmr_chain_blocks_in_flight(pmr_chain q) { return q ? q->n_inflight : 0; }
+unsigned pmr_chain_max_in_flight(pmr_chain q) { (void)q; return PIPE_DEPTH; }
+
+/* pinned host memory from THIS library's HIP runtime: what the asynchronous copies of submit / collect need */
+void *pmr_host_alloc(size_t bytes)
+{
+    void *p = NULL;
+    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : NULL;
+}
+void pmr_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int pmr_chain_process_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, int16_t *pcm, unsigned pcm_stride,
                             unsigned *n_frames, pmr_cf32 *chan_out, float *rssi_db)

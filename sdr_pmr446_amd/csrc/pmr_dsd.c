@@ -181,17 +181,19 @@ int pmr_dsd_process_block_device(pmr_dsd q, const void *d_iq, unsigned n_in, voi
     if (!q) return PMR_EINVAL;
     if (n_in > q->cfg.max_block) return dfail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
     DCHK(hipSetDevice(q->v.device), "hipSetDevice");
-    unsigned ny = 0; uint64_t a0 = 0;
-    int rc = pmr_chain_frontend_block(q->fe, d_iq, n_in, &ny, &a0);           /* :167-168 */
-    if (rc) return dfail(q, rc, pmr_chain_last_error(q->fe), hipSuccess);
-    if (a0 != q->n_res) return dfail(q, PMR_EINVAL, "internal: resampled count mismatch", hipSuccess);
+    /* every capacity check runs on the closed-form plan BEFORE any state is advanced: a refused block is not consumed */
     const unsigned S = q->up.num_stages;
-    const uint64_t j0 = q->n_u, j1 = up_count(q->n_res + ny, q->up.arb_step);
+    const unsigned ny_plan = pmr_chain_plan_resampled(q->fe, n_in);
+    const uint64_t j0 = q->n_u, j1 = up_count(q->n_res + ny_plan, q->up.arb_step);
     const unsigned nu = (unsigned)(j1 - j0), nz = nu << S;
-    q->n_res += ny; q->n_u = j1; q->last_ny = ny;
     if (n_out) *n_out = nz;
     if (nz > q->out_size) return dfail(q, PMR_ERANGE, "output overflow", hipSuccess);
     if (nz > cap && (d_pcm || d_audio)) return dfail(q, PMR_ERANGE, "cap < samples produced", hipSuccess);
+    unsigned ny = 0; uint64_t a0 = 0;
+    int rc = pmr_chain_frontend_block(q->fe, d_iq, n_in, &ny, &a0);           /* :167-168 */
+    if (rc) return dfail(q, rc, pmr_chain_last_error(q->fe), hipSuccess);
+    if (a0 != q->n_res || ny != ny_plan) return dfail(q, PMR_EINVAL, "internal: resampled count mismatch", hipSuccess);
+    q->n_res += ny; q->n_u = j1; q->last_ny = ny;
     pmr_stream_t st = (pmr_stream_t)q->v.stream_fe;
     if ((rc = pmr_launch_dsd_fm(st, q->v.d_xr, q->v.xr_mask, a0, ny, q->d_fm, q->fm_mask, q->fm_ref)))        /* :169 */
         return dfail(q, PMR_EHIP, "k_dsd_fm", (hipError_t)rc);
@@ -220,11 +222,16 @@ int pmr_dsd_process_block(pmr_dsd q, const pmr_cf32 *iq, unsigned n_in, int16_t 
     hipStream_t st = (hipStream_t)q->v.stream_fe;
     if (n_in) DCHK(hipMemcpyAsync(q->v.d_in, iq, (size_t)n_in * 8, hipMemcpyHostToDevice, st), "H2D");
     unsigned nz = 0;
+    {   /* the caller's capacity is checked before the block is consumed */
+        const uint64_t j1 = up_count(q->n_res + pmr_chain_plan_resampled(q->fe, n_in), q->up.arb_step);
+        nz = (unsigned)(j1 - q->n_u) << q->up.num_stages;
+        if (n_out) *n_out = nz;
+        if (nz > cap && (pcm || audio)) return dfail(q, PMR_ERANGE, "cap < samples produced", hipSuccess);
+    }
     int rc = pmr_dsd_process_block_device(q, q->v.d_in, n_in, pcm ? q->d_pcm : NULL, audio ? q->d_audio : NULL,
                                           q->out_size, &nz);
     if (rc) return rc;
     if (n_out) *n_out = nz;
-    if (nz > cap && (pcm || audio)) return dfail(q, PMR_ERANGE, "cap < samples produced", hipSuccess);
     if (nz && pcm) DCHK(hipMemcpyAsync(pcm, q->d_pcm, (size_t)nz * sizeof(int16_t), hipMemcpyDeviceToHost, st), "D2H pcm");
     if (nz && audio) DCHK(hipMemcpyAsync(audio, q->d_audio, (size_t)nz * sizeof(float), hipMemcpyDeviceToHost, st), "D2H audio");
     return pmr_dsd_synchronize(q);

@@ -12,6 +12,8 @@ pmr_chain pmr_chain_create_frontend(const pmr_chain_cfg *cfg);
 /* dc-block + resampler of one block on the front-end stream; the resampled samples land in the ring at absolute
  * indices [*xr_abs0, *xr_abs0 + *ny), dc carry fully applied.  Nothing is synchronised. */
 int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny, uint64_t *xr_abs0);
+/* resampled samples a block of n_in raw samples WILL yield (closed form; nothing is advanced) */
+unsigned pmr_chain_plan_resampled(pmr_chain q, unsigned n_in);
 typedef struct { void *d_xr; uint64_t xr_mask; void *stream_fe; void *d_in; unsigned res_size; int device; } pmr_fe_view;
 void pmr_chain_frontend_view(pmr_chain q, pmr_fe_view *v);
 

@@ -66,6 +66,9 @@ int pmr_launch_halfband(pmr_stream_t s, const void *zin, void *zout, unsigned n_
 int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out_ring, uint64_t out_pos0, uint64_t out_mask,
                    unsigned ny, uint32_t phase0, uint32_t step, const float *bank, int keep);
 
+/* int16 (fmt 1, x / 32768) or uint8 (fmt 2, (x - 127.5) / 127.5) interleaved I/Q -> cf32 on the device (include/pmr_io.h rules) */
+int pmr_launch_iq_convert(pmr_stream_t s, const void *raw, void *out_cf32, unsigned n_in, int fmt);
+
 /* Ring buffers.  The resampled stream lives in a power-of-two ring of cf32 addressed by the ABSOLUTE resampled
  * sample index (sample a at xr[a & xr_mask]); the discriminator output in a ring of time-major rows addressed by the
  * absolute frame index (frame t at fm[(t & fm_mask) * M + k]).  Frame f covers samples [f*M, (f+1)*M); the NCO phase

@@ -1,0 +1,102 @@
+"""Host-buffer entry points at the reference's call pattern (one readStream block per loop iteration,
+src/sdr_pmr446.c:789-796): the synchronous call, and the asynchronous submit / collect pair with up to PIPE_DEPTH blocks in
+flight -- same results, bit for bit, and +-1 LSB against the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from parity_util import CFG2, CFG5, CFG_REF, active_channels, pcm_diff
+from sdr_pmr446_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("cfg,nb,nblk,pinned", [(CFG_REF, 100000, 9, True), (CFG2, 100000, 7, False), (CFG5, 1 << 22, 5, True)],
+                         ids=["ref-point-pinned", "cfg2-pageable", "cfg5-pinned"])
+def test_submit_collect_equals_synchronous_calls(cfg, nb, nblk, pinned):
+    from sdr_pmr446_amd import chain
+    fs, M = cfg
+    ks = None if M <= 64 else list(range(0, M, 73))
+    x = synth.synth_iq(nb * nblk, fs, M, channels=ks, dev_hz=1500.0)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=nb)
+    sync = [g.process_block(x[b * nb:(b + 1) * nb], want=("pcm", "audio", "rssi")) for b in range(nblk)]
+    g.reset()
+    depth = g._L.pmr_chain_max_in_flight(g.h)
+    assert depth >= 2
+    bufs = [g.pinned_array(nb) if pinned else np.zeros(nb, np.complex64) for _ in range(depth)]
+    got, sub = [], 0
+    for b in range(nblk + depth):
+        if b >= depth or b >= nblk:                      # the pipe is full (or drained of input): take the oldest block out
+            if len(got) < nblk:
+                got.append(g.collect_block())
+        if b < nblk:
+            buf = bufs[b % depth]
+            buf[:] = x[b * nb:(b + 1) * nb]
+            g.submit_block(buf, want=("pcm", "audio", "rssi"))
+            sub += 1
+    while len(got) < nblk:
+        got.append(g.collect_block())
+    assert g._L.pmr_chain_blocks_in_flight(g.h) == 0
+    for a, b in zip(sync, got):
+        assert a["n_frames"] == b["n_frames"]
+        assert np.array_equal(a["pcm"], b["pcm"]) and np.array_equal(a["audio"], b["audio"])
+        assert np.allclose(a["rssi"], b["rssi"], atol=1e-4, equal_nan=True)
+    with pytest.raises(chain.PmrError):
+        g.collect_block() if False else g._check(g._L.pmr_chain_collect_block(g.h, None, None, 0, None, None, None))
+    # and against the oracle
+    o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=nb)
+    ref = np.concatenate([o.process_block(x[b * nb:(b + 1) * nb])["pcm"] for b in range(nblk)], axis=1)
+    pcm = np.concatenate([r["pcm"] for r in got], axis=1)
+    act = active_channels(M, ks, fs)
+    assert pcm.shape == ref.shape and pcm_diff(pcm[act], ref[act]).max() <= 1
+    g.close(); o.close()
+
+
+def test_too_many_blocks_in_flight_is_refused_not_dropped():
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=50000)
+    x = synth.synth_iq(50000, fs, M)
+    depth = g._L.pmr_chain_max_in_flight(g.h)
+    for _ in range(depth):
+        g.submit_block(x)
+    with pytest.raises(chain.PmrError):
+        g.submit_block(x)
+    g._pending.pop()                                   # the refused block was never queued
+    frames = [g.collect_block()["n_frames"] for _ in range(depth)]
+    assert sum(frames) > 0 and g._L.pmr_chain_blocks_in_flight(g.h) == 0
+    # the synchronous call works again afterwards, mixed with device-entry calls on the two-stream pipeline
+    assert g.process_block(x)["n_frames"] > 0
+
+
+@pytest.mark.parametrize("fmt", ["cs16", "cu8"])
+def test_integer_ingest_formats_are_converted_on_the_device(fmt):
+    """pmr_chain_submit_block_fmt: int16 / uint8 I/Q (include/pmr_io.h formats) cross PCIe as they are and are converted on the
+    device with the rules of the host-side reader (pmr_io.c) -- PCM bit-identical to feeding the host-converted cf32."""
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    nb, nblk = 100001, 4                                  # odd block size: the converter's tail path runs too
+    x = synth.synth_iq(nb * nblk, fs, M, dev_hz=1500.0)
+    xi = np.empty(2 * len(x), np.float32); xi[0::2] = x.real; xi[1::2] = x.imag
+    if fmt == "cs16":
+        raw = np.clip(np.round(xi * 32768.0 * 1.5), -32768, 32767).astype(np.int16)
+        host = (raw.astype(np.float32) * np.float32(1.0 / 32768.0))
+        code = chain.IQ_CS16
+    else:
+        raw = np.clip(np.round(xi * 127.5 * 1.5 + 127.5), 0, 255).astype(np.uint8)
+        host = (raw.astype(np.float32) - np.float32(127.5)) * np.float32(1.0 / 127.5)
+        code = chain.IQ_CU8
+    xc = (host[0::2] + 1j * host[1::2]).astype(np.complex64)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=nb)
+    ref = [g.process_block(xc[b * nb:(b + 1) * nb])["pcm"] for b in range(nblk)]
+    g.reset()
+    got = []
+    for b in range(nblk):
+        g.submit_block(raw[2 * b * nb:2 * (b + 1) * nb], fmt=code)
+        if b >= 2:
+            got.append(g.collect_block()["pcm"])
+    while len(got) < nblk:
+        got.append(g.collect_block()["pcm"])
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b) and a.shape[1] > 100
+    g.close()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Latency of one synchronous pmr_chain_process_block call at the REFERENCE's operating point (1.024 MS/s, 16 channels,
-100000-sample blocks = 97.7 ms of signal, host buffers in and out), and of pmr_dsd_process_block (200000 samples)."""
+"""Host-buffer entry points at the REFERENCE's operating point (1.024 MS/s, 16 channels, 100000-sample blocks = 97.7 ms of
+signal): latency of one synchronous pmr_chain_process_block_f32 call, steady-state time per block of the asynchronous
+submit / collect pair, and pmr_dsd_process_block (200000 samples)."""
 import os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,16 +10,36 @@ x = synth.synth_iq(100000, 1.024e6, 16)
 g = chain.PmrChain()
 S = g.max_frames
 pcm = np.zeros((16, S), np.int16); audio = np.zeros((16, S), np.float32); rssi = np.zeros(16, np.float32); ns = C.c_uint(0)
-def call():
-    rc = g._L.pmr_chain_process_block_f32(g.h, x.ctypes.data, len(x), pcm.ctypes.data, audio.ctypes.data, S, C.byref(ns), None, rssi.ctypes.data)
-    assert rc == 0
-for _ in range(20): call()
-t = []
-for _ in range(200):
-    t0 = time.perf_counter(); call(); t.append(time.perf_counter() - t0)
-t = np.array(t) * 1e6
-print("pmr_chain_process_block_f32, 100000 samples (97.7 ms of signal): median %.0f us, p99 %.0f us -> %.0fx real time" %
-      (np.median(t), np.percentile(t, 99), 97656.0 / np.median(t)))
+for kind in ("pageable", "pinned"):
+    xi = x
+    if kind == "pinned":
+        xi = g.pinned_array(len(x)); xi[:] = x
+    def call():
+        rc = g._L.pmr_chain_process_block_f32(g.h, xi.ctypes.data, len(xi), pcm.ctypes.data, audio.ctypes.data, S, C.byref(ns), None, rssi.ctypes.data)
+        assert rc == 0
+    for _ in range(20): call()
+    t = []
+    for _ in range(300):
+        t0 = time.perf_counter(); call(); t.append(time.perf_counter() - t0)
+    t = np.array(t) * 1e6
+    print("pmr_chain_process_block_f32 (%s input), 100000 samples (97.7 ms of signal): median %.0f us, p99 %.0f us -> %.0fx real time" %
+          (kind, np.median(t), np.percentile(t, 99), 97656.0 / np.median(t)))
+# asynchronous pair, pipe kept full
+depth = g._L.pmr_chain_max_in_flight(g.h)
+bufs = [g.pinned_array(len(x)) for _ in range(depth)]
+for b in bufs: b[:] = x
+def sub(i): assert g._L.pmr_chain_submit_block(g.h, bufs[i % depth].ctypes.data, len(x), 1 | 2 | 4) == 0
+def col(): assert g._L.pmr_chain_collect_block(g.h, pcm.ctypes.data, audio.ctypes.data, S, C.byref(ns), None, rssi.ctypes.data) == 0
+g.reset()
+for i in range(depth): sub(i)
+N = 600
+t0 = time.perf_counter()
+for i in range(N):
+    col(); sub(i)
+dt = time.perf_counter() - t0
+for i in range(depth): col()
+print("pmr_chain_submit_block / collect_block, %d blocks in flight: %.0f us per 100000-sample block (%.1f MS/s, %.0fx real time)" %
+      (depth, dt / N * 1e6, N * 1e5 / dt / 1e6, 97656.0 / (dt / N * 1e6)))
 d = chain.PmrDsd()
 xd = synth.synth_iq(200000, 1.024e6, 1)
 out = np.zeros(d.max_out, np.int16); nz = C.c_uint(0)
