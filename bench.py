@@ -145,10 +145,9 @@ def parity_check(ch, fs, M, iq, block, pcm_bufs, S, nblk):
     """Outside the timed region: `nblk` consecutive process_block_device calls on the bench block, NOT synchronised in
     between (the timed code path), PCM of every call vs the CPU oracle fed the same stream.  Returns the record."""
     import numpy as np
-    import torch
     import oracle
     from sdr_pmr446_amd import synth
-    x_host = iq.cpu().numpy()
+    x_host = iq.download(np.complex64, block)
     ref, err = [], []
 
     def run_oracle():
@@ -168,9 +167,10 @@ def parity_check(ch, fs, M, iq, block, pcm_bufs, S, nblk):
     ch.reset()
     ns = []
     for b in range(nblk):
-        ns.append(ch.process_block_device(iq.data_ptr(), block, d_pcm=pcm_bufs[b].data_ptr(), stride=S))
+        ns.append(ch.process_block_device(iq.ptr, block, d_pcm=pcm_bufs[b].ptr, stride=S))
     ch.synchronize()
-    got = torch.cat([pcm_bufs[b][:, :ns[b]] for b in range(nblk)], dim=1).cpu().numpy().astype(np.int32)
+    got = np.concatenate([pcm_bufs[b].download(np.int16, M * S).reshape(M, S)[:, :ns[b]] for b in range(nblk)],
+                         axis=1).astype(np.int32)
     th.join()
     if err:
         return {"ok": False, "error": err[0]}
@@ -195,22 +195,27 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
     import torch
     from sdr_pmr446_amd import chain as pmr
     from sdr_pmr446_amd import multigpu
-    from sdr_pmr446_amd.synth_torch import synth_iq_torch
 
     fs, M, lb, cfg_idx = WORKLOADS[name]
     lb = args.log2_block if args.log2_block is not None else lb
     block = 1 << lb
     ch = pmr.PmrChain(fs_in=fs, num_channels=M, max_block=block, device=local_rank)
     S = ch.max_frames
-    # resident in HBM before timing; periodic: the block repeated every step is one phase-continuous stream
-    iq = synth_iq_torch(block, fs, M, dev, stream_id=multigpu.stream_id_for_rank(rank), periodic=True)
+    # Resident in HBM before timing, generated there by the library's own kernel (include/pmr_mem.h: every buffer of this
+    # program lives in the library's HIP runtime; torch is here for torch.distributed only).  period_log2: all frequencies
+    # snapped to the block's grid, so the block repeated every step is one phase-continuous stream.
+    iq = pmr.synth_iq_device(block, fs, M, stream_id=multigpu.stream_id_for_rank(rank), period_log2=lb, device=local_rank)
     nchk = max(1, args.parity_blocks)
-    pcm_bufs = [torch.zeros((M, S), dtype=torch.int16, device=dev) for _ in range(nchk)]   # PCM stays in HBM
+    pcm_bufs = [pmr.DeviceBuffer(M * S * 2, local_rank) for _ in range(nchk)]                # PCM stays in HBM
     pcm = pcm_bufs[0]
-    torch.cuda.synchronize()
+    pmr.device_synchronize()
+
+    def device_sync():
+        torch.cuda.synchronize()
+        pmr.device_synchronize()
 
     def step():
-        return ch.process_block_device(iq.data_ptr(), block, d_pcm=pcm.data_ptr(), stride=S)
+        return ch.process_block_device(iq.ptr, block, d_pcm=pcm.ptr, stride=S)
 
     for _ in range(args.warmup):
         step()
@@ -230,7 +235,7 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
     sync_dev = dev if args.dist_backend == "nccl" else None
     dts, frames = [], 0
     for _ in range(max(1, args.regions if headline or world == 1 else 1)):
-        dt, frames = multigpu.timed_region(run, dist, torch.cuda.synchronize, sync_dev)
+        dt, frames = multigpu.timed_region(run, dist, device_sync, sync_dev)
         dts.append(dt)
     ch.profile_enable(0)
     prof_roof = ch.profile()
@@ -254,7 +259,7 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
     for _ in range(args.warmup):
         step()
     ch.synchronize()
-    dts1 = [multigpu.timed_region(run, dist, torch.cuda.synchronize, sync_dev)[0] for _ in range(5)]
+    dts1 = [multigpu.timed_region(run, dist, device_sync, sync_dev)[0] for _ in range(5)]
     ch.set_channel_mask(None)
 
     rec = None
@@ -305,8 +310,9 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
         if headline and world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(fs, M)
     ch.close()
-    del iq, pcm_bufs
-    torch.cuda.empty_cache()
+    iq.free()
+    for b in pcm_bufs:
+        b.free()
     return rec
 
 
@@ -321,7 +327,7 @@ def host_io(ch, iq, block, M, S):
     L = ch._L
     res = {}
     ns_c = ctypes.c_uint(0)
-    x_host = iq[:nb].cpu().numpy().view(np.complex64).reshape(-1)
+    x_host = iq.download(np.complex64, nb)
     pcm = np.zeros((M, S), dtype=np.int16)
     depth = L.pmr_chain_max_in_flight(ch.h)
     pinned = [ch.pinned_array(nb) for _ in range(depth)]

@@ -28,6 +28,9 @@ ABI_SYMBOLS = [
     "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read", "pmr_chain_set_channel_mask", "pmr_chain_reset_channel",
     "pmr_chain_submit_block", "pmr_chain_submit_block_fmt", "pmr_chain_collect_block", "pmr_chain_blocks_in_flight", "pmr_chain_max_in_flight",
     "pmr_host_alloc", "pmr_host_free",
+    # include/pmr_mem.h
+    "pmr_device_alloc", "pmr_device_free", "pmr_memcpy_h2d", "pmr_memcpy_d2h", "pmr_device_synchronize",
+    "pmr_synth_default_cfg", "pmr_synth_iq_device",
     # include/pmr_dsd.h
     "pmr_dsd_default_cfg", "pmr_dsd_create", "pmr_dsd_reset", "pmr_dsd_destroy", "pmr_dsd_max_out",
     "pmr_dsd_last_error", "pmr_dsd_process_block", "pmr_dsd_process_block_device", "pmr_dsd_synchronize",
@@ -61,6 +64,12 @@ class DsdCfg(C.Structure):
 
 class DsdPlanState(C.Structure):
     _fields_ = [("n_raw", C.c_uint64), ("n_resampled", C.c_uint64), ("down_phase", C.c_uint32)]
+
+
+class SynthCfg(C.Structure):
+    """pmr_synth_cfg (include/pmr_mem.h)."""
+    _fields_ = [("fs_in", C.c_double), ("num_channels", C.c_uint), ("stream_id", C.c_uint), ("snr_db", C.c_double),
+                ("dev_hz", C.c_double), ("ctcss_dev_hz", C.c_double), ("period_log2", C.c_uint), ("channel_step", C.c_uint)]
 
 
 class PmrCfg(C.Structure):
@@ -152,6 +161,20 @@ def load(build_if_missing=True):
     L.pmr_host_alloc.restype = vp
     L.pmr_host_free.argtypes = [vp]
     L.pmr_host_free.restype = None
+    L.pmr_device_alloc.argtypes = [C.c_size_t, i]
+    L.pmr_device_alloc.restype = vp
+    L.pmr_device_free.argtypes = [vp]
+    L.pmr_device_free.restype = None
+    L.pmr_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+    L.pmr_memcpy_h2d.restype = i
+    L.pmr_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    L.pmr_memcpy_d2h.restype = i
+    L.pmr_device_synchronize.argtypes = []
+    L.pmr_device_synchronize.restype = i
+    L.pmr_synth_default_cfg.argtypes = [C.POINTER(SynthCfg), C.c_double, u]
+    L.pmr_synth_default_cfg.restype = None
+    L.pmr_synth_iq_device.argtypes = [C.POINTER(SynthCfg), vp, C.c_uint64, C.c_size_t]
+    L.pmr_synth_iq_device.restype = i
     L.pmr_chain_set_channel_mask.argtypes = [vp, vp, u]
     L.pmr_chain_set_channel_mask.restype = i
     L.pmr_chain_reset_channel.argtypes = [vp, u]
@@ -211,6 +234,61 @@ def load(build_if_missing=True):
     L.pmr_dsd_cfg_info.restype = u
     _lib = L
     return L
+
+
+class DeviceBuffer:
+    """HBM through the library's own HIP runtime (include/pmr_mem.h): no PyTorch needed to hold a block on the device."""
+
+    def __init__(self, nbytes, device=-1):
+        self._L = load()
+        self.nbytes = int(nbytes)
+        self.ptr = self._L.pmr_device_alloc(self.nbytes, device)
+        if not self.ptr:
+            raise PmrError("pmr_device_alloc(%d) failed" % nbytes)
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        if self._L.pmr_memcpy_h2d(self.ptr + offset, arr.ctypes.data, arr.nbytes):
+            raise PmrError("pmr_memcpy_h2d failed")
+
+    def download(self, dtype, count, offset=0):
+        out = np.empty(int(count), dtype=dtype)
+        assert offset + out.nbytes <= self.nbytes
+        if self._L.pmr_memcpy_d2h(out.ctypes.data, self.ptr + offset, out.nbytes):
+            raise PmrError("pmr_memcpy_d2h failed")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._L.pmr_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def synth_iq_device(n, fs_in, num_channels, stream_id=0, n0=0, dev_hz=2500.0, ctcss_dev_hz=300.0, snr_db=30.0, period_log2=0,
+                    channel_step=1, device=-1):
+    """DeviceBuffer holding n cf32 samples [n0, n0 + n) of the synthetic SURVEY s8(d) stream, generated by a kernel in HBM."""
+    L = load()
+    buf = DeviceBuffer(int(n) * 8, device)
+    cfg = SynthCfg()
+    L.pmr_synth_default_cfg(C.byref(cfg), fs_in, num_channels)
+    cfg.stream_id, cfg.snr_db, cfg.dev_hz, cfg.ctcss_dev_hz = stream_id, snr_db, dev_hz, ctcss_dev_hz
+    cfg.period_log2, cfg.channel_step = period_log2, channel_step
+    rc = L.pmr_synth_iq_device(C.byref(cfg), buf.ptr, n0, int(n))
+    if rc:
+        raise PmrError("pmr_synth_iq_device rc=%d" % rc)
+    return buf
+
+
+def device_synchronize():
+    if load().pmr_device_synchronize():
+        raise PmrError("pmr_device_synchronize failed")
 
 
 def make_cfg(fs_in=1024000.0, num_channels=16, max_block=100000, **kw):
