@@ -104,13 +104,21 @@ unsigned pmr_chain_max_in_flight(pmr_chain q);
 void    *pmr_host_alloc(size_t bytes);                     /* NULL on failure */
 void     pmr_host_free(void *p);
 
-/* Device-resident variant: every pointer is a HIP device pointer on the chain's device; work is queued on
- * the chain's stream and NOT synchronised (call pmr_chain_synchronize).  n_frames is a host pointer and is
- * valid on return (frame counts are closed-form in n_in).                                            */
+/* Device-resident variant: every pointer is a HIP device pointer on the chain's device; nothing is synchronised (call
+ * pmr_chain_synchronize).  n_frames is a host pointer and is valid on return (frame counts are closed-form in n_in).
+ * STREAM CONTRACT.  Outputs are written by work queued on pmr_chain_stream().  d_iq is read by the front end, which
+ * pipelined calls queue on a SECOND, internal stream that does not wait for pmr_chain_stream() or the null stream:
+ *   - d_iq must be complete when the call is made, OR the caller records an event behind its producer and hands it over with
+ *     pmr_chain_wait_input_event() just before the call (the reads then wait for it on the device);
+ *   - d_iq must stay untouched until the block's front end has run: pmr_chain_synchronize_input() (or
+ *     pmr_chain_synchronize()) returns once that is true for every queued block.  Up to pmr_chain_max_in_flight() front
+ *     ends may be queued ahead of their back ends.                                                                   */
 int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
                                    void *d_pcm, void *d_audio, unsigned pcm_stride, unsigned *n_frames,
                                    void *d_chan_out, void *d_rssi_db);
 int   pmr_chain_synchronize(pmr_chain q);
+int   pmr_chain_wait_input_event(pmr_chain q, void *hip_event /* hipEvent_t */);
+int   pmr_chain_synchronize_input(pmr_chain q);
 
 /* ---- SURVEY s8 row f1, second half: demodulate only the OPEN channels (the reference's own semantics, src/sdr_pmr446.c:876-877;
  * the squelch state machine hands over the active channel, :834-839).  mask_words: bit (k & 63) of word k >> 6 enables

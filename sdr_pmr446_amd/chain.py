@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
     "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read", "pmr_chain_set_channel_mask", "pmr_chain_reset_channel",
     "pmr_chain_submit_block", "pmr_chain_submit_block_fmt", "pmr_chain_collect_block", "pmr_chain_blocks_in_flight", "pmr_chain_max_in_flight",
-    "pmr_host_alloc", "pmr_host_free",
+    "pmr_host_alloc", "pmr_host_free", "pmr_chain_wait_input_event", "pmr_chain_synchronize_input",
     # include/pmr_mem.h
     "pmr_device_alloc", "pmr_device_free", "pmr_memcpy_h2d", "pmr_memcpy_d2h", "pmr_device_synchronize",
     "pmr_synth_default_cfg", "pmr_synth_iq_device",
@@ -161,6 +161,10 @@ def load(build_if_missing=True):
     L.pmr_host_alloc.restype = vp
     L.pmr_host_free.argtypes = [vp]
     L.pmr_host_free.restype = None
+    L.pmr_chain_wait_input_event.argtypes = [vp, vp]
+    L.pmr_chain_wait_input_event.restype = i
+    L.pmr_chain_synchronize_input.argtypes = [vp]
+    L.pmr_chain_synchronize_input.restype = i
     L.pmr_device_alloc.argtypes = [C.c_size_t, i]
     L.pmr_device_alloc.restype = vp
     L.pmr_device_free.argtypes = [vp]

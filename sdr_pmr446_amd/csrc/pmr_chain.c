@@ -60,6 +60,7 @@ struct pmr_chain_s {
                                         calls: the synchronous host entry point and set_overlap(0) -- no cross-stream events at all)   */
     int last_single;                 /* the previous call was a single-stream one                                   */
     hipEvent_t ev_switch;            /* orders stream_fe behind stream when a pipelined call follows a single-stream one */
+    hipEvent_t input_ready; int has_input_ready;   /* caller's "d_iq is complete" event for the NEXT device-entry call */
     hipStream_t stream_h2d;          /* input copies of the asynchronous host-buffer pair: H2D of block b+1 under the kernels of block b */
     hipEvent_t ev_fe[PIPE_DEPTH], ev_be[PIPE_DEPTH];   /* front end / back end of block (n mod PIPE_DEPTH) finished     */
     int overlap;                     /* two-stream pipelining enabled (PMR_OVERLAP=0 disables)                     */
@@ -119,6 +120,9 @@ struct pmr_chain_s {
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
     int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_tiles_params pend_t2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
+    /* persistent one-level kernel (k_fe_persist): ticket counters, published carry records, fallback flags */
+    int fe_persist; unsigned fe_nwg; uint32_t *d_fe_tickets; uint32_t fe_ticket_base[8]; uint64_t *d_fe_prec; uint8_t *d_fe_fixflag;
+    uint32_t fe_epoch;
     unsigned fe_max_tiles;
 
     /* host-side counters (all closed form in the number of samples consumed) */
@@ -435,6 +439,28 @@ static int fe_init(pmr_chain q)
     }
     q->fe_sel = 0;
     q->fe_on = 1;
+    /* PMR_FE_PERSIST=1 (A/B switch, off by default): persistent kernel with the dc carry applied in-kernel, for the one-level
+     * cascades the specialised kernels cover (N3 six-tap stages + m = 5, 10) with at most 2 x 256 resampler outputs per tile.
+     * Correct (parity-tested) and it removes the 90 MB read-modify-write of k_fe_tilefix, but measured SLOWER on MI355X at
+     * cfg2 (isolated front end): one tile per workgroup 0.125 ms + k_fe_tilefix 0.024 ms  vs  persistent loop alone 0.150 ms,
+     * + carry hand-off 0.186 ms, + ticket atomics 0.243 ms -- so the two-kernel form stays the product. */
+    q->fe_persist = 0;
+    if (!q->fe_two && nt == 256 && !q->sw.fe_generic && q->sw.fe_persist && h >= 3 && h <= 5) {
+        int ok = q->fe_m[h - 2] == 5 && q->fe_m[h - 1] == 10;
+        for (unsigned e = 0; e + 2 < h; e++) if (q->fe_m[e] != 3) ok = 0;
+        const uint64_t max_out = ((uint64_t)q->fe_TQ << 24) / d->arb_step + 2;
+        if (ok && max_out <= 512) {
+            int ncu = 0, dev = q->device;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+            q->fe_nwg = 4u * (unsigned)ncu;                   /* 39.9 KB of LDS per workgroup: four per CU */
+            if ((rc = dev_alloc(q, (void **)&q->d_fe_tickets, 8 * sizeof(uint32_t)))) return rc;
+            if ((rc = dev_alloc(q, (void **)&q->d_fe_prec, (size_t)q->fe_max_tiles * 2 * sizeof(uint64_t)))) return rc;
+            if ((rc = dev_alloc(q, (void **)&q->d_fe_fixflag, q->fe_max_tiles))) return rc;
+            memset(q->fe_ticket_base, 0, sizeof(q->fe_ticket_base));
+            q->fe_epoch = 0;
+            q->fe_persist = 1;
+        }
+    }
     return PMR_OK;
 }
 
@@ -561,6 +587,8 @@ static void read_switches(pmr_switches *w)
     memset(w, 0, sizeof(*w));
     w->fe_staged = env_is("PMR_FRONTEND", "staged");
     w->fe_generic = env_is("PMR_FE_KERNEL", "generic");
+    w->fe_persist = env_is("PMR_FE_PERSIST", "1");
+    { const char *e = getenv("PMR_FE_STAGGER"); w->fe_stagger = e ? atoi(e) : 2; }
     { const char *e = getenv("PMR_FE_LEVELS"); w->fe_levels = e ? atoi(e) : 0; }
     w->l2_on_fe = env_is("PMR_L2_STREAM", "fe");
     w->chan_generic = env_is("PMR_CHANNELIZER", "generic");
@@ -656,7 +684,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_tickets, q->d_fe_prec, q->d_fe_fixflag, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
@@ -705,6 +733,10 @@ int pmr_chain_reset(pmr_chain q)
         HIPCHK(hipMemsetAsync(q->d_fe_hist[i], 0, (size_t)q->fe_hcap * sizeof(cfl), q->stream), "reset");
         HIPCHK(hipMemsetAsync(q->d_fe_vstate[i], 0, sizeof(cfl), q->stream), "reset");
     }
+    if (q->d_fe_tickets) {
+        HIPCHK(hipMemsetAsync(q->d_fe_tickets, 0, 8 * sizeof(uint32_t), q->stream), "reset");
+        memset(q->fe_ticket_base, 0, sizeof(q->fe_ticket_base));
+    }
     q->fe_sel = 0;
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
     q->pend_l2 = 0;
@@ -720,6 +752,26 @@ unsigned pmr_chain_max_frames(pmr_chain q) { return q ? q->chan_size : 0; }
 unsigned pmr_chain_num_channels(pmr_chain q) { return q ? q->M : 0; }
 const char *pmr_chain_last_error(pmr_chain q) { return q ? q->err : "null handle"; }
 void *pmr_chain_stream(pmr_chain q) { return q ? (void *)q->stream : NULL; }
+
+/* d_iq of pmr_chain_process_block_device is READ by the front end, which pipelined calls queue on a second stream: a caller
+ * that produces d_iq on a stream of its own hands over an event recorded behind its producer; the next call's reads wait for it. */
+int pmr_chain_wait_input_event(pmr_chain q, void *hip_event)
+{
+    if (!q || !hip_event) return PMR_EINVAL;
+    q->input_ready = (hipEvent_t)hip_event;
+    q->has_input_ready = 1;
+    return PMR_OK;
+}
+
+/* returns when every queued block's front end has finished reading its d_iq: the buffers may be overwritten */
+int pmr_chain_synchronize_input(pmr_chain q)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(q->stream_fe), "hipStreamSynchronize");
+    if (q->last_single) HIPCHK(hipStreamSynchronize(q->stream), "hipStreamSynchronize");
+    return PMR_OK;
+}
 
 int pmr_chain_synchronize(pmr_chain q)
 {
@@ -870,14 +922,34 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     p.dc_a1 = d->dc_a1; p.zeta = d->zeta; p.lam_wave = q->fe_lam_wave;
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     fe_fill_taps(q, &p, 0, h);
-    LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic));
+    if (q->fe_persist) {
+        const unsigned CH = 64, nwg = ntiles < q->fe_nwg ? ntiles : q->fe_nwg;
+        p.tickets = q->d_fe_tickets; memcpy(p.ticket_base, q->fe_ticket_base, sizeof(p.ticket_base));
+        p.chunk = CH; p.stagger = (unsigned)q->sw.fe_stagger; p.ntiles = ntiles; p.prec = q->d_fe_prec; p.epoch = ++q->fe_epoch; p.fixflag = q->d_fe_fixflag;
+        if (p.epoch == 0) p.epoch = ++q->fe_epoch;            /* 0 is what freshly zeroed records carry */
+        p.v_in = t.v_in; p.v_out = t.v_out; p.rho_pow = t.rho_pow; p.carry_K = t.K; p.rho = t.rho; p.lamHh = t.lamHh;
+        p.inv_lamHh = t.inv_lamHh; p.inv_lamL = t.inv_lamL; p.lamEnd = t.lamEnd;
+        p.GA = q->d_fe_GA; p.T1 = q->d_fe_T1; p.T2 = q->d_fe_T2; p.Kgain = q->fe_Kgain;
+        LAUNCH_FE(K_FE, pmr_launch_fe_persist(q->sfe, &p, nwg));
+        /* every workgroup takes tickets until one falls beyond the last tile: counter x hands out (tiles of its chunks) + (its
+         * workgroups) tickets per launch -- the host tracks the bases, the counters are never reset */
+        for (unsigned xc = 0; xc < 8; xc++) {
+            unsigned tiles_x = 0;
+            for (unsigned ch0 = xc; (uint64_t)ch0 * CH < ntiles; ch0 += 8)
+                tiles_x += (uint64_t)(ch0 + 1) * CH <= ntiles ? CH : ntiles - ch0 * CH;
+            q->fe_ticket_base[xc] += tiles_x + (nwg + 7 - xc) / 8;
+        }
+    } else {
+        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic));
+    }
 
     pmr_fe_fix_params f;
     memset(&f, 0, sizeof(f));
     f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[slot]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
     f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
     f.Kgain = q->fe_Kgain;
-    LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q));
+    /* persistent kernel: only the tiles it flagged (carry not available in time) are corrected here -- normally none */
+    LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, q->fe_persist ? q->d_fe_fixflag : NULL));
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
     *ny_out = ny;
@@ -1145,6 +1217,10 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
         if (q->n_calls >= PIPE_DEPTH) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
     }
     q->last_single = single;
+    if (q->has_input_ready) {                    /* the caller's producer of d_iq finishes first (pmr_chain_wait_input_event) */
+        q->has_input_ready = 0;
+        HIPCHK(hipStreamWaitEvent(q->sfe, q->input_ready, 0), "wait input event");
+    }
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
     if ((rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)

@@ -427,32 +427,35 @@ __global__ __launch_bounds__(256) void k_fe_carry(pmr_fe_tiles_params t, pmr_fe_
 // its tile produced, in place:  xr[j] -= V_c * K * mu^q' * GA[idx_j]   (q' = tile-local decimated index, idx_j = polyphase
 // branch of output j; K, mu, GA: closed-form gains of the cascade for the exponential the missing carry adds).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_fe_fix_params f, unsigned n_q /*decimated samples of the block*/)
+__global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_fe_fix_params f, unsigned n_q /*decimated samples of the block*/,
+                                                    const uint8_t *__restrict__ flags)
 {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned c = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (c >= t.ntiles) return;
+    if (flags && !flags[c]) return;                              // fallback mode: k_fe_persist already corrected this tile
     const cf *pa = (const cf *)t.probeA, *pb = (const cf *)t.probeB;
-    // ---- V_c exactly as fe_carry_V computes it, the K-term sum spread over the lanes ----
+    // ---- V_c: the K-term sum spread over the lanes, in EXACTLY the arithmetic of k_fe_persist's in-kernel look-back (record of
+    // tile 0 = P_0 + rho W_0, lane k-1 holds term k, xor-butterfly reduction), so a tile corrected here as the persistent kernel's
+    // fallback gets bit for bit the carry it would have got there ----
     const unsigned kmax = c < t.K ? c : t.K;
     float ar = 0.f, ai = 0.f;
+    float V0r = 0.f, V0i = 0.f;
+    if (c <= t.K) {
+        const cf vs = *(const cf *)t.v_in, pl = *(const cf *)t.probeL;
+        V0r = (vs.x - pl.x) * t.inv_lamL; V0i = (vs.y - pl.y) * t.inv_lamL;
+    }
     for (unsigned k = 1 + lane; k <= kmax; k += 64u) {
         const cf A = pa[c - k], B = pb[c - k];
+        float Pr = fmaf(-t.rho, A.x, B.x), Pi = fmaf(-t.rho, A.y, B.y);
+        if (k == c) { Pr = fmaf(t.rho, fmaf(t.lamHh, V0r, A.x), Pr); Pi = fmaf(t.rho, fmaf(t.lamHh, V0i, A.y), Pi); }
         const float pw = t.rho_pow[k - 1];                           // rho^(k-1), tabulated in double on the host
-        ar = fmaf(pw, fmaf(-t.rho, A.x, B.x), ar);
-        ai = fmaf(pw, fmaf(-t.rho, A.y, B.y), ai);
+        ar += pw * Pr; ai += pw * Pi;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { ar += __shfl_xor(ar, d); ai += __shfl_xor(ai, d); }
-    if (c <= t.K) {
-        const cf vs = *(const cf *)t.v_in, pl = *(const cf *)t.probeL, a0 = pa[0];
-        const float V0r = (vs.x - pl.x) * t.inv_lamL, V0i = (vs.y - pl.y) * t.inv_lamL;
-        const float W0r = fmaf(t.lamHh, V0r, a0.x), W0i = fmaf(t.lamHh, V0i, a0.y);
-        const float pw = t.rho_pow[kmax];
-        ar = fmaf(pw, W0r, ar); ai = fmaf(pw, W0i, ai);
-    }
     const cf Ac = pa[c];
-    const float Vr = (ar - Ac.x) * t.inv_lamHh, Vi = (ai - Ac.y) * t.inv_lamHh;
+    const float Vr = c == 0 ? V0r : (ar - Ac.x) * t.inv_lamHh, Vi = c == 0 ? V0i : (ai - Ac.y) * t.inv_lamHh;
     if (lane == 0) {
         ((cf *)t.V)[c] = cfm(Vr, Vi);
         if (c == t.c_end) {
@@ -568,9 +571,10 @@ extern "C" int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t,
     return (int)hipGetLastError();
 }
 
-extern "C" int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q)
+extern "C" int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q,
+                                     const uint8_t *flags)
 {
     if (!t->ntiles) return 0;
-    hipLaunchKernelGGL(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, *t, *f, n_q);
+    hipLaunchKernelGGL(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, *t, *f, n_q, flags);
     return (int)hipGetLastError();
 }

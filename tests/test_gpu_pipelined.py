@@ -113,6 +113,7 @@ CASES = [
     ({}, CFG2, RAGGED2, True),                         # CTCSS branch enabled (second FIR pass + detector kernels in the back end)
     ({"PMR_L2_STREAM": "fe"}, CFG5, RAGGED5, False),
     ({"PMR_FRONTEND": "staged"}, CFG2, RAGGED2, False),
+    ({"PMR_FE_PERSIST": "1"}, CFG2, RAGGED2, False),        # in-kernel carry hand-off with blocks in flight
 ]
 
 

@@ -17,8 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     L = chain.load()
-    hdr = open(os.path.join(ROOT, "include", "pmr_chain.h")).read() + open(os.path.join(ROOT, "include", "pmr_dsd.h")).read() + \
-        open(os.path.join(ROOT, "include", "pmr_io.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("pmr_chain.h", "pmr_dsd.h", "pmr_io.h", "pmr_mem.h"))
     declared = set(re.findall(r"\b(pmr_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(chain.ABI_SYMBOLS), declared ^ set(chain.ABI_SYMBOLS)
     for sym in declared:

@@ -1,0 +1,14 @@
+#!/bin/bash
+# usage (GPU box): bash tools/variant_bench.sh <workload> "<extra hipcc flags>" ... : rebuild the library with each flag set and bench
+W=$1; shift
+for F in "$@"; do
+  PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" python3 sdr_pmr446_amd/build.py --force > /dev/null 2>&1
+  echo "== flags: $F"
+  python3 bench.py --workload $W --also none --no-cpu-baseline --regions 5 --parity-blocks 0 2>&1 | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']
+        print('value %.1f GS/s  ms/step %.4f  fe(contended) %.4f' % (d['value']/1e3,d['ms_per_step'],r['avg_kernel_ms']), {k:round(v,4) for k,v in r['kernels_ms_per_step_isolated'].items()})
+"
+done
