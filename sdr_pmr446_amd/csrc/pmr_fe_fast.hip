@@ -24,6 +24,9 @@
 #include "pmr_fe_common.hpp"
 
 enum { FE_FULL = 0, FE_L1 = 1 };
+#ifndef FE_DMA_AUX
+#define FE_DMA_AUX 0        /* cache policy of the raw-tile LDS-DMA: 0 default, 2 = nt (streaming, read once) */
+#endif
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
         for (int i = 0; i < N0 / 2 / NT; i++) {
             const int s0 = wave * (N0 / 8) + i * 64;                       // first slot of this wave-instruction (1 KiB)
             __builtin_amdgcn_global_load_lds((gptr_t *)(src + fe_swz(s0 + lane)), (lptr_t *)(reinterpret_cast<float4 *>(buf) + s0),
-                                             16, 0, 0);
+                                             16, 0, FE_DMA_AUX);
         }
     } else {
         // edge tiles (history before the block, zeros beyond it, or an unaligned block): plain loads into the same image
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_persist(pmr_fe_params p)
 #pragma unroll
             for (int i = 0; i < N0 / 2 / NT; i++) {
                 const int s0 = wave * (N0 / 8) + i * 64;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(src + fe_swz(s0 + lane)), (lptr_t *)(reinterpret_cast<float4 *>(buf) + s0), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t *)(src + fe_swz(s0 + lane)), (lptr_t *)(reinterpret_cast<float4 *>(buf) + s0), 16, 0, FE_DMA_AUX);
             }
         } else {
 #pragma unroll 4

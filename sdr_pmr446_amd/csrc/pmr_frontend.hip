@@ -375,11 +375,27 @@ static __device__ __forceinline__ cf fe_carry_V(const pmr_fe_tiles_params &p, un
     const cf *pa = (const cf *)p.probeA, *pb = (const cf *)p.probeB;
     float ar = 0.f, ai = 0.f;
     const unsigned kmax = c < p.K ? c : p.K;
-    for (unsigned k = 1; k <= kmax; k++) {
-        const cf A = pa[c - k], B = pb[c - k];
-        const float pw = p.rho_pow[k - 1];                           // rho^(k-1), tabulated in double on the host
-        ar = fmaf(pw, fmaf(-p.rho, A.x, B.x), ar);
-        ai = fmaf(pw, fmaf(-p.rho, A.y, B.y), ai);
+    if (p.K <= 16) {
+        // every probe of the look-back is requested before the first is used: the loop below with a run-time bound would pay the
+        // L2 latency of its loads one after the other (15 in a row for a 6 us kernel)
+        cf A[16], B[16]; float pw[16];
+#pragma unroll
+        for (unsigned k = 1; k <= 16; k++) {
+            const unsigned i = k <= kmax ? c - k : c;
+            A[k - 1] = pa[i]; B[k - 1] = pb[i]; pw[k - 1] = k <= kmax ? p.rho_pow[k - 1] : 0.f;
+        }
+#pragma unroll
+        for (unsigned k = 1; k <= 16; k++) {
+            ar = fmaf(pw[k - 1], fmaf(-p.rho, A[k - 1].x, B[k - 1].x), ar);
+            ai = fmaf(pw[k - 1], fmaf(-p.rho, A[k - 1].y, B[k - 1].y), ai);
+        }
+    } else {
+        for (unsigned k = 1; k <= kmax; k++) {
+            const cf A = pa[c - k], B = pb[c - k];
+            const float pw = p.rho_pow[k - 1];                           // rho^(k-1), tabulated in double on the host
+            ar = fmaf(pw, fmaf(-p.rho, A.x, B.x), ar);
+            ai = fmaf(pw, fmaf(-p.rho, A.y, B.y), ai);
+        }
     }
     if (c <= p.K) {
         const cf vs = *(const cf *)p.v_in, pl = *(const cf *)p.probeL, a0 = pa[0];
