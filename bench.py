@@ -200,6 +200,8 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
     lb = args.log2_block if args.log2_block is not None else lb
     block = 1 << lb
     ch = pmr.PmrChain(fs_in=fs, num_channels=M, max_block=block, device=local_rank)
+    if args.ctcss:
+        ch._check(ch._L.pmr_chain_ctcss_enable(ch.h, 1))
     S = ch.max_frames
     # Resident in HBM before timing, generated there by the library's own kernel (include/pmr_mem.h: every buffer of this
     # program lives in the library's HIP runtime; torch is here for torch.distributed only).  period_log2: all frequencies
@@ -397,6 +399,8 @@ def main():
     ap.add_argument("--host-io", action="store_true",
                     help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
+    ap.add_argument("--ctcss", action="store_true", help="run with the CTCSS detector enabled (SURVEY s8 row f2) -- an A/B aid, "
+                                                         "not the headline workload")
     args = ap.parse_args()
 
     import torch

@@ -148,7 +148,8 @@ enum { PMR_DESIGN_HALFBAND = 0, PMR_DESIGN_ARB = 1, PMR_DESIGN_PFB = 2 };
 unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx);
 unsigned pmr_chain_design(pmr_chain q, int what, unsigned idx, float *out, unsigned cap);
 enum { PMR_DEBUG_RESAMPLED = 0,   /* cf32 [ny]  resampler output of the last block (:796)              */
-       PMR_DEBUG_FM = 1 };        /* f32 [ns][M] discriminator output of the last block, time-major     */
+       PMR_DEBUG_FM = 1,          /* f32 [ns][M] discriminator output of the last block, time-major     */
+       PMR_DEBUG_CTCSS_LP = 2 };  /* f32 [ns][M] CTCSS low-pass branch delay188(x) - hp(x) (:889) of the last block (detector on) */
 int pmr_chain_debug_enable(pmr_chain q, int on);   /* capture the intermediates of subsequent blocks */
 int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes, size_t *n_bytes);
 

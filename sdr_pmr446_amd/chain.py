@@ -14,7 +14,7 @@ PMR_OK, PMR_EINVAL, PMR_ERANGE, PMR_EHIP, PMR_ENOMEM = 0, 1, 2, 3, 4
 
 INFO_NUM_STAGES, INFO_M_STAGE, INFO_ARB_STEP, INFO_NCO_DTHETA, INFO_ARB_NPFB, INFO_ARB_M, INFO_PFB_P = range(7)
 DESIGN_HALFBAND, DESIGN_ARB, DESIGN_PFB = range(3)
-DEBUG_RESAMPLED, DEBUG_FM = range(2)
+DEBUG_RESAMPLED, DEBUG_FM, DEBUG_CTCSS_LP = range(3)
 
 #: every symbol include/pmr_chain.h declares
 ABI_SYMBOLS = [
@@ -422,7 +422,7 @@ class PmrChain:
         rssi = np.zeros(M, dtype=np.float32) if "rssi" in want else None
         if "ctcss" in want:
             self._check(self._L.pmr_chain_ctcss_enable(self.h, 1))
-        dbg = bool(want & {"resampled", "fm"})
+        dbg = bool(want & {"resampled", "fm", "ctcss_lp"})
         if dbg:
             self._check(self._L.pmr_chain_debug_enable(self.h, 1))
         ns = C.c_uint(0)
@@ -446,6 +446,9 @@ class PmrChain:
         if "fm" in want:
             fm = self.debug_read(DEBUG_FM, np.float32)
             out["fm"] = fm.reshape(-1, M).T.copy() if len(fm) else np.zeros((M, 0), np.float32)
+        if "ctcss_lp" in want:
+            lp = self.debug_read(DEBUG_CTCSS_LP, np.float32)
+            out["ctcss_lp"] = lp.reshape(-1, M).T.copy() if len(lp) else np.zeros((M, 0), np.float32)
         return out
 
     # -- asynchronous host-buffer pair ------------------------------------------------------------

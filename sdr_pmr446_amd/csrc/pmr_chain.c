@@ -94,6 +94,7 @@ struct pmr_chain_s {
 
     /* CTCSS branch (pmr_ctcss.hip), allocated by pmr_chain_ctcss_enable */
     int ct_on; unsigned ct_max_ev, ct_nev_last; int ct_sel;
+    float *d_ct_taps_ext;            /* the low-pass-branch taps zero-extended to the folded audio filter's length (dual pass) */
     float *d_ctlp, *d_ct_taps, *d_ct_agg, *d_ct_W, *d_ct_dcstate, *d_ct_U, *d_ct_coef, *d_ct_part, *d_ct_carry[2];
     pmr_ctcss_event *d_ct_events;
     unsigned hp_len_raw;             /* length of the un-folded high-pass table (377)                 */
@@ -131,7 +132,7 @@ struct pmr_chain_s {
     uint64_t xr_abs;                 /* resampled samples produced since reset                */
     uint64_t frames_done;            /* frames channelized since reset                        */
     unsigned last_ny, last_ns;
-    int dbg_on; cfl *d_dbg_xr; float *d_dbg_fm;
+    int dbg_on; cfl *d_dbg_xr; float *d_dbg_fm, *d_dbg_ct;
 
     /* profiling */
     int prof_on;
@@ -598,6 +599,7 @@ static void read_switches(pmr_switches *w)
                 : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
     w->fir_mfma_global = env_is("PMR_FIR_MFMA", "global");
     { const char *e = getenv("PMR_FIR_TPW"); w->fir_tpw = e ? atoi(e) : 2; }
+    w->fir_nodual = env_is("PMR_FIR_DUAL", "0");
     w->no_overlap = env_is("PMR_OVERLAP", "0");
     w->equal_prio = env_is("PMR_STREAM_PRIO", "0");
 }
@@ -681,10 +683,10 @@ int pmr_chain_destroy(pmr_chain q)
     void *bufs[] = { q->d_arb_bank, q->d_pfb_taps_t, q->d_fft_tw, q->d_nco_cs, q->d_lam_thread_pow,
                      q->d_lam_tile_idx_pow, q->d_hp_pad, q->d_lp_pad, q->d_de_pad, q->d_in, q->d_dc_state,
                      q->d_dc_agg, q->d_dc_W, q->d_xr, q->d_fm, q->d_aux1, q->d_aux2, q->d_scratch,
-                     q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_fe_taps, q->d_fe_GA,
+                     q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_dbg_ct, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_tickets, q->d_fe_prec, q->d_fe_fixflag, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_tickets, q->d_fe_prec, q->d_fe_fixflag, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
@@ -1083,13 +1085,20 @@ void pmr_chain_frontend_view(pmr_chain q, pmr_fe_view *v)
 
 /* ------------------------------------------------------------------------------------------- */
 
+static int ring_to_linear(pmr_chain q, void *dst, const void *ring, uint64_t mask, uint64_t pos, size_t n, size_t elem);
+
 /* ---- CTCSS branch: low-pass branch FIR -> dc-block scan -> Goertzel bank, all channels ---- */
-static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns)
+static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*the low-pass branch is already in d_ctlp*/)
 {
     const unsigned M = q->M, N = PMR_CT_BLOCK;
     /* tmp1 = delay188(fm) - hp(fm) (:884-889) as one FIR with taps delta_188 - h */
-    LAUNCH(K_CT_FIR, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
+    if (!fir_done) LAUNCH(K_CT_FIR, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
                                        0.f, 0.f, 0.f, q->d_ctlp, NULL, NULL, 0, q->mask_on ? q->d_chan_list : NULL, q->n_enabled));
+    if (q->dbg_on) {                                               /* the branch before ctcss_execute's dc blocker (:889 -> :606) */
+        int rc_;
+        if (!q->d_dbg_ct && (rc_ = dev_alloc(q, (void **)&q->d_dbg_ct, (size_t)q->chan_size * M * sizeof(float)))) return rc_;
+        if ((rc_ = ring_to_linear(q, q->d_dbg_ct, q->d_ctlp, q->fm_mask, (uint64_t)frame0, ns, (size_t)M * sizeof(float)))) return rc_;
+    }
     const float a1 = -1.0f + 0.0005f;                              /* iirfilt_rrrf_create_dc_blocker(0.0005f), :450 */
     const double lam = -(double)a1;
     const unsigned nchunks = (ns + 255) / 256, len_last = ns - (nchunks - 1) * 256;
@@ -1123,6 +1132,13 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on)
         for (unsigned i = 0; i < n; i++) tc[i] = -hp[i];
         tc[(n - 1) / 2] += 1.0f;                                   /* wdelayf((n-1)/2), :447 */
         rc = upload_padded_taps(q, &q->d_ct_taps, tc, n);
+        if (!rc && q->hp_len >= n) {
+            /* same taps as a filter of the folded audio filter's length (zeros behind): both products then run over one window
+             * in ONE pass of the MFMA kernel (pmr_launch_fir_dual) */
+            float *te = (float *)calloc(q->hp_len, sizeof(float));
+            if (!te) rc = fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+            else { memcpy(te, tc, n * sizeof(float)); rc = upload_padded_taps(q, &q->d_ct_taps_ext, te, q->hp_len); free(te); }
+        }
         free(tc);
         if (rc) return rc;
         /* Goertzel weights U_m = sin((m+1)w)/sin(w), coef = 2cos(w) as the reference computes it (:360-361) */
@@ -1272,10 +1288,21 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
         if (d_rssi_db)
             LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->d_rssi_part, ntiles, M, ns, (float *)d_rssi_db));
 
-        if (q->ct_on && (rc = ctcss_run(q, frame0, ns))) return rc;
+        /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906); with the CTCSS
+         * detector on, its low-pass branch delay188(x) - hp(x) (:884-889) is a second tap set over the same samples: one pass */
+        int ct_fir_done = 0;
+        if (q->ct_on && q->d_ct_taps_ext && !q->sw.fir_nodual && (d_pcm || d_audio) && !q->cfg.deemph_fir && !q->cfg.lowpass) {
+            prof_pending pp_; prof_begin(q, K_FIR_HP, &pp_, q->stream);
+            const int rd = pmr_launch_fir_dual(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->d_ct_taps_ext,
+                                               q->hp_len, (int16_t *)d_pcm, (float *)d_audio, pcm_stride, q->d_ctlp,
+                                               q->mask_on ? q->d_chan_list : NULL, q->n_enabled);
+            prof_end(q, &pp_, q->stream);
+            if (rd > 0) return fail(q, PMR_EHIP, k_names[K_FIR_HP], (hipError_t)rd);
+            ct_fir_done = rd == 0;
+        }
+        if (q->ct_on && (rc = ctcss_run(q, frame0, ns, ct_fir_done))) return rc;
 
-        /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906) */
-        if (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass) {
+        if (!ct_fir_done && (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass)) {
             const int more = q->cfg.deemph_fir || q->cfg.lowpass;
             /* only the open channels are demodulated to audio.  With follow-on FIR passes (deemph_fir / lowpass) the mask
              * applies to the LAST pass only: the intermediate rings must keep every channel's history current, or a channel
@@ -1622,6 +1649,7 @@ int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes
     const void *src = NULL; size_t n = 0;
     if (what == PMR_DEBUG_RESAMPLED) { src = q->d_dbg_xr; n = (size_t)q->last_ny * sizeof(cfl); }
     else if (what == PMR_DEBUG_FM)   { src = q->d_dbg_fm; n = (size_t)q->last_ns * q->M * sizeof(float); }
+    else if (what == PMR_DEBUG_CTCSS_LP && q->d_dbg_ct) { src = q->d_dbg_ct; n = (size_t)q->last_ns * q->M * sizeof(float); }
     else return PMR_EINVAL;
     if (n_bytes) *n_bytes = n;
     if (n > cap_bytes) n = cap_bytes;

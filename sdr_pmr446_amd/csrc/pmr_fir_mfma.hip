@@ -46,15 +46,20 @@ static __device__ __forceinline__ int16_t pcm16(float y)
 // window staging (4-byte gathers instead of 64-byte rows) and the store addresses differ; the MFMA loop is the same.
 template <bool GLB, int TPW /*tiles per workgroup: 2 = the second tile's window is prefetched under the first tile's MFMAs*/,
           bool SWAP /*operands exchanged: the accumulators hold the TRANSPOSED tile (lane = frame), see the epilogue*/,
-          bool GATHER = false>
+          bool GATHER = false,
+          bool DUAL = false /*a SECOND tap set over the same samples, written time-major to out2_tm: the CTCSS low-pass branch
+                              delay188(x) - hp(x) (reference :884-889) in the same pass as the audio filter -- one window
+                              staging and one B operand for two banded-Toeplitz products*/>
 __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict__ in, unsigned long long row_mask,
                                                       long long row0, unsigned ns, const float *__restrict__ taps_c,
                                                       unsigned ntaps, float *__restrict__ out_tm,
                                                       int16_t *__restrict__ pcm, float *__restrict__ audio,
                                                       unsigned stride, unsigned M /*row width, multiple of 16*/,
-                                                      const unsigned *__restrict__ chan_list, unsigned n_units, unsigned nseg)
+                                                      const unsigned *__restrict__ chan_list, unsigned n_units, unsigned nseg,
+                                                      const float *__restrict__ taps2_c, float *__restrict__ out2_tm)
 {
     static_assert(!GATHER || (TPW == 1 && !GLB), "gathered units: one tile per workgroup, LDS window");
+    static_assert(!DUAL || (TPW == 1 && !GLB && SWAP), "dual tap sets: one tile per workgroup (register budget), LDS window");
     __shared__ unsigned s_ch[16];                                    // channel of column slot s (relative to the pointers below)
     __shared__ long s_t0[16];                                        // first frame of slot s
     if constexpr (GATHER) {
@@ -68,19 +73,22 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
         const unsigned cg0 = blockIdx.y * 16u;
         in += cg0;
         if (out_tm) out_tm += cg0;
+        if (DUAL) out2_tm += cg0;
         if (pcm) pcm += (size_t)cg0 * stride;
         if (audio) audio += (size_t)cg0 * stride;
     }
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
     float *Qs = reinterpret_cast<float *>(smem_m);                   // [ntaps + 2*PMR_TAP_PAD] padded taps
     const unsigned qlen = ntaps + 2 * PMR_TAP_PAD;
-    float *Xs = Qs + ((qlen + 31) & ~31u);                           // rows: r at r*16 + 16*(r>>5)
+    float *Q2 = Qs + ((qlen + 31) & ~31u);                           // DUAL: second padded tap table
+    float *Xs = Q2 + (DUAL ? ((qlen + 31) & ~31u) : 0u);             // rows: r at r*16 + 16*(r>>5)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned nrows = FM_TILE + ntaps + 31;                     // frames T0-(ntaps-1) .. T0+255 (+32: kappa padded to 32)
     const int j = lane & 31, kk = lane >> 5, ch = j & 15, blk = j >> 4;
     const int Tj = 64 * wave + 32 * blk;                             // frame offset of this column inside the tile
 
     for (unsigned i = tid; i < qlen; i += FM_NT) Qs[i] = taps_c[i];
+    if constexpr (DUAL) for (unsigned i = tid; i < qlen; i += FM_NT) Q2[i] = taps2_c[i];
 
     // window of the tile starting at frame T0: global -> registers (issue), registers -> LDS (commit)
     float4 pre[FM_PRE];
@@ -137,9 +145,9 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
     const bool active = GATHER || T0 + 64 * wave < (long)ns;         // else: whole wave beyond the block
 
     if (active) {
-    f32x16 acc;
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    for (int i = 0; i < 16; i++) { acc[i] = 0.f; acc2[i] = 0.f; }
     // kappa runs over [0, ntaps + 31), padded up to a multiple of 32 (the extra taps are zeros of the padded table): 16
     // MFMA steps per group.  Inside a group every LDS address is one per-lane base plus a compile-time offset:
     //   tap     for kappa = 2s + kk :  Qs[PAD + (ntaps-1) + (lane&31) - kk - 2s]
@@ -153,6 +161,14 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
     const long long rb0 = row0 + T0 + Tj + kk - (long long)(ntaps - 1);            // GLB: ring row of group 0, step 0
     const float *gin = in + ch;
     float a0[16], b0[16], a1[16], b1[16];
+    float c0[DUAL ? 16 : 1], c1[DUAL ? 16 : 1];                                     // DUAL: taps of the second set
+    const float *q20 = Q2 + (q0 - Qs);
+#define FM_LOAD2(C, G) do { if constexpr (DUAL) { const unsigned gi_ = (G) < groups ? (G) : groups - 1;                    \
+        const float *q_ = q20 - 32 * (int)gi_;                                                                                \
+        _Pragma("unroll") for (int u = 0; u < 16; u++) C[u] = q_[2 * (15 - u)]; } } while (0)
+#define FM_MMA2(C, B) do { if constexpr (DUAL) { _Pragma("unroll") for (int u = 0; u < 16; u++)                            \
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(C[u], B[u], acc2, 0, 0, 0);                                              \
+        __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define FM_LOAD(A, B, G) do { const unsigned gi_ = (G) < groups ? (G) : groups - 1;   /* clamped: never past the tables */ \
         const float *q_ = q0 - 32 * (int)gi_, *x_ = x0 + (16 * 32 + 16) * (int)gi_;                                          \
         const long long rg_ = rb0 + 32 * (long long)gi_;                                                                      \
@@ -165,17 +181,32 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
         acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(B[u], A[u], acc, 0, 0, 0)                                          \
                    : __builtin_amdgcn_mfma_f32_32x32x2f32(A[u], B[u], acc, 0, 0, 0);                                         \
         __builtin_amdgcn_sched_barrier(0); } while (0)
+    FM_LOAD2(c0, 0u);
     FM_LOAD(a0, b0, 0u);
     unsigned g = 0;
     for (; g + 2 <= groups; g += 2) {
+        FM_LOAD2(c1, g + 1);
         FM_LOAD(a1, b1, g + 1);
-        FM_MMA(a0, b0);
+        FM_MMA(a0, b0); FM_MMA2(c0, b0);
+        FM_LOAD2(c0, g + 2);
         FM_LOAD(a0, b0, g + 2);
-        FM_MMA(a1, b1);
+        FM_MMA(a1, b1); FM_MMA2(c1, b1);
     }
-    if (groups & 1) FM_MMA(a0, b0);                                                // set 0 holds group groups-1 here
+    if (groups & 1) { FM_MMA(a0, b0); FM_MMA2(c0, b0); }                            // set 0 holds group groups-1 here
 #undef FM_LOAD
 #undef FM_MMA
+#undef FM_LOAD2
+#undef FM_MMA2
+    if constexpr (DUAL) {
+        // second product in the UNTRANSPOSED layout (lane = column (slot, block), register 4g + q = frame 8g + 4kk + q): a
+        // register's 32 lanes cover 16 adjacent channels of two rows of the time-major ring
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const long t = (GATHER ? s_t0[ch] : T0) + Tj + 8 * (r >> 2) + 4 * kk + (r & 3);
+            const unsigned chs = GATHER ? s_ch[ch] : (unsigned)ch;
+            if (t < (long)ns) out2_tm[((unsigned long long)(row0 + t) & row_mask) * M + chs] = acc2[r];
+        }
+    }
 
     if constexpr (SWAP) {
         // Operands exchanged => D' = D^T (same products, same k order): lane = frame (column lane & 31), register 4g + q =
@@ -251,14 +282,17 @@ extern "C" int pmr_fir_mfma_supported(unsigned M, unsigned ntaps)
 
 extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
                                    unsigned ns, unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm,
-                                   float *audio, unsigned stride, const unsigned *chan_list, unsigned n_chan)
+                                   float *audio, unsigned stride, const unsigned *chan_list, unsigned n_chan,
+                                   const float *taps2_pad, float *out2_tm)
 {
     if (!ns) return 0;
     if (!pmr_fir_mfma_supported(M, ntaps)) return (int)hipErrorInvalidValue;
     const unsigned qlen = ntaps + 2 * PMR_TAP_PAD, nrows = FM_TILE + ntaps + 31;
-    const size_t lds = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float) +
+    const int dual = taps2_pad && out2_tm && !out_tm;          /* second tap set -> time-major out2_tm, same pass */
+    if ((taps2_pad || out2_tm) && !dual) return (int)hipErrorInvalidValue;
+    const size_t lds = (dual ? 2 : 1) * (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float) +
                        ((size_t)nrows * 16 + 16 * ((nrows >> 5) + 1)) * sizeof(float);
-    /* <= 47 KB of dynamic LDS (window of at most 704 rows x 16 columns + taps): inside the 64 KB default limit */
+    /* <= 49 KB of dynamic LDS (window of at most 704 rows x 16 columns + taps): inside the 64 KB default limit */
     hipStream_t st = (hipStream_t)s;
     const unsigned long long rm = (unsigned long long)row_mask;
     const long long r0 = (long long)row0;
@@ -269,12 +303,21 @@ extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const
         if (nrows * 16 > 4 * FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
         const unsigned n_units = n_chan * tiles;
         const dim3 grid((n_units + 15) / 16);
-        if (!out_tm)
+        if (dual)
+            hipLaunchKernelGGL((k_fir_mfma16<false, 1, true, true, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
+                               out_tm, pcm, audio, stride, M, chan_list, n_units, tiles, taps2_pad, out2_tm);
+        else if (!out_tm)
             hipLaunchKernelGGL((k_fir_mfma16<false, 1, true, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
-                               out_tm, pcm, audio, stride, M, chan_list, n_units, tiles);
+                               out_tm, pcm, audio, stride, M, chan_list, n_units, tiles, (const float *)nullptr, (float *)nullptr);
         else
             hipLaunchKernelGGL((k_fir_mfma16<false, 1, false, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
-                               out_tm, pcm, audio, stride, M, chan_list, n_units, tiles);
+                               out_tm, pcm, audio, stride, M, chan_list, n_units, tiles, (const float *)nullptr, (float *)nullptr);
+        return (int)hipGetLastError();
+    }
+    if (dual) {
+        if (nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_fir_mfma16<false, 1, true, false, true>), dim3(tiles, M / 16), dim3(FM_NT), lds, st, in, rm, r0, ns,
+                           taps_pad, ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u, taps2_pad, out2_tm);
         return (int)hipGetLastError();
     }
     /* PMR_FIR_MFMA=global: B operand straight from the ring (no LDS window; co-resides with front-end tiles).  Measured
@@ -283,7 +326,7 @@ extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const
     if (sw->fir_mfma_global) {
         const size_t lds_g = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float);
         hipLaunchKernelGGL((k_fir_mfma16<true, 1, false>), dim3(tiles, M / 16), dim3(FM_NT), lds_g, st, in, rm, r0, ns, taps_pad,
-                           ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u);
+                           ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u, (const float *)nullptr, (float *)nullptr);
         return (int)hipGetLastError();
     }
     /* two tiles per workgroup only while that still leaves enough workgroups to fill the chip (3 per CU fit) */
@@ -291,7 +334,7 @@ extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const
     if (!two && nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
     const dim3 grid(two ? (tiles + 1) / 2 : tiles, M / 16);
 #define FM_GO(TPW_, SWAP_) hipLaunchKernelGGL((k_fir_mfma16<false, TPW_, SWAP_>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, \
-                                              ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u)
+                                              ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u, (const float *)nullptr, (float *)nullptr)
     if (two) { if (!out_tm) FM_GO(2, true); else FM_GO(2, false); }
     else     { if (!out_tm) FM_GO(1, true); else FM_GO(1, false); }
 #undef FM_GO

@@ -30,6 +30,7 @@ typedef struct {
     int fir_mode;           /* PMR_FIR=pair|lds|global: VALU versions of the audio FIR (PMR_FIR_*)          */
     int fir_mfma_global;    /* PMR_FIR_MFMA=global: MFMA FIR without the LDS sample window                  */
     int fir_tpw;            /* PMR_FIR_TPW=1: one tile per workgroup in the MFMA FIR (default 2)            */
+    int fir_nodual;         /* PMR_FIR_DUAL=0: CTCSS low-pass branch in a FIR pass of its own                */
     int no_overlap;         /* PMR_OVERLAP=0                                                                */
     int equal_prio;         /* PMR_STREAM_PRIO=0                                                            */
 } pmr_switches;
@@ -119,12 +120,18 @@ int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsign
 int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                       const float *taps_pad, unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                       float *out_tm, int16_t *pcm, float *audio, unsigned stride, const unsigned *chan_list, unsigned n_chan);
+/* audio FIR (-> pcm / audio) and a second tap set of the same length (-> time-major out2_tm) in ONE pass over the samples;
+ * returns -1 when the MFMA kernel cannot take it (caller then runs two passes) */
+int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+                        const float *taps_pad, const float *taps2_pad, unsigned ntaps, int16_t *pcm, float *audio, unsigned stride,
+                        float *out2_tm, const unsigned *chan_list, unsigned n_chan);
 
 /* M = 16 audio FIR on the matrix pipe (pmr_fir_mfma.hip): banded-Toeplitz x data with v_mfma_f32_32x32x2_f32 */
 int pmr_fir_mfma_supported(unsigned M, unsigned ntaps);
 int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
                         unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio,
-                        unsigned stride, const unsigned *chan_list /*nullable: enabled channels (device)*/, unsigned n_chan);
+                        unsigned stride, const unsigned *chan_list /*nullable: enabled channels (device)*/, unsigned n_chan,
+                        const float *taps2_pad /*nullable: second tap set (same ntaps), -> out2_tm, same pass*/, float *out2_tm);
 
 /* ---- CTCSS branch (pmr_ctcss.hip) ---- */
 #define PMR_CT_TONES 38u

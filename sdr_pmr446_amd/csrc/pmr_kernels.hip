@@ -771,6 +771,16 @@ extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, un
     return (int)hipGetLastError();
 }
 
+extern "C" int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
+                                   unsigned M, const float *taps_pad, const float *taps2_pad, unsigned ntaps, int16_t *pcm, float *audio,
+                                   unsigned stride, float *out2_tm, const unsigned *chan_list, unsigned n_chan)
+{
+    if (sw->fir_mode != PMR_FIR_MFMA || sw->fir_mfma_global || !pmr_fir_mfma_supported(M, ntaps)) return -1;
+    if (!ns) return 0;
+    return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan,
+                               taps2_pad, out2_tm);
+}
+
 extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
                                  unsigned ns, unsigned M, const float *taps_pad, unsigned ntaps, float gain, int iir, float b0,
                                  float b1, float a1, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
@@ -779,7 +789,7 @@ extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const f
     if (!ns) return 0;
     const int mode = sw->fir_mode;           /* PMR_FIR_MFMA (default where supported), _PAIR, _LDS, _TM */
     if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
-        return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan);
+        return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr);
     if ((mode == PMR_FIR_PAIR || mode == PMR_FIR_MFMA) && M >= 2) {
         const unsigned segs = (ns + FP_R - 1) / FP_R;
         const size_t threads = (size_t)segs * (M >> 1);

@@ -43,3 +43,35 @@ def test_ctcss_matches_oracle(fs, M, N, splits, ks):
     carriers = [k for k in active_channels(M, ks) if synth.channel_kind(k) == "carrier"]
     for k in carriers:                                                          # bare carrier: no tone, in both
         assert not eo["detected"][k].any() and not eg["detected"][k].any()
+
+
+@pytest.mark.parametrize("opts,masked", [({}, False), ({}, True), (dict(lowpass=True), False)],
+                         ids=["dual-pass", "dual-pass-masked", "two-passes-lowpass"])
+def test_ctcss_low_pass_branch_matches_oracle(opts, masked):
+    """The intermediate the detector runs on -- tmp1 = delay188(x) - hp(x), reference src/sdr_pmr446.c:884-889 -- against the
+    oracle's, sample by sample.  With the default audio chain it comes out of the SAME MFMA pass as the audio (second tap set);
+    with follow-on FIR passes out of a pass of its own."""
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    n, splits = 260000, [100000, 60001, 99999]
+    x = synth.synth_iq(n, fs, M, dev_hz=1500.0, ctcss_dev_hz=700.0)
+    o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=max(splits), **opts)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(splits), **opts)
+    en = [0, 2, 5, 9] if masked else list(range(M))
+    if masked:
+        g.set_channel_mask(en)
+    pos, frames, checked = 0, 0, 0
+    for b, s in enumerate(splits):
+        ro = o.process_block(x[pos:pos + s], want=("pcm", "ctcss_lp", "ctcss"))
+        rg = g.process_block(x[pos:pos + s], want=("pcm", "ctcss_lp", "ctcss"))
+        pos += s
+        act = [k for k in active_channels(M) if k in en]
+        skip = max(0, 700 - frames)                       # start-up: |chan| ~ 0 makes arg() ill-conditioned and rings through the FIR
+        frames += ro["n_frames"]
+        assert rg["ctcss_lp"].shape == ro["ctcss_lp"].shape
+        d = np.abs(rg["ctcss_lp"][act][:, skip:] - ro["ctcss_lp"][act][:, skip:])
+        checked += d.size
+        assert d.size == 0 or d.max() < 2e-6, d.max()
+        assert np.abs(rg["pcm"][act].astype(np.int32) - ro["pcm"][act].astype(np.int32)).max() <= 1
+        assert np.array_equal(rg["ctcss"]["index"][act], ro["ctcss"]["index"][act])
+    assert checked > 2000
