@@ -71,10 +71,11 @@ def awgn(seed, n0, n, sigma):
 
 
 def synth_iq(n, fs_in, num_channels, stream_id=0, n0=0, snr_db=30.0, channels=None, dc_offset=0.0,
-             chunk=1 << 18, dev_hz=2500.0, ctcss_dev_hz=300.0):
+             chunk=1 << 18, dev_hz=2500.0, ctcss_dev_hz=300.0, ctcss_dev_of=None):
     """Return complex64 IQ samples [n0, n0+n) of stream `stream_id`.
 
     channels: iterable of channel indices to synthesise (default: all M).  Amplitudes/noise do not depend on it.
+    ctcss_dev_of: optional callable k -> CTCSS deviation in Hz of channel k (default: ctcss_dev_hz for every channel).
     """
     M = num_channels
     seed = (SEED_BASE + stream_id) & 0xFFFFFFFFFFFFFFFF
@@ -96,7 +97,8 @@ def synth_iq(n, fs_in, num_channels, stream_id=0, n0=0, snr_db=30.0, channels=No
             if kind == "fm":
                 fa = audio_tone_hz(k)
                 fc = CTCSS_FREQS[k % 38]
-                ph = ph + (dev_hz / fa) * np.sin(2.0 * np.pi * fa * t) + (ctcss_dev_hz / fc) * np.sin(2.0 * np.pi * fc * t)
+                cd = ctcss_dev_hz if ctcss_dev_of is None else float(ctcss_dev_of(k))
+                ph = ph + (dev_hz / fa) * np.sin(2.0 * np.pi * fa * t) + (cd / fc) * np.sin(2.0 * np.pi * fc * t)
             acc = acc + amp * np.exp(1j * ph)
         out[c0:c1] = acc.astype(np.complex64)
     return out

@@ -75,3 +75,34 @@ def test_ctcss_low_pass_branch_matches_oracle(opts, masked):
         assert np.abs(rg["pcm"][act].astype(np.int32) - ro["pcm"][act].astype(np.int32)).max() <= 1
         assert np.array_equal(rg["ctcss"]["index"][act], ro["ctcss"]["index"][act])
     assert checked > 2000
+
+
+def test_ctcss_decisions_around_the_thresholds():
+    """Tone levels swept THROUGH the decision thresholds avg > 120 && max/avg > 10 (reference src/sdr_pmr446.c:403-404): the
+    powers agree with the oracle within 0.5 %, and the decision agrees wherever the oracle's own margin to a threshold
+    exceeds that tolerance (inside the margin either answer is a rounding coin-flip in the reference itself)."""
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    n, splits = 2400000, [900000, 600001, 899999]
+    # Hz of CTCSS deviation: avg power crosses 120 near 300 Hz
+    devs = {k: d for k, d in zip(range(M), [150, 200, 230, 245, 250, 252, 255, 260, 280, 300, 320, 340, 400, 500, 600, 700])}
+    x = synth.synth_iq(n, fs, M, dev_hz=1500.0, ctcss_dev_of=lambda k: devs[k])
+    eo = _run(oracle.OracleChain(fs_in=fs, num_channels=M, max_block=max(splits)), x, splits)
+    eg = _run(chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(splits)), x, splits)
+    assert eo.shape == eg.shape and eo.shape[1] >= 4
+    fm_ch = [k for k in active_channels(M) if synth.channel_kind(k) == "fm"]
+    tol = 5e-3
+    seen = {0: 0, 1: 0}
+    near = 0
+    for k in fm_ch:
+        assert np.allclose(eg["avg_power"][k], eo["avg_power"][k], rtol=tol)
+        assert np.allclose(eg["max_power"][k], eo["max_power"][k], rtol=tol)
+        for b in range(1, eo.shape[1]):                       # (block 0 holds the start-up transient)
+            avg, mx = float(eo["avg_power"][k, b]), float(eo["max_power"][k, b])
+            margin = min(abs(avg - 120.0) / 120.0, abs(mx / avg - 10.0) / 10.0) if avg > 0 else 1.0
+            if margin > 2 * tol:
+                assert eg["detected"][k, b] == eo["detected"][k, b], (k, b, avg, mx / avg)
+                seen[int(eo["detected"][k, b])] += 1
+            else:
+                near += 1
+    assert seen[0] >= 4 and seen[1] >= 4, (seen, near)        # the sweep really straddles the avg > 120 threshold (252 Hz ~ 120)
