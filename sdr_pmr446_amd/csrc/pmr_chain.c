@@ -1101,8 +1101,8 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
     }
     const float a1 = -1.0f + 0.0005f;                              /* iirfilt_rrrf_create_dc_blocker(0.0005f), :450 */
     const double lam = -(double)a1;
-    const unsigned nchunks = (ns + 255) / 256, len_last = ns - (nchunks - 1) * 256;
-    LAUNCH(K_CT_DC, pmr_launch_ct_dc(q->stream, q->d_ctlp, q->fm_mask, frame0, ns, M, a1, (float)pow(lam, 256.0),
+    const unsigned nchunks = (ns + PMR_CT_CHUNK - 1) / PMR_CT_CHUNK, len_last = ns - (nchunks - 1) * PMR_CT_CHUNK;
+    LAUNCH(K_CT_DC, pmr_launch_ct_dc(q->stream, q->d_ctlp, q->fm_mask, frame0, ns, M, a1, (float)pow(lam, (double)PMR_CT_CHUNK),
                                      (float)pow(lam, (double)len_last), q->d_ct_dcstate, q->d_ct_agg, q->d_ct_W));
     const uint64_t f0 = (uint64_t)frame0, f1 = f0 + ns;
     const unsigned nblk = (unsigned)((f1 - 1) / N - f0 / N + 1), ncomplete = (unsigned)(f1 / N - f0 / N);
@@ -1154,7 +1154,7 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on)
         free(U);
         if (rc) return rc;
         if ((rc = dev_upload(q, &q->d_ct_coef, coef, PMR_CT_TONES))) return rc;
-        const size_t rows = (size_t)(q->fm_mask + 1), nch = q->chan_size / 256 + 2;
+        const size_t rows = (size_t)(q->fm_mask + 1), nch = q->chan_size / PMR_CT_CHUNK + 2;
         q->ct_max_ev = q->chan_size / N + 2;
         if ((rc = dev_alloc(q, (void **)&q->d_ctlp, rows * M * sizeof(float)))) return rc;
         if ((rc = dev_alloc(q, (void **)&q->d_ct_agg, nch * M * sizeof(float)))) return rc;

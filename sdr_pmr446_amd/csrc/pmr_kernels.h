@@ -135,7 +135,8 @@ int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in,
 
 /* ---- CTCSS branch (pmr_ctcss.hip) ---- */
 #define PMR_CT_TONES 38u
-#define PMR_CT_SEG 8u           /* time segments a Goertzel block is split into */
+#define PMR_CT_SEG 16u          /* time segments a Goertzel block is split into */
+#define PMR_CT_CHUNK 64u        /* frames per chunk of the CTCSS branch's dc-blocker scan */
 #define PMR_CT_BLOCK 2441u      /* CTCSS_BLOCK_SIZE, src/sdr_pmr446.c:37,:46 */
 int pmr_launch_ct_dc(pmr_stream_t s, float *lp, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M, float a1,
                      float lam_chunk, float lam_last, float *state, float *agg, float *W);
