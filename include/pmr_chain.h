@@ -104,8 +104,10 @@ unsigned pmr_chain_max_in_flight(pmr_chain q);
 void    *pmr_host_alloc(size_t bytes);                     /* NULL on failure */
 void     pmr_host_free(void *p);
 
-/* Device-resident variant: every pointer is a HIP device pointer on the chain's device; nothing is synchronised (call
- * pmr_chain_synchronize).  n_frames is a host pointer and is valid on return (frame counts are closed-form in n_in).
+/* Device-resident variant: every pointer is a HIP device pointer on the chain's device; the call does not wait for the block
+ * (call pmr_chain_synchronize).  Back-pressure: at most pmr_chain_max_in_flight() blocks are ever queued -- a call made while
+ * that many are in flight first waits (on the host) for the oldest one's back end, whose ring space it reuses.
+ * n_frames is a host pointer and is valid on return (frame counts are closed-form in n_in).
  * STREAM CONTRACT.  Outputs are written by work queued on pmr_chain_stream().  d_iq is read by the front end, which
  * pipelined calls queue on a SECOND, internal stream that does not wait for pmr_chain_stream() or the null stream:
  *   - d_iq must be complete when the call is made, OR the caller records an event behind its producer and hands it over with

@@ -601,7 +601,8 @@ static void read_switches(pmr_switches *w)
     { const char *e = getenv("PMR_FIR_TPW"); w->fir_tpw = e ? atoi(e) : 2; }
     w->fir_nodual = env_is("PMR_FIR_DUAL", "0");
     w->no_overlap = env_is("PMR_OVERLAP", "0");
-    w->equal_prio = env_is("PMR_STREAM_PRIO", "0");
+    w->be_prio = env_is("PMR_STREAM_PRIO", "1");
+    w->host_gate = !env_is("PMR_HOST_GATE", "0");
 }
 
 static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only);
@@ -636,13 +637,12 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
     }
     q->M = cfg->num_channels;
     pmr_design_buffer_sizes(&q->d, cfg->max_block, &q->res_size, &q->chan_size);
-    /* The back end gets the higher stream priority: its kernels are short and their workgroups are bulky (77 KB / 45 KB
-     * of LDS), so at equal priority they starve behind the front end's 36 KB tiles and the whole pipeline runs at the
-     * back end's (contended) pace.  With priority they run at nearly their isolated speed and the front end -- the
-     * longer kernel -- fills every CU slot they leave. */
+    /* Stream priorities: equal by default.  Round 1 gave the back end the higher priority (its kernels then were bulky: 77 KB /
+     * 45 KB of LDS per workgroup, and starved behind the front end's tiles).  With round 2's kernels that is neutral at cfg2 /
+     * cfg3 and costs 3.6 % at cfg5 (425 vs 440 GS/s, tools/env_ab.sh): PMR_STREAM_PRIO=1 restores it for A/B runs. */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       /* numerically lower = higher priority */
-    if (q->sw.equal_prio) prio_hi = prio_lo;
+    if (!q->sw.be_prio) prio_hi = prio_lo;
     if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_lo) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
@@ -1230,7 +1230,13 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
             HIPCHK(hipEventRecord(q->ev_switch, q->stream), "record");
             HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_switch, 0), "wait single-stream calls");
         }
-        if (q->n_calls >= PIPE_DEPTH) HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
+        if (q->n_calls >= PIPE_DEPTH) {
+            /* ring reuse: the back end of block n - PIPE_DEPTH must be done.  The HOST waits for it (back-pressure: at most
+             * PIPE_DEPTH blocks are ever queued) -- a wait packet on the front-end stream instead (PMR_HOST_GATE=0) sits between
+             * two front-end launches and costs 3 % at cfg5 (439 vs 454 GS/s, tools/env_ab.sh) */
+            if (q->sw.host_gate) HIPCHK(hipEventSynchronize(q->ev_be[par]), "wait back end");
+            else HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
+        }
     }
     q->last_single = single;
     if (q->has_input_ready) {                    /* the caller's producer of d_iq finishes first (pmr_chain_wait_input_event) */

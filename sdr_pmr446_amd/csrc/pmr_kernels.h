@@ -32,7 +32,8 @@ typedef struct {
     int fir_tpw;            /* PMR_FIR_TPW=1: one tile per workgroup in the MFMA FIR (default 2)            */
     int fir_nodual;         /* PMR_FIR_DUAL=0: CTCSS low-pass branch in a FIR pass of its own                */
     int no_overlap;         /* PMR_OVERLAP=0                                                                */
-    int equal_prio;         /* PMR_STREAM_PRIO=0                                                            */
+    int be_prio;            /* PMR_STREAM_PRIO=1: back-end stream at the higher priority (round-1 default)  */
+    int host_gate;          /* default on; PMR_HOST_GATE=0: ring-reuse gating by a wait packet on the front-end stream */
 } pmr_switches;
 
 #define PMR_DC_TILE 4096u       /* raw samples per dc-block tile (256 threads x 16) */

@@ -52,7 +52,7 @@ VARIANTS = [
     ({"PMR_FIR_MFMA": "global"}, CFG2),
     ({"PMR_FIR_TPW": "1"}, CFG2),
     ({"PMR_FIR_DUAL": "0"}, CFG2),
-    ({"PMR_OVERLAP": "0", "PMR_STREAM_PRIO": "0"}, CFG2),
+    ({"PMR_OVERLAP": "0", "PMR_STREAM_PRIO": "1"}, CFG2),
 ]
 
 
