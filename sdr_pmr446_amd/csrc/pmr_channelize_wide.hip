@@ -81,16 +81,18 @@ __global__ __launch_bounds__(256) void k_pfb_wide(pmr_chan_params q, unsigned lo
         if (r0 + f < nrows) Xg[(size_t)(r0 + f) * M + c] = acc[f];
 }
 
-// M-point forward FFTs of FPW rows, radix-4 Stockham (natural order in and out), ping-pong between two LDS arrays.
-//   pass Ns = 1, 4, 16, ...:  butterfly j of an FFT reads in[j + r M/4] (r = 0..3), multiplies by W_{4 Ns}^{r (j mod Ns)}, takes the
-//   4-point DFT and writes out[(j / Ns) 4 Ns + (j mod Ns) + r Ns].
+// M-point forward FFTs of FPW rows, radix-4 Stockham (natural order in and out), IN PLACE in one LDS array: a pass reads its
+// butterflies' inputs into registers, the workgroup synchronises, then the outputs go back to the same array (two barriers per
+// pass, half the LDS of a ping-pong pair: 20 KB at M = 1024, so the kernel co-resides with the front end's tiles).
+//   pass Ns = 1, 4, 16, ...:  butterfly j of an FFT reads x[j + r M/4] (r = 0..3), multiplies by W_{4 Ns}^{r (j mod Ns)}, takes the
+//   4-point DFT and writes x[(j / Ns) 4 Ns + (j mod Ns) + r Ns].
 template <int M, int FPW>
 __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *__restrict__ Xg)
 {
     constexpr int NB = FPW * (M / 4), NPT = NB / 256;            // butterflies per pass; per thread
     static_assert(NB % 256 == 0 && NPT >= 1, "butterflies must tile the workgroup");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf *A = reinterpret_cast<cf *>(smem), *B = A + FPW * M, *tw = B + FPW * M;      // [FPW][M] x 2, [M/2]
+    cf *A = reinterpret_cast<cf *>(smem), *tw = A + FPW * M;                        // [FPW][M], [M/2]
     const int tid = threadIdx.x;
     const unsigned ns = q.ns;
     const unsigned row0 = blockIdx.x * (FPW - 1);                // first row of Xg this workgroup reads (= previous frame)
@@ -107,27 +109,32 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
         const cf w = tw[i & (M / 2 - 1)];
         return i >= M / 2 ? -w : w;
     };
-    cf *in = A, *out = B;
 #pragma unroll
     for (int Ns = 1; Ns < M; Ns *= 4) {
+        cf y[NPT][4];
 #pragma unroll
         for (int u = 0; u < NPT; u++) {
             const int idx = tid + 256 * u, f = idx / (M / 4), j = idx % (M / 4), k = j & (Ns - 1);
-            const cf *x = in + f * M + j;
+            const cf *x = A + f * M + j;
             cf v0 = x[0], v1 = x[M / 4], v2 = x[M / 2], v3 = x[3 * M / 4];
             if (Ns > 1) {
                 const int ti = k * (M / (4 * Ns));
                 v1 = cmul(v1, twid(ti)); v2 = cmul(v2, twid(2 * ti)); v3 = cmul(v3, twid(3 * ti));
             }
             const cf t0 = v0 + v2, t1 = v0 - v2, t2 = v1 + v3, d = v1 - v3, t3 = cfm(d.y, -d.x);     // t3 = -j (v1 - v3)
-            cf *y = out + f * M + (j - k) * 4 + k;
-            y[0] = t0 + t2; y[Ns] = t1 + t3; y[2 * Ns] = t0 - t2; y[3 * Ns] = t1 - t3;
+            y[u][0] = t0 + t2; y[u][1] = t1 + t3; y[u][2] = t0 - t2; y[u][3] = t1 - t3;
+        }
+        __syncthreads();                                          // every butterfly of the pass holds its inputs
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int idx = tid + 256 * u, f = idx / (M / 4), j = idx % (M / 4), k = j & (Ns - 1);
+            cf *o = A + f * M + (j - k) * 4 + k;
+            o[0] = y[u][0]; o[Ns] = y[u][1]; o[2 * Ns] = y[u][2]; o[3 * Ns] = y[u][3];
         }
         __syncthreads();
-        cf *tmp = in; in = out; out = tmp;
     }
     // ---- discriminator (:881) m = arg(conj(prev) cur) / (2 pi kf) for the new frames, tap-off, RSSI partial sums ----
-    const cf *Y = in;
+    const cf *Y = A;
     cf *__restrict__ chan_out = (cf *)q.chan_out;
     const unsigned nnew = nrow - 1;
     for (unsigned wi = tid; wi < nnew * M; wi += 256) {
@@ -153,7 +160,7 @@ static int launch_fft_disc(hipStream_t st, const pmr_chan_params *p, const cf *X
 {
     const unsigned ntiles = (p->ns + FPW - 2) / (FPW - 1);
     if (ntiles_out) *ntiles_out = ntiles;
-    const size_t lds = ((size_t)2 * FPW * M + M / 2) * sizeof(cf);
+    const size_t lds = ((size_t)FPW * M + M / 2) * sizeof(cf);
     static unsigned long long attr_set = 0;
     int dev = 0;
     if (lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(attr_set >> dev & 1ull)) {

@@ -98,6 +98,41 @@ static __device__ __forceinline__ void hb_stage_pp(const cf *__restrict__ src, c
     __syncthreads();
 }
 
+// the same stage IN PLACE: read window -> barrier -> write over the input -> barrier.  Two barriers instead of one, half the LDS
+// (a level-2 tile then fits beside four level-1 tiles on a CU).
+template <int P, int MM>
+static __device__ __forceinline__ void hb_stage_ip(cf *__restrict__ buf, int tid, int n_threads, const float *h1, float scale)
+{
+    constexpr int NE = P + 2 * MM - 1, G = 2 * P;
+    cf y[P];
+    if (tid < n_threads) {
+        const cf *w = buf + tid * (G + 1);
+        cf we[NE], wd[P];
+#pragma unroll
+        for (int i = 0; i < NE; i++) we[i] = w[loff<G>(2 * i - (4 * MM - 2))];
+#pragma unroll
+        for (int p = 0; p < P; p++) wd[p] = w[loff<G>(2 * p + 1 - 2 * MM)];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            cf a = cfm(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 2 * MM; j++) a = cfma(h1[j], we[p + j], a);
+            y[p] = cadd_scale(wd[p], a, scale);
+        }
+    }
+    __syncthreads();
+    if (tid < n_threads) {
+        if constexpr (P >= 2) {
+            cf *o = buf + tid * (P + 1);               // L(P)
+#pragma unroll
+            for (int p = 0; p < P; p++) o[p] = y[p];
+        } else {
+            buf[tid + (tid >> 1)] = y[0];              // L(2)
+        }
+    }
+    __syncthreads();
+}
+
 // Resampler bookkeeping of one tile (wave-uniform): the tile owns decimated samples [qa, qb) and therefore the resampler
 // outputs j in [ja, jb) whose input index (phi0 + j*step) >> 24 falls in that range (resamp_crcf phase rule).
 struct fe_jrange { unsigned long long ja, jb; };

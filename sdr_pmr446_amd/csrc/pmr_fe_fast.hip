@@ -572,13 +572,12 @@ __global__ __launch_bounds__(256, 4) void k_fe_persist(pmr_fe_params p)
 // already fixed the last few in place: index >= fix_limit); it is subtracted here while loading.  A tile starts at a multiple
 // of 4 in absolute ring index, so samples are loaded as 16-byte pairs.  1/16 of the raw rate flows through here (cfg5).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void k_fe_level2(pmr_fe_params p)
+__global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = 256, N0 = 2048;
-    constexpr int R1_OFF = N0 + N0 / 8;                    // input (layout L(8)) fills [0, R1_OFF); z1 (1024, L(4)) behind it
-    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
-    cf *R0 = buf, *R1 = buf + R1_OFF;
+    constexpr int NT = 256;                                // 2048 ring samples per tile
+    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;       // input (layout L(8)), then z1 (L(4)), then z2 (L(2)), all in place
+    cf *R0 = buf;
     const int tid = threadIdx.x;
     const int c = blockIdx.x;
     const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // index of tile sample 0 among this call's new ring samples
@@ -629,8 +628,8 @@ __global__ __launch_bounds__(256, 4) void k_fe_level2(pmr_fe_params p)
         }
     }
     __syncthreads();
-    hb_stage_pp<4, 5>(R0, R1, tid, NT, p.taps_k, 1.0f);                    // 1024 outputs, L(8) -> L(4)
-    hb_stage_pp<2, 10>(R1, R0, tid, NT, p.taps_k + 10, p.zeta);            //  512 outputs, L(4) -> L(2)
+    hb_stage_ip<4, 5>(R0, tid, NT, p.taps_k, 1.0f);                        // 1024 outputs, L(8) -> L(4), in place
+    hb_stage_ip<2, 10>(R0, tid, NT, p.taps_k + 10, p.zeta);                //  512 outputs, L(4) -> L(2), in place
     fe_arb_store<NT, 1>(p, ap, qa, R0, bk0, bk1, tid);
 }
 
@@ -689,7 +688,7 @@ extern "C" int pmr_launch_fe_persist(pmr_stream_t s, const pmr_fe_params *p, uns
 extern "C" int pmr_launch_fe_level2_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles)
 {
     if (!ntiles) return 0;
-    const size_t lds = (FE_PAD + (2048 + 256) + (1024 + 256)) * sizeof(cf);
+    const size_t lds = (FE_PAD + (2048 + 256)) * sizeof(cf);          /* 18.9 KB: the stages run in place */
     hipLaunchKernelGGL(k_fe_level2, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p);
     return (int)hipGetLastError();
 }
