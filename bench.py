@@ -37,6 +37,7 @@ WORKLOADS = {
     "cfg5": (1.0e9, 1024, 26, 4),    # 1024-ch channelizer + demod @ 1 GS/s -- HBM-roofline config
 }
 HEADLINE = "cfg5"
+EVENT_EVERY = 8        # timed region: every 8th front-end launch carries start/stop events
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 KERNEL_SYMBOLS = ("slot k_frontend = k_frontend_fast<MODE,N3,TAIL> (specialised cascades; MODE 1 = level 1 of the two-level "
                   "front end) or k_frontend<NT,SPT,MODE> in a rocprofv3 trace; k_fir_tm<hp> = k_fir_mfma16<...>")
@@ -223,9 +224,11 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
         step()
     ch.synchronize()
     ch.profile_reset()
-    # HIP events in the timed region only around the roofline kernel (k_frontend): event records around all
-    # kernels of a step cost 6-16 % of the step time (measured); the full per-kernel breakdown is taken right after
-    ch.profile_enable(0 if args.no_kernel_events else 2)
+    # HIP events in the timed region only on the roofline kernel (the front end), as start/stop events its launch carries
+    # (the kernel's own begin..end) on every EVENT_EVERY-th launch: event RECORDS around every front-end launch are two
+    # marker packets on the critical stream and cost 11 % of the step (cfg5: 0.146 vs 0.132 ms, tools/steps_ab.sh);
+    # the full per-kernel breakdown is taken right after, outside the timed region
+    ch.profile_enable(0 if args.no_kernel_events else 1 + EVENT_EVERY)
 
     def run():
         n = 0
@@ -279,6 +282,7 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": load_measured_traffic(name, block),
                     "avg_kernel_ms": ms / n, "launches_timed": n, "launches_per_step": launches_per_step,
+                    "events": "start/stop events carried by every %d-th launch of the kernel inside the timed regions" % EVENT_EVERY,
                     "algorithmic_bytes_per_sample": b_alg, "algorithmic_bytes_per_launch": b_alg * block,
                     "kernel_symbols": KERNEL_SYMBOLS,
                     "kernels_ms_per_step_isolated": {k: v[0] / max(1, breakdown_steps) for k, v in sorted(prof.items())}}
@@ -385,7 +389,8 @@ def host_io(ch, iq, block, M, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200, help="blocks per timed region (three blocks are in flight: a region "
+                    "pays one pipeline fill/drain of ~0.17 ms, 6 % of a 20-step region)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--also", default=None, help="comma list of further workloads reported as sub-records "

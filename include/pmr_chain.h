@@ -137,7 +137,10 @@ int   pmr_chain_set_overlap(pmr_chain q, int on);
 void *pmr_chain_stream(pmr_chain q);                       /* hipStream_t the kernels are launched on   */
 
 /* ---- measurement hooks (bench.py): HIP-event time of every kernel launched by this handle ---- */
-int         pmr_chain_profile_enable(pmr_chain q, int mode);   /* 0 off, 1 every kernel, 2 only the front-end kernel */
+/* mode 0 off; 1 every kernel (event records around each launch: ~7 us of marker packets per launch, for un-pipelined breakdown
+ * passes); m >= 2 only the front-end kernel, every (m-1)-th launch, by start/stop events the launch itself carries
+ * (hipExtLaunchKernel: the kernel's own begin..end, ~5 us per sampled launch and nothing on the others) */
+int         pmr_chain_profile_enable(pmr_chain q, int mode);
 int         pmr_chain_profile_reset(pmr_chain q);
 unsigned    pmr_chain_profile_count(pmr_chain q);                          /* number of distinct kernels   */
 const char *pmr_chain_profile_name(pmr_chain q, unsigned i);

@@ -515,7 +515,7 @@ class PmrChain:
 
     # -- measurement / introspection -------------------------------------------------------------
     def profile_enable(self, mode=1):
-        """0 off, 1 every kernel, 2 only the front-end (roofline) kernel."""
+        """0 off, 1 every kernel, m >= 2 only the front-end (roofline) kernel, every (m-1)-th launch (include/pmr_chain.h)."""
         self._check(self._L.pmr_chain_profile_enable(self.h, int(mode)))
 
     def profile_reset(self):

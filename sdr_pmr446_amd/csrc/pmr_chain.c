@@ -135,7 +135,9 @@ struct pmr_chain_s {
     int dbg_on; cfl *d_dbg_xr; float *d_dbg_fm, *d_dbg_ct;
 
     /* profiling */
-    int prof_on;
+    int prof_on; unsigned prof_tick;
+    hipEvent_t fe_done_ev; int fe_done_used;   /* event the front-end stream's LAST launch of this call signals itself (pipelined
+                                                  calls: ev_fe[par]) and whether a launch took it */
     double prof_ms[PROF_SLOTS]; unsigned prof_n[PROF_SLOTS];
     prof_pending *pend; unsigned npend, cappend;
     hipEvent_t *pool; unsigned npool, cappool;
@@ -190,7 +192,7 @@ static void prof_begin(pmr_chain q, int slot, prof_pending *pp, hipStream_t st)
 {
     pp->slot = -1;
     if (!q->prof_on) return;
-    if (q->prof_on == 2 && slot != K_FE) return;          /* mode 2: only the front-end (roofline) kernel */
+    if (q->prof_on >= 2) return;          /* modes >= 2: only the front-end (roofline) kernel, by events its launch carries */
     hipEvent_t ev[2];
     for (int i = 0; i < 2; i++) {
         if (q->npool) ev[i] = q->pool[--q->npool];
@@ -200,10 +202,9 @@ static void prof_begin(pmr_chain q, int slot, prof_pending *pp, hipStream_t st)
     hipEventRecord(pp->a, st);
 }
 
-static void prof_end(pmr_chain q, prof_pending *pp, hipStream_t st)
+static void prof_push(pmr_chain q, const prof_pending *pp)
 {
     if (pp->slot < 0) return;
-    hipEventRecord(pp->b, st);
     if (q->npend == q->cappend) {
         unsigned nc = q->cappend ? 2 * q->cappend : 256;
         prof_pending *np = (prof_pending *)realloc(q->pend, nc * sizeof(*np));
@@ -211,6 +212,34 @@ static void prof_end(pmr_chain q, prof_pending *pp, hipStream_t st)
         q->pend = np; q->cappend = nc;
     }
     q->pend[q->npend++] = *pp;
+}
+
+static void prof_end(pmr_chain q, prof_pending *pp, hipStream_t st)
+{
+    if (pp->slot < 0) return;
+    hipEventRecord(pp->b, st);
+    prof_push(q, pp);
+}
+
+/* Events a front-end launch carries itself (pmr_launch_events: no packets of their own on the stream).
+ *  - profile mode m >= 2: every (m-1)-th launch of the front-end kernel takes a start/stop pair (kernel begin..end);
+ *  - otherwise the launch that is the front-end stream's last of this call signals "front end done" (fe_done_ev). */
+static void fe_launch_events(pmr_chain q, int slot, int last_on_stream, pmr_launch_events *ev, prof_pending *pp)
+{
+    ev->start = ev->stop = NULL;
+    pp->slot = -1;
+    if (q->prof_on == 1) return;                          /* mode 1 brackets every launch with records (LAUNCH_ON) */
+    if (q->prof_on >= 2 && slot == K_FE && q->prof_tick++ % (unsigned)(q->prof_on - 1) == 0) {
+        hipEvent_t e[2];
+        for (int i = 0; i < 2; i++) {
+            if (q->npool) e[i] = q->pool[--q->npool];
+            else if (hipEventCreate(&e[i]) != hipSuccess) return;
+        }
+        pp->a = e[0]; pp->b = e[1]; pp->slot = slot;
+        ev->start = e[0]; ev->stop = e[1];
+        return;
+    }
+    if (last_on_stream && q->fe_done_ev) { ev->stop = q->fe_done_ev; q->fe_done_used = 1; }
 }
 
 static void prof_resolve(pmr_chain q)
@@ -603,6 +632,7 @@ static void read_switches(pmr_switches *w)
     w->no_overlap = env_is("PMR_OVERLAP", "0");
     w->be_prio = env_is("PMR_STREAM_PRIO", "1");
     w->host_gate = !env_is("PMR_HOST_GATE", "0");
+    w->fe_marker = env_is("PMR_FE_EVENT", "marker");
 }
 
 static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only);
@@ -942,7 +972,10 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
             q->fe_ticket_base[xc] += tiles_x + (nwg + 7 - xc) / 8;
         }
     } else {
-        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic));
+        pmr_launch_events ev; prof_pending pe;
+        fe_launch_events(q, K_FE, 0, &ev, &pe);
+        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic, &ev));
+        prof_push(q, &pe);
     }
 
     pmr_fe_fix_params f;
@@ -951,7 +984,11 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
     f.Kgain = q->fe_Kgain;
     /* persistent kernel: only the tiles it flagged (carry not available in time) are corrected here -- normally none */
-    LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, q->fe_persist ? q->d_fe_fixflag : NULL));
+    {
+        pmr_launch_events ev; prof_pending pe;
+        fe_launch_events(q, K_FE_TILEFIX, t.ntiles != 0, &ev, &pe);
+        LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, q->fe_persist ? q->d_fe_fixflag : NULL, &ev));
+    }
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
     *ny_out = ny;
@@ -999,7 +1036,13 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     p.dc_a1 = d->dc_a1; p.zeta = 1.0f; p.lam_wave = q->fe_lam_wave;
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     fe_fill_taps(q, &p, 0, s1);
-    LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles1, 256, 16, q->sw.fe_generic));
+    {
+        /* with level 2 deferred to the back-end stream, level 1 is the front-end stream's last launch of this call */
+        pmr_launch_events ev; prof_pending pe;
+        fe_launch_events(q, K_FE, q->l2_on_backend && ntiles1 != 0, &ev, &pe);
+        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles1, 256, 16, q->sw.fe_generic, &ev));
+        prof_push(q, &pe);
+    }
 
     /* ---- carries of level 1 + in-place fix of the ring tail: the last `keep` new samples are what the NEXT call's level 2
      * re-reads as history; level 2 of THIS call skips them (fix_limit) and corrects everything before them at load ---- */
@@ -1056,6 +1099,7 @@ int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsig
     const int keep_l2 = q->l2_on_backend;
     q->l2_on_backend = 0;                         /* this entry point has no back-end stream: everything on stream_fe */
     q->sfe = q->stream_fe;
+    q->fe_done_ev = NULL; q->fe_done_used = 0;
     int rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                        : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny);
     q->l2_on_backend = keep_l2;
@@ -1245,10 +1289,14 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     }
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
+    q->fe_done_ev = (single || q->sw.fe_marker) ? NULL : q->ev_fe[par];
+    q->fe_done_used = 0;
     if ((rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                         : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny))) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
-    if (!single) HIPCHK(hipEventRecord(q->ev_fe[par], q->stream_fe), "record");
+    /* "front end of this block finished": the completion signal of the front-end stream's last launch where that launch could
+     * carry it, a record packet otherwise (staged kernels, level 2 on the front-end stream, empty blocks, profiled launches) */
+    if (!single && !q->fe_done_used) HIPCHK(hipEventRecord(q->ev_fe[par], q->stream_fe), "record");
     q->n_raw += n_in;
     q->xr_abs += ny;
     q->last_ny = ny;

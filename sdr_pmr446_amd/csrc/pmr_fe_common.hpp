@@ -5,6 +5,7 @@
 #define PMR_FE_COMMON_HPP
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "pmr_kernels.h"
@@ -202,5 +203,15 @@ static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, cons
         out[(p.out_pos0 + j) & p.out_mask] = resamp(j, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
     }
 }
+
+
+// launch with optional per-launch events (pmr_launch_events, pmr_kernels.h)
+#define PMR_LAUNCH_EV(kern, grid, block, lds, st, ev, ...)                                                                        \
+    do {                                                                                                                           \
+        if ((ev) && ((ev)->start || (ev)->stop))                                                                                   \
+            hipExtLaunchKernelGGL(kern, grid, block, (unsigned)(lds), st, (hipEvent_t)(ev)->start, (hipEvent_t)(ev)->stop, 0,      \
+                                  __VA_ARGS__);                                                                                    \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                          \
+    } while (0)
 
 #endif

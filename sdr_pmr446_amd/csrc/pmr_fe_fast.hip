@@ -635,11 +635,11 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
 
 // ---------------------------------------------------------------------------------------------
 template <int MODE, int N3, int TAIL>
-static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
+static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
     const size_t lds = (FE_PAD + 4096 + 4 + 44) * sizeof(cf);
     auto kern = k_fe_fast<MODE, N3, TAIL>;
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), lds, st, *p);
+    PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p);
     return (int)hipGetLastError();
 }
 
@@ -654,21 +654,21 @@ static int fast_pattern(const pmr_fe_params *p, int *n3, int *tail)
     return 0;
 }
 
-extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles)
+extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
     hipStream_t st = (hipStream_t)s;
     int n3 = 0, tail = 0;
     if (!p->taps_valid || !fast_pattern(p, &n3, &tail)) return -1;
     if (p->mode == FE_FULL && tail) {
-        if (n3 == 1) return launch_fast<FE_FULL, 1, 1>(st, p, ntiles);
-        if (n3 == 2) return launch_fast<FE_FULL, 2, 1>(st, p, ntiles);
-        if (n3 == 3) return launch_fast<FE_FULL, 3, 1>(st, p, ntiles);
+        if (n3 == 1) return launch_fast<FE_FULL, 1, 1>(st, p, ntiles, ev);
+        if (n3 == 2) return launch_fast<FE_FULL, 2, 1>(st, p, ntiles, ev);
+        if (n3 == 3) return launch_fast<FE_FULL, 3, 1>(st, p, ntiles, ev);
     }
     if (p->mode == FE_L1 && !tail) {
-        if (n3 == 2) return launch_fast<FE_L1, 2, 0>(st, p, ntiles);
-        if (n3 == 3) return launch_fast<FE_L1, 3, 0>(st, p, ntiles);
-        if (n3 == 4) return launch_fast<FE_L1, 4, 0>(st, p, ntiles);
-        if (n3 == 5) return launch_fast<FE_L1, 5, 0>(st, p, ntiles);
+        if (n3 == 2) return launch_fast<FE_L1, 2, 0>(st, p, ntiles, ev);
+        if (n3 == 3) return launch_fast<FE_L1, 3, 0>(st, p, ntiles, ev);
+        if (n3 == 4) return launch_fast<FE_L1, 4, 0>(st, p, ntiles, ev);
+        if (n3 == 5) return launch_fast<FE_L1, 5, 0>(st, p, ntiles, ev);
     }
     return -1;
 }

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
 
 // ---------------------------------------------------------------------------------------------
 template <int NT, int SPT, int MODE>
-static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned ntiles)
+static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev = nullptr)
 {
     const size_t n0 = (size_t)NT * SPT;
     const size_t lds = (FE_PAD + n0 + n0 / SPT + 32 + 10 * (NT / 64 + 1)) * sizeof(cf);   /* pad + tile + scan scratch + halo exchange */
@@ -547,7 +547,7 @@ static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned nt
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     auto kern = k_frontend<NT, SPT, MODE>;
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), lds, st, *p);
+    PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(NT), lds, st, ev, *p);
     return (int)hipGetLastError();
 }
 
@@ -556,19 +556,20 @@ extern "C" int pmr_launch_fe_level2_fast(pmr_stream_t s, const pmr_fe_params *p,
 /* tile geometries: (threads, samples per thread).  4096-sample tiles as 256 x 16; 16384-sample tiles (cascades too deep
  * for those where the two-level split does not apply) as 1024 x 16.  The specialised kernels of pmr_fe_fast.hip take the
  * cascades they cover unless `generic` is set (PMR_FE_KERNEL=generic).                                               */
-extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt, int generic)
+extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt, int generic,
+                                   const pmr_launch_events *ev)
 {
     if (!ntiles) return 0;
     hipStream_t st = (hipStream_t)s;
     if (!generic && nt == 256 && spt == 16 && (p->mode == FE_FULL || p->mode == FE_L1)) {
-        const int rc = pmr_launch_fe_fast(s, p, ntiles);
+        const int rc = pmr_launch_fe_fast(s, p, ntiles, ev);
         if (rc >= 0) return rc;
     }
-    if (p->mode == FE_L1 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L1>(st, p, ntiles);
-    if (p->mode == FE_L2 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L2>(st, p, ntiles);
+    if (p->mode == FE_L1 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L1>(st, p, ntiles, ev);
+    if (p->mode == FE_L2 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L2>(st, p, ntiles, ev);
     if (p->mode != FE_FULL) return (int)hipErrorInvalidValue;
-    if (nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_FULL>(st, p, ntiles);
-    if (nt == 1024 && spt == 16) return launch_frontend_t<1024, 16, FE_FULL>(st, p, ntiles);
+    if (nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_FULL>(st, p, ntiles, ev);
+    if (nt == 1024 && spt == 16) return launch_frontend_t<1024, 16, FE_FULL>(st, p, ntiles, ev);
     return (int)hipErrorInvalidValue;
 }
 
@@ -588,9 +589,9 @@ extern "C" int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t,
 }
 
 extern "C" int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q,
-                                     const uint8_t *flags)
+                                     const uint8_t *flags, const pmr_launch_events *ev)
 {
     if (!t->ntiles) return 0;
-    hipLaunchKernelGGL(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, *t, *f, n_q, flags);
+    PMR_LAUNCH_EV(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, ev, *t, *f, n_q, flags);
     return (int)hipGetLastError();
 }

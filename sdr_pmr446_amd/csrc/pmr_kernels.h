@@ -34,6 +34,8 @@ typedef struct {
     int no_overlap;         /* PMR_OVERLAP=0                                                                */
     int be_prio;            /* PMR_STREAM_PRIO=1: back-end stream at the higher priority (round-1 default)  */
     int host_gate;          /* default on; PMR_HOST_GATE=0: ring-reuse gating by a wait packet on the front-end stream */
+    int fe_marker;          /* PMR_FE_EVENT=marker: "front end done" as a separate event-record packet (default: the last
+                               front-end launch's own completion signal) */
 } pmr_switches;
 
 #define PMR_DC_TILE 4096u       /* raw samples per dc-block tile (256 threads x 16) */
@@ -218,12 +220,17 @@ typedef struct {
     float Kgain;
 } pmr_fe_fix_params;
 
-int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt, int generic);
+/* A launch can carry its own events (hipExtLaunchKernel): `stop` is the dispatch packet's completion signal -- no packet of its
+ * own on the stream, where hipEventRecord is a marker packet that costs ~3.6 us between two back-to-back kernels -- and
+ * `start` a marker in front (start..stop = the kernel's own begin..end timestamps).  Both nullable hipEvent_t; ev may be NULL. */
+typedef struct { void *start, *stop; } pmr_launch_events;
+int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt, int generic,
+                        const pmr_launch_events *ev);
 /* level 2 of the two-level front end: the specialised k_fe_level2 (m = 5, 10 + resampler, 2048-sample tiles) or the generic
  * k_frontend in mode 2 (4096-sample tiles) */
 int pmr_launch_frontend_l2(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int fast);
 /* specialised kernels of pmr_fe_fast.hip; return -1 when the cascade is not one they cover */
-int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles);
+int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev);
 /* persistent one-level kernel; `nwg` workgroups.  Returns -1 when the cascade is not covered. */
 int pmr_launch_fe_persist(pmr_stream_t s, const pmr_fe_params *p, unsigned nwg);
 /* tile carries of a level-1 launch (V[c], next call's dc state) + in-place dc fix of the ring samples [f->j0, f->ny) */
@@ -231,7 +238,7 @@ int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_
 /* one-level front end, carries + correction of the resampled stream in place, one wave per tile.  `flags` (nullable): only
  * tiles whose flag is set are handled (fallback of the persistent kernel); NULL: every tile */
 int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q,
-                          const uint8_t *flags);
+                          const uint8_t *flags, const pmr_launch_events *ev);
 
 #ifdef __cplusplus
 }
