@@ -122,6 +122,8 @@ struct pmr_chain_s {
     int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_tiles_params pend_t2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     /* persistent one-level kernel (k_fe_persist): ticket counters, published carry records, fallback flags */
+    unsigned fe_last_ntiles;         /* tiles of the last fused front-end launch */
+    int fe_lb;                       /* k_fe_fast<.., LB>: carry applied in-kernel by look-back (default where covered) */
     int fe_persist; unsigned fe_nwg; uint32_t *d_fe_tickets; uint32_t fe_ticket_base[8]; uint64_t *d_fe_prec; uint8_t *d_fe_fixflag;
     uint32_t fe_epoch;
     unsigned fe_max_tiles;
@@ -474,7 +476,24 @@ static int fe_init(pmr_chain q)
      * Correct (parity-tested) and it removes the 90 MB read-modify-write of k_fe_tilefix, but measured SLOWER on MI355X at
      * cfg2 (isolated front end): one tile per workgroup 0.125 ms + k_fe_tilefix 0.024 ms  vs  persistent loop alone 0.150 ms,
      * + carry hand-off 0.186 ms, + ticket atomics 0.243 ms -- so the two-kernel form stays the product. */
-    q->fe_persist = 0;
+    q->fe_persist = 0; q->fe_lb = 0;
+    /* PMR_FE_LOOKBACK=1 (A/B switch, off by default): one tile per workgroup, the tile applies its own dc carry before it stores
+     * its outputs (k_fe_fast<.., LB>: look-back over its predecessors' published records); k_fe_tilefix then only visits the
+     * tiles that raised their flag (the heads of the XCD ranges: 105 of 17 698 at cfg2).  Correct and parity-tested, removes
+     * the read-modify-write of the resampled stream -- and measured SLOWER (profiles/r02_fe_lookback_experiment.txt): the 15
+     * predecessors of a tile run CONCURRENTLY with it (1024 tiles are resident, a block has 16 384), so their records are
+     * read with agent-scope loads that miss L2 by construction, at loaded-HBM latency, late in the tile's life: front end
+     * 0.123 -> 0.198 ms at cfg2. */
+    if (!q->fe_two && nt == 256 && !q->sw.fe_generic && !q->sw.fe_persist && q->sw.fe_lookback && h >= 3 && h <= 5) {
+        int ok = q->fe_m[h - 2] == 5 && q->fe_m[h - 1] == 10;
+        for (unsigned e = 0; e + 2 < h; e++) if (q->fe_m[e] != 3) ok = 0;
+        if (ok) {
+            if ((rc = dev_alloc(q, (void **)&q->d_fe_prec, (size_t)q->fe_max_tiles * 2 * sizeof(uint64_t)))) return rc;
+            if ((rc = dev_alloc(q, (void **)&q->d_fe_fixflag, q->fe_max_tiles))) return rc;
+            q->fe_epoch = 0;
+            q->fe_lb = 1;
+        }
+    }
     if (!q->fe_two && nt == 256 && !q->sw.fe_generic && q->sw.fe_persist && h >= 3 && h <= 5) {
         int ok = q->fe_m[h - 2] == 5 && q->fe_m[h - 1] == 10;
         for (unsigned e = 0; e + 2 < h; e++) if (q->fe_m[e] != 3) ok = 0;
@@ -618,6 +637,7 @@ static void read_switches(pmr_switches *w)
     w->fe_staged = env_is("PMR_FRONTEND", "staged");
     w->fe_generic = env_is("PMR_FE_KERNEL", "generic");
     w->fe_persist = env_is("PMR_FE_PERSIST", "1");
+    w->fe_lookback = env_is("PMR_FE_LOOKBACK", "1");
     { const char *e = getenv("PMR_FE_STAGGER"); w->fe_stagger = e ? atoi(e) : 2; }
     { const char *e = getenv("PMR_FE_LEVELS"); w->fe_levels = e ? atoi(e) : 0; }
     w->l2_on_fe = env_is("PMR_L2_STREAM", "fe");
@@ -972,6 +992,13 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
             q->fe_ticket_base[xc] += tiles_x + (nwg + 7 - xc) / 8;
         }
     } else {
+        if (q->fe_lb) {
+            p.ntiles = ntiles; p.prec = q->d_fe_prec; p.epoch = ++q->fe_epoch; p.fixflag = q->d_fe_fixflag;
+            if (p.epoch == 0) p.epoch = ++q->fe_epoch;        /* 0 is what freshly zeroed records carry */
+            p.v_in = t.v_in; p.v_out = t.v_out; p.rho_pow = t.rho_pow; p.carry_K = t.K; p.rho = t.rho; p.lamHh = t.lamHh;
+            p.inv_lamHh = t.inv_lamHh; p.inv_lamL = t.inv_lamL; p.lamEnd = t.lamEnd;
+            p.GA = q->d_fe_GA; p.T1 = q->d_fe_T1; p.T2 = q->d_fe_T2; p.Kgain = q->fe_Kgain;
+        }
         pmr_launch_events ev; prof_pending pe;
         fe_launch_events(q, K_FE, 0, &ev, &pe);
         LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic, &ev));
@@ -987,8 +1014,9 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     {
         pmr_launch_events ev; prof_pending pe;
         fe_launch_events(q, K_FE_TILEFIX, t.ntiles != 0, &ev, &pe);
-        LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, q->fe_persist ? q->d_fe_fixflag : NULL, &ev));
+        LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, (q->fe_persist || q->fe_lb) ? q->d_fe_fixflag : NULL, &ev));
     }
+    q->fe_last_ntiles = ntiles;
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
     *ny_out = ny;
@@ -1625,6 +1653,26 @@ int pmr_chain_set_overlap(pmr_chain q, int on)
     int rc = pmr_chain_synchronize(q);
     q->overlap = on ? 1 : 0;
     return rc;
+}
+
+int pmr_chain_fe_fallback_tiles(pmr_chain q, unsigned *flagged, unsigned *tiles)
+{
+    if (!q) return PMR_EINVAL;
+    if (flagged) *flagged = 0;
+    if (tiles) *tiles = 0;
+    if (!(q->fe_lb || q->fe_persist) || !q->fe_last_ntiles) return PMR_OK;
+    int rc = pmr_chain_synchronize(q);
+    if (rc) return rc;
+    uint8_t *h = (uint8_t *)malloc(q->fe_last_ntiles);
+    if (!h) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
+    const hipError_t e = hipMemcpy(h, q->d_fe_fixflag, q->fe_last_ntiles, hipMemcpyDeviceToHost);
+    unsigned n = 0;
+    for (unsigned i = 0; i < q->fe_last_ntiles; i++) n += h[i] != 0;
+    free(h);
+    if (e != hipSuccess) return fail(q, PMR_EHIP, "hipMemcpy", e);
+    if (flagged) *flagged = n;
+    if (tiles) *tiles = q->fe_last_ntiles;
+    return PMR_OK;
 }
 
 int pmr_chain_profile_reset(pmr_chain q)

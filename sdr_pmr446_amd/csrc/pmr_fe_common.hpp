@@ -174,17 +174,25 @@ static __device__ __forceinline__ fe_arb_plan fe_arb_prepare(const pmr_fe_params
     return a;
 }
 
-template <int NT, int GS>
+// FIX: the tile's dc carry (Vr, Vi) is known -- every output leaves corrected, y - V * K * GA[branch] * mu^q' (the expression and
+// its rounding are k_fe_tilefix's: a tile corrected here and one corrected there agree bit for bit).
+template <int NT, int GS, bool FIX = false>
 static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, const fe_arb_plan &a, unsigned long long qa,
-                                                    const cf *fin, const float (&bk0)[14], const float (&bk1)[14], int tid)
+                                                    const cf *fin, const float (&bk0)[14], const float (&bk1)[14], int tid,
+                                                    float Vr = 0.f, float Vi = 0.f)
 {
     cf *__restrict__ out = (cf *)p.out;
     const auto resamp = [&](unsigned long long j, const float *bk) {
         const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
-        const int ql = (int)((ph >> 24) - qa) + p.HhQ - 13;
+        const int qd = (int)((ph >> 24) - qa) + p.HhQ;                            // tile-local decimated index
+        const int ql = qd - 13;
         cf y = cfm(0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 14; k++) y = cfma(bk[k], fin[(ql + k) + ((ql + k) >> GS)], y);
+        if constexpr (FIX) {
+            const float u = p.Kgain * (p.GA[(unsigned)(ph & 0xffffffu) >> 16] * (p.T1[qd >> 5] * p.T2[qd & 31]));
+            y = cfm(fmaf(-Vr, u, y.x), fmaf(-Vi, u, y.y));
+        }
         return y;
     };
     if (a.pairs && a.j0 + 1 < a.jb) {

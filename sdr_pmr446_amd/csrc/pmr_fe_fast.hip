@@ -34,9 +34,29 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // slot of 16-byte chunk g (and chunk of slot g: the map is an involution)
 static __device__ __forceinline__ int fe_swz(int g) { return (g & ~7) | ((g & 7) ^ ((g >> 4) & 7)); }
 
-template <int MODE, int N3, int TAIL>
+// a tile's published carry record: 8-byte {value, epoch} granules, agent-scope relaxed atomics (see k_fe_persist below)
+static __device__ __forceinline__ void fe_publish(uint64_t *rec, float v, uint32_t epoch)
+{
+    __hip_atomic_store(rec, (uint64_t)__builtin_bit_cast(uint32_t, v) | ((uint64_t)epoch << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifndef FEP_SPINS
+#define FEP_SPINS 48        /* bounded wait for a predecessor's record: 48 x s_sleep(16) ~ 20 us, then the tile falls back */
+#endif
+
+// LB ("look-back", FE_FULL only): the tile applies its OWN dc carry to its outputs before they are stored, so no pass over the
+// resampled stream follows.  The carry V_c = (W_c - A_c) lambda^-Hh, W_c = sum_{k=1..K} rho^(k-1) P_{c-k}, needs the records
+// P = probeB - rho probeA of the K ~ 15 preceding tiles, and each of those is known as soon as ITS tile has run its dc scan
+// (phase B) -- there is no chain.  Tiles are dealt to the XCDs in contiguous ranges (below), workgroups of an XCD start in
+// blockIdx order, so a tile's predecessors were started just before it on the same XCD and have published by the time this
+// tile reaches its last stage (the records are requested before the m = 5 stage and summed before the m = 10 stage).
+// Correctness never depends on that timing: the wait is bounded; a tile whose records did not arrive (and the first K tiles of
+// an XCD's range, whose predecessors run at the END of another XCD's range) stores its outputs uncorrected and raises its
+// flag, and k_fe_tilefix(flags) corrects exactly those tiles from the probes -- in the same arithmetic, bit for bit.
+template <int MODE, int N3, int TAIL, bool LB = false>
 __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 {
+    static_assert(!LB || (MODE == FE_FULL && TAIL == 1), "look-back is for the one-level kernels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256, SPT = 16, N0 = NT * SPT;
     constexpr int H = N3 + 2 * TAIL;
@@ -45,7 +65,9 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     // R1 (z2, 1280 slots) | scan scratch] = 33.6 KB -> four tiles per CU
     cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
     cf *wagg = buf + N0;
-    cf *bnd = wagg + NT / 64;
+    cf *bnd = wagg + NT / 64;                                 // [4][10]
+    cf *pr = bnd + 40;                                        // LB: [2] probes A, B of this tile
+    float *sV = reinterpret_cast<float *>(pr + 2);            // LB: carry (re, im), [2] = ok
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const cf *__restrict__ x = (const cf *)p.x;
@@ -55,9 +77,13 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     // CONTIGUOUS range of tiles -- a tile's halo is its left neighbour's tail and can then be an L2 hit instead of a second
     // HBM read (PMC: 8 % extra fetch without it).  Placement only affects speed, never results.
     int c = blockIdx.x;
+    bool lb_try = LB;                                      // LB: this tile's predecessors run before it (wave-uniform)
     {
         const int nt_all = gridDim.x, per = nt_all >> 3, main = per << 3;
-        if (c < main) c = (c & 7) * per + (c >> 3);
+        if (c < main) {
+            if (LB && (c & 7) != 0 && (c >> 3) < (int)p.carry_K) lb_try = false;     // head of an XCD's range (not XCD 0's)
+            c = (c & 7) * per + (c >> 3);
+        }
     }
     const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // block-relative index of tile sample 0
 
@@ -141,8 +167,8 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
                 if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = v0;
             }
         }
-        if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;               // local v at tile offset Hh-1
-        if (tid == NT - 1) ((cf *)p.probeB)[c] = v1;                       // local v at tile offset N0-1
+        if (tid == p.Hh / SPT - 1) { ((cf *)p.probeA)[c] = v1; if (LB) pr[0] = v1; }      // local v at tile offset Hh-1
+        if (tid == NT - 1) { ((cf *)p.probeB)[c] = v1; if (LB) pr[1] = v1; }              // local v at tile offset N0-1
         // halo of stage 0: the previous thread's yb[6..15] (lane 0: previous wave's lane 63, through LDS)
         cf W[26];
 #pragma unroll
@@ -154,6 +180,20 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             for (int i = 0; i < 10; i++) bnd[wave * 10 + i] = yb[6 + i];
         }
         __syncthreads();
+        if (LB && tid == 0) {
+            // PUBLISH this tile's record (k_fe_persist's arithmetic): tile 0 folds the previous call's state in, P'_0 = P_0 + rho W_0
+            const cf A = pr[0], B = pr[1];
+            float Pr = fmaf(-p.rho, A.x, B.x), Pi = fmaf(-p.rho, A.y, B.y);
+            if (c == 0) {
+                const cf vs = *(const cf *)p.v_in, pl = *(const cf *)p.probeL;
+                const float V0r = (vs.x - pl.x) * p.inv_lamL, V0i = (vs.y - pl.y) * p.inv_lamL;
+                Pr = fmaf(p.rho, fmaf(p.lamHh, V0r, A.x), Pr); Pi = fmaf(p.rho, fmaf(p.lamHh, V0i, A.y), Pi);
+            }
+#ifndef FEL_NOPUB            /* experiment (results wrong): nothing published */
+            fe_publish(p.prec + 2 * (size_t)c, Pr, p.epoch);
+            fe_publish(p.prec + 2 * (size_t)c + 1, Pi, p.epoch);
+#endif
+        }
         if (lane == 0 && wave > 0) {
 #pragma unroll
             for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * 10 + i];
@@ -181,7 +221,56 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
     if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
     if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
-    if constexpr (TAIL) { FE_STAGE(N3, 5, 6 * N3); FE_STAGE(N3 + 1, 10, 6 * N3 + 10); }
+    // LB, wave 0: lane k-1 fetches the record of tile c - k before the m = 5 stage and the wave sums them before the m = 10
+    // stage, whose barrier publishes the carry to the workgroup
+    uint64_t lb_re = 0, lb_im = 0;
+    const int lbk = lane + 1;
+#ifdef FEL_NOLOAD            /* experiment (results wrong): no record loads */
+    const bool lb_mine = false;
+#else
+    const bool lb_mine = LB && wave == 0 && lb_try && lbk <= (int)p.carry_K && lbk <= c;
+#endif
+    if constexpr (LB) {
+        if (lb_mine) {
+            lb_re = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lb_im = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (TAIL) FE_STAGE(N3, 5, 6 * N3);
+    if constexpr (LB) {
+        if (wave == 0) {
+            bool ok = !lb_mine || ((uint32_t)(lb_re >> 32) == p.epoch && (uint32_t)(lb_im >> 32) == p.epoch);
+            if (lb_try) {
+                for (int spin = 0; spin < FEP_SPINS && !__all(ok); spin++) {   // bounded: a late predecessor costs this tile the fallback
+                    __builtin_amdgcn_s_sleep(16);
+                    if (!ok) {
+                        lb_re = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lb_im = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (uint32_t)(lb_re >> 32) == p.epoch && (uint32_t)(lb_im >> 32) == p.epoch;
+                    }
+                }
+            }
+            const bool all_ok = lb_try && __all(ok);
+            float wr = 0.f, wi = 0.f;
+            if (lb_mine && all_ok) {
+                const float pw = p.rho_pow[lbk - 1];
+                wr = pw * __builtin_bit_cast(float, (uint32_t)lb_re); wi = pw * __builtin_bit_cast(float, (uint32_t)lb_im);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { wr += __shfl_xor(wr, d); wi += __shfl_xor(wi, d); }
+            if (lane == 0) {
+                if (c == 0) {                                  // tile 0: its carry comes from the previous call's state
+                    const cf vs = *(const cf *)p.v_in, pl = *(const cf *)p.probeL;
+                    sV[0] = (vs.x - pl.x) * p.inv_lamL; sV[1] = (vs.y - pl.y) * p.inv_lamL;
+                } else {
+                    const cf A = pr[0];
+                    sV[0] = (wr - A.x) * p.inv_lamHh; sV[1] = (wi - A.y) * p.inv_lamHh;
+                }
+                sV[2] = all_ok ? 1.f : 0.f;
+            }
+        }
+    }
+    if constexpr (TAIL) FE_STAGE(N3 + 1, 10, 6 * N3 + 10);
 #undef FE_STAGE
     constexpr int NLAST = (N0 / 2) >> (H - 1);
     constexpr int PLAST = H == 1 ? 8 : (NLAST >= NT ? NLAST / NT : 1);
@@ -203,6 +292,21 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             *reinterpret_cast<float4 *>(out + ((p.out_pos0 + qa + i) & p.out_mask)) = make_float4(a.x, a.y, b.x, b.y);
         }
         if (((nown - head) & 1) && tid == 0) out[(p.out_pos0 + qa + nown - 1) & p.out_mask] = ld(nown - 1);
+    } else if constexpr (LB) {
+        const bool ok = sV[2] != 0.f;
+        const float Vr = ok ? sV[0] : 0.f, Vi = ok ? sV[1] : 0.f;
+#ifdef FEL_NOFIX             /* experiment (results wrong): outputs stored uncorrected */
+        fe_arb_store<NT, GS, false>(p, ap, qa, fin, bk0, bk1, tid);
+#else
+        fe_arb_store<NT, GS, true>(p, ap, qa, fin, bk0, bk1, tid, Vr, Vi);
+#endif
+        if (tid == 0) {
+            p.fixflag[c] = ok ? 0 : 1;
+            if (ok && c == p.c_end) {                           // dc state handed to the next call
+                const cf pe = *(const cf *)p.probeE;
+                *(cf *)p.v_out = cfm(fmaf(p.lamEnd, Vr, pe.x), fmaf(p.lamEnd, Vi, pe.y));
+            }
+        }
     } else {
         fe_arb_store<NT, GS>(p, ap, qa, fin, bk0, bk1, tid);
     }
@@ -239,11 +343,6 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 // stored uncorrected and flagged, and k_fe_tilefix (launched after every block, one early-exit wave per tile) corrects exactly
 // the flagged tiles from the probes, as before.
 // ---------------------------------------------------------------------------------------------
-static __device__ __forceinline__ void fe_publish(uint64_t *rec, float v, uint32_t epoch)
-{
-    __hip_atomic_store(rec, (uint64_t)__builtin_bit_cast(uint32_t, v) | ((uint64_t)epoch << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int N3>
 __global__ __launch_bounds__(256, 4) void k_fe_persist(pmr_fe_params p)
 {
@@ -319,9 +418,6 @@ __global__ __launch_bounds__(256, 4) void k_fe_persist(pmr_fe_params p)
         const int k = lane + 1;
         const bool mine = k <= (int)p.carry_K && k <= h_c;
         bool ok = !mine || ((uint32_t)(lb_re >> 32) == p.epoch && (uint32_t)(lb_im >> 32) == p.epoch);
-#ifndef FEP_SPINS
-#define FEP_SPINS 48
-#endif
         for (int spin = 0; spin < FEP_SPINS && !__all(ok); spin++) {      // bounded: a late predecessor costs this tile the fallback, nothing more
             __builtin_amdgcn_s_sleep(16);
             if (!ok) {
@@ -634,11 +730,14 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int N3, int TAIL>
+template <int MODE, int N3, int TAIL, bool LB = false>
 static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
-    const size_t lds = (FE_PAD + 4096 + 4 + 44) * sizeof(cf);
-    auto kern = k_fe_fast<MODE, N3, TAIL>;
+#ifndef FE_EXTRA_LDS
+#define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup (8192 -> three tiles per CU instead of four) */
+#endif
+    const size_t lds = (FE_PAD + 4096 + 4 + 44) * sizeof(cf) + FE_EXTRA_LDS;
+    auto kern = k_fe_fast<MODE, N3, TAIL, LB>;
     PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p);
     return (int)hipGetLastError();
 }
@@ -659,6 +758,14 @@ extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsign
     hipStream_t st = (hipStream_t)s;
     int n3 = 0, tail = 0;
     if (!p->taps_valid || !fast_pattern(p, &n3, &tail)) return -1;
+    if (p->prec) {                                            /* look-back records given: carry applied in-kernel */
+        if (p->mode == FE_FULL && tail) {
+            if (n3 == 1) return launch_fast<FE_FULL, 1, 1, true>(st, p, ntiles, ev);
+            if (n3 == 2) return launch_fast<FE_FULL, 2, 1, true>(st, p, ntiles, ev);
+            if (n3 == 3) return launch_fast<FE_FULL, 3, 1, true>(st, p, ntiles, ev);
+        }
+        return (int)hipErrorInvalidValue;                     /* the caller planned on flags only this kernel writes */
+    }
     if (p->mode == FE_FULL && tail) {
         if (n3 == 1) return launch_fast<FE_FULL, 1, 1>(st, p, ntiles, ev);
         if (n3 == 2) return launch_fast<FE_FULL, 2, 1>(st, p, ntiles, ev);

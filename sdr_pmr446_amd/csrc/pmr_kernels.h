@@ -21,6 +21,7 @@ typedef struct {
     int fe_staged;          /* PMR_FRONTEND=staged: one kernel per front-end stage                         */
     int fe_generic;         /* PMR_FE_KERNEL=generic: run-time-parameterised k_frontend                     */
     int fe_persist;         /* PMR_FE_PERSIST=1: persistent one-level kernel, dc carry applied in-kernel      */
+    int fe_lookback;        /* PMR_FE_LOOKBACK=1: one tile per workgroup with the dc carry applied in-kernel (look-back) */
     int fe_stagger;         /* PMR_FE_STAGGER=n: start-up phase shift of the persistent kernel's workgroups  */
     int fe_levels;          /* PMR_FE_LEVELS=1|2: force the one- / two-level front end (0 = automatic)      */
     int l2_on_fe;           /* PMR_L2_STREAM=fe: level 2 on the front-end stream                            */

@@ -114,6 +114,8 @@ CASES = [
     ({"PMR_L2_STREAM": "fe"}, CFG5, RAGGED5, False),
     ({"PMR_FRONTEND": "staged"}, CFG2, RAGGED2, False),
     ({"PMR_FE_PERSIST": "1"}, CFG2, RAGGED2, False),        # in-kernel carry hand-off with blocks in flight
+    ({"PMR_FE_LOOKBACK": "1"}, CFG3, RAGGED3, False),       # look-back carry, fallback flags, blocks in flight
+    ({"PMR_FE_EVENT": "marker"}, CFG2, RAGGED2, False),     # "front end done" as a record packet instead of the launch's own signal
 ]
 
 

@@ -40,6 +40,8 @@ VARIANTS = [
     ({"PMR_FE_KERNEL": "generic"}, CFG2),
     ({"PMR_FE_PERSIST": "1"}, CFG2),
     ({"PMR_FE_PERSIST": "1", "PMR_FE_STAGGER": "0"}, CFG3),
+    ({"PMR_FE_LOOKBACK": "1"}, CFG2),                        # one tile per workgroup, dc carry by in-kernel look-back
+    ({"PMR_FE_LOOKBACK": "1"}, CFG3),
     ({"PMR_FE_LEVELS": "2"}, CFG3),
     ({"PMR_L2_STREAM": "fe"}, CFG5),
     ({"PMR_FE_KERNEL": "generic"}, CFG5),
