@@ -29,7 +29,13 @@ static __device__ __forceinline__ cf cmul(cf a, cf w) { return __builtin_element
 #define PW_F 8          /* frames per (channel, group) work item of the filter bank */
 #define PW_P 26         /* branch taps (2 m, m = 13: reference :437) */
 
-__global__ __launch_bounds__(256) void k_pfb_wide(pmr_chan_params q, unsigned log2M, cf *__restrict__ Xg)
+#ifndef PW_MINB
+#define PW_MINB 4       /* workgroups per CU the register budget allows for: 4 -> <= 128 VGPRs, a wave fits beside four front-end waves on a SIMD */
+#endif
+#ifndef PW_RB
+#define PW_RB 9         /* rows per batch: loads first, then the MACs */
+#endif
+__global__ __launch_bounds__(256, PW_MINB) void k_pfb_wide(pmr_chan_params q, unsigned log2M, cf *__restrict__ Xg)
 {
     const unsigned M = q.M, nrows = q.ns + 1;                    // row r of Xg <-> frame (frame0 - 1 + r)
     const unsigned w = blockIdx.x * 256u + threadIdx.x;
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void k_pfb_wide(pmr_chan_params q, unsigned lo
     // the NCO table has period 2 M (reference :432-434: d theta = -2 pi (M-1)/(2M)), so a thread meets only two factors: one on
     // even rows of its window, one on odd rows
     const cf cs_e = nco_cs[a0 & nco_mask], cs_o = nco_cs[(a0 + M) & nco_mask];
-    constexpr int RB = 11;                                       // rows per batch: loads first, then the MACs
+    constexpr int RB = PW_RB;
 #pragma unroll
     for (int rr0 = 0; rr0 < PW_F + PW_P - 1; rr0 += RB) {
         cf xm[RB];
