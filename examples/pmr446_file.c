@@ -1,9 +1,10 @@
 /* pmr446_file -- headless stand-in for the reference's main() loops on a RECORDED cf32 stream:
  *
- *   pmr446_file chan <in.cf32|-> <out.wav> [fs_in] [num_channels] [channel|-1]
+ *   pmr446_file chan <in.cf32|-> <out.wav> [fs_in] [num_channels] [channel|-1] [waterfall]
  *       the block loop of src/sdr_pmr446.c:788-908: read a chunk (:789) -> pmr_chain_process_block_f32 -> squelch state
  *       machine on the GPU's RSSI (:828-874) -> float32 WAV at 12.5 kHz.  channel >= 0 writes that channel (mono, like
- *       the RtAudio sink :585); -1 writes all channels (multi-channel WAV).
+ *       the RtAudio sink :585); -1 writes all channels (multi-channel WAV).  waterfall = W > 0 (a power of two): the
+ *       reference's waterfall line per block (asgramcf of the resampled stream, :910-915) on stderr, W characters wide.
  *   pmr446_file dsd <in.cf32|-> <out.s16|-> [fs_in]
  *       the loop of src/dsd_in.c:159-179: s16le mono 48 kHz, ready for `dsd -i -`.
  *
@@ -16,7 +17,7 @@
 #include "pmr_dsd.h"
 #include "pmr_io.h"
 
-static int run_chan(const char *in, const char *out, double fs, unsigned M, int only)
+static int run_chan(const char *in, const char *out, double fs, unsigned M, int only, unsigned waterfall)
 {
     pmr_chain_cfg cfg;
     pmr_chain_default_cfg(&cfg);
@@ -32,6 +33,11 @@ static int run_chan(const char *in, const char *out, double fs, unsigned M, int 
     if (!r || !w || !iq || !audio || !rssi || !pcm) { fprintf(stderr, "pmr446_file: cannot open / allocate\n"); return 3; }
     pmr_squelch sq;
     pmr_squelch_init(&sq);
+    float *psd = NULL; char *ascii = NULL;
+    if (waterfall) {                                                                  /* :473-477 */
+        psd = (float *)malloc((size_t)4 * waterfall * sizeof(float)); ascii = (char *)malloc(waterfall + 1);
+        if (!psd || !ascii || pmr_chain_spectrum_enable(q, waterfall)) { fprintf(stderr, "pmr446_file: %s\n", pmr_chain_last_error(q)); return 3; }
+    }
     int n, rc = 0;
     unsigned long blocks = 0, frames = 0;
     while ((n = pmr_iq_reader_read(r, iq, cfg.max_block)) > 0) {                      /* :789 */
@@ -43,11 +49,17 @@ static int run_chan(const char *in, const char *out, double fs, unsigned M, int 
                         sq.active_chan + 1, sq.rssi);
         rc = pmr_wav_writer_write_f32(w, only >= 0 ? audio + (size_t)only * S : audio, ns, S);
         if (rc) break;
+        if (waterfall) {                                                              /* :910-915 */
+            unsigned ntr = 0; float maxval = 0.f, maxfreq = 0.f;
+            if ((rc = pmr_chain_spectrum_read(q, psd, 4 * waterfall, &ntr))) break;
+            pmr_asgram_ascii(psd, waterfall, ntr, -40.0f, 2.0f, ascii, &maxval, &maxfreq);
+            fprintf(stderr, " > %s < pk%5.1fdB [%5.2f] [max SNR: %5.1fdB]\n", ascii, maxval, maxfreq, sq.rssi);
+        }
         blocks++; frames += ns;
     }
     fprintf(stderr, "pmr446_file: %lu blocks, %lu frames per channel\n", blocks, frames);
     pmr_wav_writer_close(w); pmr_iq_reader_close(r); pmr_chain_destroy(q);
-    free(iq); free(audio); free(rssi); free(pcm);
+    free(iq); free(audio); free(rssi); free(pcm); free(psd); free(ascii);
     return rc || n < 0 ? 1 : 0;
 }
 
@@ -80,10 +92,10 @@ int main(int argc, char **argv)
 {
     if (argc >= 4 && !strcmp(argv[1], "chan"))
         return run_chan(argv[2], argv[3], argc > 4 ? atof(argv[4]) : 1024000.0, argc > 5 ? (unsigned)atoi(argv[5]) : 16,
-                        argc > 6 ? atoi(argv[6]) : -1);
+                        argc > 6 ? atoi(argv[6]) : -1, argc > 7 ? (unsigned)atoi(argv[7]) : 0);
     if (argc >= 4 && !strcmp(argv[1], "dsd"))
         return run_dsd(argv[2], argv[3], argc > 4 ? atof(argv[4]) : 1024000.0);
-    fprintf(stderr, "usage: %s chan <in.cf32|-> <out.wav> [fs_in] [num_channels] [channel|-1]\n"
+    fprintf(stderr, "usage: %s chan <in.cf32|-> <out.wav> [fs_in] [num_channels] [channel|-1] [waterfall]\n"
                     "       %s dsd  <in.cf32|-> <out.s16|-> [fs_in]\n", argv[0], argv[0]);
     return 64;
 }

@@ -172,6 +172,18 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on);
  * Synchronises the chain's streams.                                                                       */
 int pmr_chain_ctcss_read(pmr_chain q, pmr_ctcss_event *events, unsigned cap, unsigned *n_events);
 
+/* ---- the waterfall line -- asgramcf of the resampled stream (asgramcf_create(width) +
+ * set_scale(-40, 2) src/sdr_pmr446.c:473-477; asgramcf_write(resamp_buf, ny) + asgramcf_execute per block :911-912).
+ * When enabled every process_block call also averages the periodograms of ITS resampled samples (Hann window of `nfft` samples
+ * every nfft / 2, 4 nfft-point transforms; execute resets liquid's spgram, so blocks are independent). ---- */
+int pmr_chain_spectrum_enable(pmr_chain q, unsigned nfft /* display width: power of two 8..1024; 0 = off */);
+/* PSD in dB of the LAST block: psd_db[4 nfft], bin i <-> frequency (i / (4 nfft) - 0.5) x the resampled rate.  *n_transforms =
+ * periodograms averaged (0: the block had fewer than nfft / 2 resampled samples; psd_db zeroed).  Synchronises. */
+int pmr_chain_spectrum_read(pmr_chain q, float *psd_db, unsigned cap, unsigned *n_transforms);
+/* host: asgramcf_execute's peak search and character mapping; ascii[nfft + 1] (terminated) */
+int pmr_asgram_ascii(const float *psd_db, unsigned nfft, unsigned n_transforms, float ref, float div, char *ascii, float *peakval,
+                     float *peakfreq);
+
 /* ---- channel select + squelch hysteresis on rssi_db (host logic; mirrors find_max_rssi_channel,
  * src/sdr_pmr446.c:668-700, and the proc_scanning / proc_tuned state machine, :828-874) ---- */
 enum { PMR_SCANNING = 0, PMR_TUNED = 1 };

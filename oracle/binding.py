@@ -121,6 +121,12 @@ def lib():
         L.orc_msresamp_rrrf_create.restype = C.c_void_p
         L.orc_msresamp_rrrf_destroy.argtypes = [C.c_void_p]
         L.orc_msresamp_rrrf_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.POINTER(C.c_uint)]
+        L.orc_asgramcf_create.argtypes = [C.c_uint]
+        L.orc_asgramcf_create.restype = C.c_void_p
+        L.orc_asgramcf_destroy.argtypes = [C.c_void_p]
+        L.orc_asgramcf_set_scale.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.orc_asgramcf_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        L.orc_asgramcf_execute.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p]
         _lib = L
     return _lib
 
@@ -305,3 +311,36 @@ class OracleDsd:
         if "fm" in want:
             out["fm"] = fm[:ny.value].copy()
         return out
+
+
+class OracleAsgram:
+    """asgramcf as the reference drives it (src/sdr_pmr446.c:474-476 create + set_scale(-40, 2); :911-912 write the block's
+    resampled samples, execute); see oracle/orc_dsp.h for the restated liquid algorithm."""
+
+    def __init__(self, nfft, ref=-40.0, div=2.0):
+        self.nfft, self.nfftp = int(nfft), 4 * int(nfft)
+        self.h = lib().orc_asgramcf_create(self.nfft)
+        if not self.h:
+            raise RuntimeError("orc_asgramcf_create failed (nfft must be a power of two >= 2)")
+        lib().orc_asgramcf_set_scale(self.h, ref, div)
+
+    def close(self):
+        if self.h:
+            lib().orc_asgramcf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def block(self, resampled):
+        """One loop iteration: write + execute.  Returns dict(ascii, peakval, peakfreq, psd_db[4 nfft])."""
+        x = np.ascontiguousarray(resampled, dtype=np.complex64)
+        lib().orc_asgramcf_write(self.h, x.ctypes.data, len(x))
+        buf = C.create_string_buffer(self.nfft + 1)
+        pv, pf = C.c_float(0), C.c_float(0)
+        psd = np.zeros(self.nfftp, dtype=np.float32)
+        lib().orc_asgramcf_execute(self.h, buf, C.byref(pv), C.byref(pf), psd.ctypes.data)
+        return {"ascii": buf.raw[:self.nfft].decode("ascii"), "peakval": pv.value, "peakfreq": pf.value, "psd_db": psd}

@@ -804,3 +804,124 @@ int orc_cbuffercf_release(orc_cbuffercf *q, unsigned n)
     q->num -= n;
     return 0;
 }
+
+/* ================= spgramcf / asgramcf (see orc_dsp.h) ================= */
+orc_spgramcf *orc_spgramcf_create(unsigned nfft, unsigned window_len, unsigned delay)
+{
+    if (nfft < 2 || window_len == 0 || window_len > nfft || delay == 0) return NULL;
+    orc_fft *fft = orc_fft_create(nfft);
+    if (!fft) return NULL;
+    orc_spgramcf *q = (orc_spgramcf *)calloc(1, sizeof(*q));
+    q->nfft = nfft; q->window_len = window_len; q->delay = delay; q->fft = fft;
+    q->w = (float *)calloc(window_len, sizeof(float));
+    q->buf_time = (cf32 *)calloc(nfft, sizeof(cf32));
+    q->buf_freq = (cf32 *)calloc(nfft, sizeof(cf32));
+    q->psd = (float *)calloc(nfft, sizeof(float));
+    orc_windowcf_init(&q->buffer, window_len);
+    /* liquid_hann(i, wlen) = 0.5 - 0.5 cos(2 pi i / (wlen - 1)), then the scale by window magnitude and FFT size */
+    float g = 0.0f;
+    for (unsigned i = 0; i < window_len; i++) {
+        q->w[i] = 0.5f - 0.5f * cosf((2.0f * (float)M_PI * (float)i) / ((float)(window_len - 1)));
+        g += q->w[i] * q->w[i];
+    }
+    g = (float)M_SQRT2 / (sqrtf(g / (float)window_len) * sqrtf((float)nfft));
+    for (unsigned i = 0; i < window_len; i++) q->w[i] *= g;
+    orc_spgramcf_reset(q);
+    return q;
+}
+
+void orc_spgramcf_destroy(orc_spgramcf *q)
+{
+    if (!q) return;
+    orc_windowcf_free(&q->buffer); orc_fft_destroy(q->fft);
+    free(q->w); free(q->buf_time); free(q->buf_freq); free(q->psd); free(q);
+}
+
+void orc_spgramcf_reset(orc_spgramcf *q)
+{
+    memset(q->buf_time, 0, q->nfft * sizeof(cf32));
+    memset(q->psd, 0, q->nfft * sizeof(float));
+    q->sample_timer = q->delay; q->num_transforms = 0;
+    orc_windowcf_reset(&q->buffer);
+}
+
+static void spgram_step(orc_spgramcf *q)
+{
+    const cf32 *rc = orc_windowcf_read(&q->buffer);
+    for (unsigned i = 0; i < q->window_len; i++) q->buf_time[i] = rc[i] * q->w[i];      /* the rest stays zero (padding) */
+    orc_fft_forward(q->fft, q->buf_time, q->buf_freq);
+    for (unsigned i = 0; i < q->nfft; i++) {
+        const float re = crealf(q->buf_freq[i]), im = cimagf(q->buf_freq[i]);
+        const float v = re * re + im * im;
+        q->psd[i] = q->num_transforms == 0 ? v : q->psd[i] + v;                           /* alpha = 1: plain accumulation */
+    }
+    q->num_transforms++;
+}
+
+void orc_spgramcf_write(orc_spgramcf *q, const cf32 *x, unsigned n)
+{
+    for (unsigned i = 0; i < n; i++) {
+        orc_windowcf_push(&q->buffer, x[i]);
+        if (--q->sample_timer) continue;
+        q->sample_timer = q->delay;
+        spgram_step(q);
+    }
+}
+
+void orc_spgramcf_get_psd(const orc_spgramcf *q, float *psd_db)
+{
+    const float scale = 1.0f / (float)(q->num_transforms ? q->num_transforms : 1);
+    const unsigned h = q->nfft / 2;
+    for (unsigned i = 0; i < q->nfft; i++) {
+        float v = q->psd[(i + h) % q->nfft];
+        if (v < 1e-12f) v = 1e-12f;
+        psd_db[i] = 10.0f * log10f(v * scale);
+    }
+}
+
+orc_asgramcf *orc_asgramcf_create(unsigned nfft)
+{
+    if (nfft < 2) return NULL;
+    orc_asgramcf *q = (orc_asgramcf *)calloc(1, sizeof(*q));
+    q->nfft = nfft; q->p = 4; q->nfftp = nfft * q->p;
+    q->periodogram = orc_spgramcf_create(q->nfftp, nfft, nfft / 2);
+    if (!q->periodogram) { free(q); return NULL; }
+    q->psd = (float *)calloc(q->nfftp, sizeof(float));
+    static const char lc[10] = {' ', '.', ',', '-', '+', '*', '&', 'N', 'M', '#'};
+    q->num_levels = 10;
+    memcpy(q->levelchar, lc, sizeof(lc));
+    orc_asgramcf_set_scale(q, 0.0f, 10.0f);
+    return q;
+}
+
+void orc_asgramcf_destroy(orc_asgramcf *q) { if (!q) return; orc_spgramcf_destroy(q->periodogram); free(q->psd); free(q); }
+
+void orc_asgramcf_set_scale(orc_asgramcf *q, float ref, float div)
+{
+    q->ref = ref; q->div = div;
+    for (unsigned i = 0; i < q->num_levels; i++) q->levels[i] = q->ref + (float)i * q->div;
+}
+
+void orc_asgramcf_write(orc_asgramcf *q, const cf32 *x, unsigned n) { orc_spgramcf_write(q->periodogram, x, n); }
+
+void orc_asgramcf_execute(orc_asgramcf *q, char *ascii, float *peakval, float *peakfreq, float *psd_db_out)
+{
+    if (q->periodogram->num_transforms == 0) {
+        memset(ascii, ' ', q->nfft);
+        *peakval = 0.0f; *peakfreq = 0.0f;
+        if (psd_db_out) for (unsigned i = 0; i < q->nfftp; i++) psd_db_out[i] = 0.0f;
+        orc_spgramcf_reset(q->periodogram);
+        return;
+    }
+    orc_spgramcf_get_psd(q->periodogram, q->psd);
+    orc_spgramcf_reset(q->periodogram);
+    if (psd_db_out) memcpy(psd_db_out, q->psd, q->nfftp * sizeof(float));
+    for (unsigned i = 0; i < q->nfftp; i++)
+        if (i == 0 || q->psd[i] > *peakval) { *peakval = q->psd[i]; *peakfreq = (float)i / (float)q->nfftp - 0.5f; }
+    for (unsigned i = 0; i < q->nfft; i++) {
+        float v = 0.0f;
+        for (unsigned j = 0; j < q->p; j++) { const float x = q->psd[q->p * i + j]; v = (j == 0 || x > v) ? x : v; }
+        ascii[i] = q->levelchar[0];
+        for (unsigned j = 0; j < q->num_levels; j++) if (v > q->levels[j]) ascii[i] = q->levelchar[j];
+    }
+}

@@ -206,4 +206,35 @@ int  orc_cbuffercf_write(orc_cbuffercf *q, const cf32 *v, unsigned n);
 void orc_cbuffercf_read(orc_cbuffercf *q, unsigned n, cf32 **v, unsigned *nread);
 int  orc_cbuffercf_release(orc_cbuffercf *q, unsigned n);
 
+/* ---- spgramcf / asgramcf : the waterfall line of the reference (src/sdr_pmr446.c:473-477 create + set_scale(-40, 2),
+ * :911-912 write(resamp_buf, ny) + execute per block).  liquid-dsp v1.7.0 src/fft/src/spgram.proto.c, asgram.proto.c restated
+ * from knowledge of the library [structure M, window normalisation L]; where confidence < H this restatement DEFINES the
+ * behaviour (SURVEY App. A rule):
+ *   asgram(nfft): display width nfft, transform size nfftp = 4 nfft, spgram(nfftp, HANN, window_len = nfft, delay = nfft / 2);
+ *   spgram: every `delay` pushed samples, FFT of (last window_len samples) * w, zero-padded to nfftp; psd += |X|^2;
+ *           w[i] = hann(i, window_len) * sqrt(2) / (sqrt(sum w^2 / window_len) * sqrt(nfftp));
+ *           get_psd: 10 log10(max(1e-12, psd[(i + nfftp/2) % nfftp] / num_transforms));
+ *   asgram execute: get_psd, spgram reset (accumulators AND window buffer: every call starts from an empty window), peak over the
+ *           nfftp bins, one character per group of 4 bins (the group's maximum against levels ref + k div, " .,-+*&NM#"). ---- */
+typedef struct {
+    unsigned nfft, window_len, delay, sample_timer;
+    unsigned long long num_transforms;
+    float *w; cf32 *buf_time, *buf_freq; float *psd;
+    orc_windowcf buffer; orc_fft *fft;
+} orc_spgramcf;
+orc_spgramcf *orc_spgramcf_create(unsigned nfft, unsigned window_len, unsigned delay);   /* Hann window; nfft a power of two */
+void orc_spgramcf_destroy(orc_spgramcf *q);
+void orc_spgramcf_reset(orc_spgramcf *q);
+void orc_spgramcf_write(orc_spgramcf *q, const cf32 *x, unsigned n);
+void orc_spgramcf_get_psd(const orc_spgramcf *q, float *psd_db /*[nfft]*/);
+
+typedef struct { unsigned nfft, nfftp, p; orc_spgramcf *periodogram; float *psd; float levels[10]; char levelchar[10];
+                 unsigned num_levels; float div, ref; } orc_asgramcf;
+orc_asgramcf *orc_asgramcf_create(unsigned nfft);
+void orc_asgramcf_destroy(orc_asgramcf *q);
+void orc_asgramcf_set_scale(orc_asgramcf *q, float ref, float div);
+void orc_asgramcf_write(orc_asgramcf *q, const cf32 *x, unsigned n);
+/* ascii: nfft characters (no terminator); psd_db_out (nullable): the nfftp PSD values the characters were drawn from */
+void orc_asgramcf_execute(orc_asgramcf *q, char *ascii, float *peakval, float *peakfreq, float *psd_db_out);
+
 #endif

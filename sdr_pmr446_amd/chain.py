@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read",
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
+    "pmr_chain_spectrum_enable", "pmr_chain_spectrum_read", "pmr_asgram_ascii",
     "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read", "pmr_chain_set_channel_mask", "pmr_chain_reset_channel",
     "pmr_chain_submit_block", "pmr_chain_submit_block_fmt", "pmr_chain_collect_block", "pmr_chain_blocks_in_flight", "pmr_chain_max_in_flight",
     "pmr_host_alloc", "pmr_host_free", "pmr_chain_wait_input_event", "pmr_chain_synchronize_input",
@@ -189,6 +190,12 @@ def load(build_if_missing=True):
     L.pmr_chain_ctcss_enable.restype = i
     L.pmr_chain_ctcss_read.argtypes = [vp, vp, u, C.POINTER(u)]
     L.pmr_chain_ctcss_read.restype = i
+    L.pmr_chain_spectrum_enable.argtypes = [vp, u]
+    L.pmr_chain_spectrum_enable.restype = i
+    L.pmr_chain_spectrum_read.argtypes = [vp, vp, u, C.POINTER(u)]
+    L.pmr_chain_spectrum_read.restype = i
+    L.pmr_asgram_ascii.argtypes = [vp, u, u, C.c_float, C.c_float, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.pmr_asgram_ascii.restype = i
     L.pmr_squelch_init.argtypes = [C.POINTER(Squelch)]
     L.pmr_squelch_init.restype = None
     L.pmr_find_max_rssi_channel.argtypes = [vp, u, C.c_uint64, C.POINTER(C.c_float)]
@@ -334,6 +341,17 @@ def cfg_design_dict(cfg):
 
 class PmrError(RuntimeError):
     pass
+
+
+def asgram_ascii(psd_db, nfft, n_transforms, ref=-40.0, div=2.0):
+    """asgramcf_execute's character line + peak (host logic of the library): (ascii, peakval_db, peakfreq)."""
+    psd = np.ascontiguousarray(psd_db, dtype=np.float32)
+    buf = C.create_string_buffer(int(nfft) + 1)
+    pv, pf = C.c_float(0), C.c_float(0)
+    rc = load().pmr_asgram_ascii(psd.ctypes.data, int(nfft), int(n_transforms), ref, div, buf, C.byref(pv), C.byref(pf))
+    if rc:
+        raise RuntimeError("pmr_asgram_ascii rc=%d" % rc)
+    return buf.raw[:int(nfft)].decode("ascii"), pv.value, pf.value
 
 
 class PmrChain:
@@ -514,6 +532,19 @@ class PmrChain:
         n = C.c_uint(0)
         self._check(self._L.pmr_chain_ctcss_read(self.h, ev.ctypes.data, cap, C.byref(n)))
         return ev[:, :n.value].copy()
+
+    # -- waterfall line (reference src/sdr_pmr446.c:473-477, :911-915) -----------------
+    def spectrum_enable(self, nfft):
+        """asgramcf_create(nfft): every following block also yields the averaged periodogram of its resampled samples (0 = off)."""
+        self._check(self._L.pmr_chain_spectrum_enable(self.h, int(nfft)))
+        self._spec_nfft = int(nfft)
+
+    def spectrum_read(self):
+        """(psd_db[4 nfft], n_transforms) of the last block."""
+        psd = np.zeros(4 * self._spec_nfft, dtype=np.float32)
+        n = C.c_uint(0)
+        self._check(self._L.pmr_chain_spectrum_read(self.h, psd.ctypes.data, len(psd), C.byref(n)))
+        return psd, n.value
 
     # -- measurement / introspection -------------------------------------------------------------
     def profile_enable(self, mode=1):

@@ -31,12 +31,12 @@
 typedef struct { float re, im; } cfl;
 
 enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
-       K_FE, K_FE_TILES, K_CHANNELIZE_SMALL, K_FE_L2, K_CT_FIR, K_CT_DC, K_CT_GOERTZEL, K_FE_TILEFIX, K_COUNT };
+       K_FE, K_FE_TILES, K_CHANNELIZE_SMALL, K_FE_L2, K_CT_FIR, K_CT_DC, K_CT_GOERTZEL, K_FE_TILEFIX, K_SPGRAM, K_COUNT };
 static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
                                         "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
                                         "k_fir_tm<lp>", "k_frontend", "k_fe_carry",
                                         "k_channelize_small", "k_frontend<level2>", "k_fir_tm<ctcss_lp>",
-                                        "k_ct_dc_*", "k_ct_goertzel+final", "k_fe_tilefix" };
+                                        "k_ct_dc_*", "k_ct_goertzel+final", "k_fe_tilefix", "k_spgram+finish" };
 
 typedef struct { hipEvent_t a, b; int slot; } prof_pending;
 
@@ -123,6 +123,8 @@ struct pmr_chain_s {
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     /* persistent one-level kernel (k_fe_persist): ticket counters, published carry records, fallback flags */
     unsigned fe_last_ntiles;         /* tiles of the last fused front-end launch */
+    /* waterfall periodogram (pmr_spectrum.hip): display width (0 = off), window / twiddle tables, per-workgroup partial rows, PSD */
+    unsigned spec_nfft, spec_ntr_last; float *d_spec_win, *d_spec_tw, *d_spec_part, *d_spec_psd;
     int fe_lb;                       /* k_fe_fast<.., LB>: carry applied in-kernel by look-back (default where covered) */
     int fe_persist; unsigned fe_nwg; uint32_t *d_fe_tickets; uint32_t fe_ticket_base[8]; uint64_t *d_fe_prec; uint8_t *d_fe_fixflag;
     uint32_t fe_epoch;
@@ -737,7 +739,8 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
                      q->d_fe_V[1], q->d_fe_V[2], q->d_fe_tickets, q->d_fe_prec, q->d_fe_fixflag, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
-                     q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events };
+                     q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events,
+                     q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
         pmr_slot *sl = &q->slot[i];
@@ -1189,6 +1192,86 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
     return PMR_OK;
 }
 
+/* ---- the waterfall line.  Window as liquid's spgram scales it (oracle/orc_dsp.h):
+ * hann(i, n) * sqrt(2) / (sqrt(sum w^2 / n) * sqrt(4 n)), evaluated in float like the restatement. ---- */
+int pmr_chain_spectrum_enable(pmr_chain q, unsigned nfft)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    int rc = pmr_chain_synchronize(q);
+    if (rc) return rc;
+    if (nfft == q->spec_nfft) return PMR_OK;
+    void **bufs[] = { (void **)&q->d_spec_win, (void **)&q->d_spec_tw, (void **)&q->d_spec_part, (void **)&q->d_spec_psd };
+    for (size_t i = 0; i < 4; i++) if (*bufs[i]) { hipFree(*bufs[i]); *bufs[i] = NULL; }
+    q->spec_nfft = 0; q->spec_ntr_last = 0;
+    if (!nfft) return PMR_OK;
+    if (nfft < 8 || nfft > 1024 || (nfft & (nfft - 1))) return fail(q, PMR_EINVAL, "spectrum width: a power of two, 8..1024", hipSuccess);
+    const unsigned P = 4 * nfft;
+    float *w = (float *)malloc(nfft * sizeof(float)), *tw = (float *)malloc(P * sizeof(float));
+    if (!w || !tw) { free(w); free(tw); return fail(q, PMR_ENOMEM, "malloc", hipSuccess); }
+    float g = 0.0f;
+    for (unsigned i = 0; i < nfft; i++) {
+        w[i] = 0.5f - 0.5f * cosf((2.0f * (float)M_PI * (float)i) / ((float)(nfft - 1)));
+        g += w[i] * w[i];
+    }
+    g = (float)M_SQRT2 / (sqrtf(g / (float)nfft) * sqrtf((float)P));
+    for (unsigned i = 0; i < nfft; i++) w[i] *= g;
+    for (unsigned k = 0; k < P / 2; k++) {
+        const double a = -2.0 * M_PI * (double)k / (double)P;
+        tw[2 * k] = (float)cos(a); tw[2 * k + 1] = (float)sin(a);
+    }
+    rc = dev_upload(q, &q->d_spec_win, w, nfft);
+    if (!rc) rc = dev_upload(q, &q->d_spec_tw, tw, P);
+    free(w); free(tw);
+    if (!rc) rc = dev_alloc(q, (void **)&q->d_spec_part, (size_t)pmr_spgram_max_workgroups() * P * sizeof(float));
+    if (!rc) rc = dev_alloc(q, (void **)&q->d_spec_psd, P * sizeof(float));
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(q->stream), "sync");
+    q->spec_nfft = nfft;
+    return PMR_OK;
+}
+
+int pmr_chain_spectrum_read(pmr_chain q, float *psd_db, unsigned cap, unsigned *n_transforms)
+{
+    if (!q || !psd_db) return PMR_EINVAL;
+    if (!q->spec_nfft) return fail(q, PMR_EINVAL, "spectrum not enabled", hipSuccess);
+    const unsigned P = 4 * q->spec_nfft;
+    if (cap < P) return fail(q, PMR_ERANGE, "spectrum buffer", hipSuccess);
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    int rc = pmr_chain_synchronize(q);
+    if (rc) return rc;
+    if (n_transforms) *n_transforms = q->spec_ntr_last;
+    if (!q->spec_ntr_last) { memset(psd_db, 0, P * sizeof(float)); return PMR_OK; }
+    HIPCHK(hipMemcpy(psd_db, q->d_spec_psd, P * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy");
+    for (unsigned i = 0; i < P; i++) psd_db[i] = 10.0f * log10f(psd_db[i]);
+    return PMR_OK;
+}
+
+/* asgramcf_execute's peak search and character mapping (levels ref + k div, k = 0..9; the reference sets -40, 2 at :476) */
+int pmr_asgram_ascii(const float *psd_db, unsigned nfft, unsigned n_transforms, float ref, float div, char *ascii, float *peakval,
+                     float *peakfreq)
+{
+    static const char lc[10] = {' ', '.', ',', '-', '+', '*', '&', 'N', 'M', '#'};
+    if (!psd_db || !ascii || !nfft) return PMR_EINVAL;
+    const unsigned P = 4 * nfft;
+    float pv = 0.0f, pf = 0.0f;
+    ascii[nfft] = 0;
+    if (!n_transforms) {
+        memset(ascii, ' ', nfft);
+    } else {
+        for (unsigned i = 0; i < P; i++) if (i == 0 || psd_db[i] > pv) { pv = psd_db[i]; pf = (float)i / (float)P - 0.5f; }
+        for (unsigned i = 0; i < nfft; i++) {
+            float v = 0.0f;
+            for (unsigned j = 0; j < 4; j++) { const float x = psd_db[4 * i + j]; v = (j == 0 || x > v) ? x : v; }
+            ascii[i] = lc[0];
+            for (unsigned j = 0; j < 10; j++) if (v > ref + (float)j * div) ascii[i] = lc[j];
+        }
+    }
+    if (peakval) *peakval = pv;
+    if (peakfreq) *peakfreq = pf;
+    return PMR_OK;
+}
+
 int pmr_chain_ctcss_enable(pmr_chain q, int on)
 {
     if (!q) return PMR_EINVAL;
@@ -1338,6 +1421,11 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     }
     if (q->dbg_on && ny)
         if ((rc = ring_to_linear(q, q->d_dbg_xr, q->d_xr, q->xr_mask, xr_abs0, ny, sizeof(cfl)))) return rc;
+    if (q->spec_nfft) {                           /* asgramcf_write(resamp_buf, ny) + execute (:911-912): PSD of THIS block's samples */
+        q->spec_ntr_last = ny / (q->spec_nfft / 2);
+        LAUNCH(K_SPGRAM, pmr_launch_spgram(q->stream, q->d_xr, q->xr_mask, xr_abs0, ny, q->spec_nfft, q->d_spec_win, q->d_spec_tw,
+                                           q->d_spec_part, q->d_spec_psd));
+    }
 
     /* ring carry (:797,:804): frames of M samples, 0..M-1 remainder stays for the next call */
     const unsigned ns = (unsigned)((q->xr_abs - q->frames_done * M) / M);

@@ -241,6 +241,11 @@ int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_
 int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q,
                           const uint8_t *flags, const pmr_launch_events *ev);
 
+/* waterfall periodogram (pmr_spectrum.hip): PSD (linear, averaged, fft-shifted, 4 wlen bins) of ny ring samples from pos0 */
+unsigned pmr_spgram_max_workgroups(void);
+int pmr_launch_spgram(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t pos0, unsigned ny, unsigned wlen,
+                      const float *win, const void *tw, float *partial /*[max workgroups][4 wlen]*/, float *psd_mag /*[4 wlen]*/);
+
 #ifdef __cplusplus
 }
 #endif

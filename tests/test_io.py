@@ -95,6 +95,19 @@ def test_headless_harness_end_to_end(tmp_path):
     assert np.array_equal(data, audio.T)
     rate, one = wavfile.read(str(tmp_path / "ch2.wav"))
     assert np.array_equal(one, audio[2])
+    # waterfall line of every block (reference :910-915), 64 characters wide: same lines as the binding gives
+    r = subprocess.run([exe, "chan", str(tmp_path / "in.cf32"), str(tmp_path / "wf.wav"), str(fs), str(M), "2", "64"], check=True,
+                       capture_output=True, text=True)
+    lines = [l for l in r.stderr.splitlines() if l.startswith(" > ")]
+    ch.reset()
+    ch.spectrum_enable(64)
+    want = []
+    for i in range(0, n, 100000):
+        ch.process_block(x[i:i + 100000], want=("pcm",))
+        psd, ntr = ch.spectrum_read()
+        want.append(chain.asgram_ascii(psd, 64, ntr)[0])
+    assert len(lines) == len(want) == 4 and all(l[3:3 + 64] == w for l, w in zip(lines, want))
+    assert any(c != " " for c in want[0])
     # dsd mode: s16le 48 kHz stream
     xd = synth.synth_iq(450000, fs, 1)
     (tmp_path / "d.cf32").write_bytes(xd.tobytes())
