@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/exp/ext_event tools/exp/ext_event.hip ; run on the GPU box: ./tools/exp/ext_event
 // experiment: what do hipExtLaunchKernel's start/stop events cost and measure, next to hipEventRecord markers?
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
