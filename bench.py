@@ -443,6 +443,9 @@ def main():
                "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic"}
+        if world > 1:
+            out["dist"] = {"backend": args.dist_backend, "use": "start/stop barrier and MAX of the elapsed time only: one "
+                           "independent IQ stream per rank, no data-path collective"}
         for k in ("timed_regions", "config", "roofline", "one_open_channel", "parity_checked", "host_io", "cpu_baseline"):
             if k in head:
                 out[k] = head[k]

@@ -38,6 +38,9 @@ static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcbloc
                                         "k_channelize_small", "k_frontend<level2>", "k_fir_tm<ctcss_lp>",
                                         "k_ct_dc_*", "k_ct_goertzel+final", "k_fe_tilefix", "k_spgram+finish" };
 
+#define ZC_MAX_IN  (1u << 18)            /* zero-copy synchronous calls: samples (above this a copy engine + HBM-speed kernels win) */
+#define ZC_MAX_OUT (1u << 20)            /* ... and bytes of [rssi | pcm | audio] */
+
 typedef struct { hipEvent_t a, b; int slot; } prof_pending;
 
 /* one block in flight between host buffers (pmr_chain_submit_block / _collect_block; the synchronous entry points use slot 0) */
@@ -46,6 +49,7 @@ typedef struct {
     void *d_raw;                                 /* device: int16 / uint8 input before conversion (submit_block_fmt)           */
     hipEvent_t in_ready; int used; unsigned par; /* input copy finished; pipeline parity of the block that last used the slot  */
     char *h_out; cfl *h_chan;                    /* pinned host copies of the outputs                                         */
+    char *hd_out; cfl *hd_chan;                  /* the same pinned buffers as the DEVICE sees them (zero-copy outputs of small blocks) */
     size_t out_bytes, off_pcm, off_audio;
     hipEvent_t done; unsigned ns, stride, want;
 } pmr_slot;
@@ -655,6 +659,8 @@ static void read_switches(pmr_switches *w)
     w->be_prio = env_is("PMR_STREAM_PRIO", "1");
     w->host_gate = !env_is("PMR_HOST_GATE", "0");
     w->fe_marker = env_is("PMR_FE_EVENT", "marker");
+    w->no_zerocopy = env_is("PMR_ZEROCOPY", "0");
+    { const char *e = getenv("PMR_ZEROCOPY_MAX"); w->zc_max_in = e && atol(e) > 0 ? (unsigned)atol(e) : ZC_MAX_IN; }
 }
 
 static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only);
@@ -1537,18 +1543,25 @@ static int slot_prepare(pmr_chain q, unsigned i, int want_chan)
             hipEventCreateWithFlags(&sl->done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&sl->in_ready, hipEventDisableTiming) != hipSuccess)
             return fail(q, PMR_ENOMEM, "pinned slot buffers", hipSuccess);
+        if (hipHostGetDevicePointer((void **)&sl->hd_out, sl->h_out, 0) != hipSuccess) { sl->hd_out = NULL; (void)hipGetLastError(); }
         HIPCHK(hipStreamSynchronize(q->stream), "slot init");
     }
     if (want_chan && !sl->d_chan) {
         if ((rc = dev_alloc(q, (void **)&sl->d_chan, out_n * sizeof(cfl)))) return rc;
         if (hipHostMalloc((void **)&sl->h_chan, out_n * sizeof(cfl), hipHostMallocDefault) != hipSuccess)
             return fail(q, PMR_ENOMEM, "pinned slot buffers", hipSuccess);
+        if (hipHostGetDevicePointer((void **)&sl->hd_chan, sl->h_chan, 0) != hipSuccess) { sl->hd_chan = NULL; (void)hipGetLastError(); }
         HIPCHK(hipStreamSynchronize(q->stream), "slot init");
     }
     return PMR_OK;
 }
 
-/* queue one block: H2D -> chain -> D2H into the slot's pinned buffers; nothing is waited for */
+static const void *host_zero_copy(const void *p, size_t bytes);
+
+/* queue one block: H2D -> chain -> D2H into the slot's pinned buffers; nothing is waited for.
+ * Synchronous calls on SMALL blocks skip both copy engines (each copy is a submission of its own with ~10 us of hand-over on
+ * either side, 100 us -> 70 us per 100 000-sample call): the front end reads the caller's pinned buffer in place and the last
+ * kernels write the slot's pinned output buffer directly (PMR_ZEROCOPY=0 restores the copies). */
 static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigned n_in, unsigned want, int single)
 {
     pmr_slot *sl = &q->slot[i];
@@ -1567,7 +1580,12 @@ static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigne
     /* input: H2D (+ int16 / uint8 -> cf32 on the device).  Pipelined calls copy on their own stream, so the copy of block b+1
      * runs under the kernels of block b; it may not overwrite the slot's staging before the front end that last read it is done */
     hipStream_t s_in = single ? q->stream : q->stream_h2d;
-    if (n_in) {
+    const cfl *d_iq = sl->d_in;
+    if (single && fmt == 0 && n_in && n_in <= q->sw.zc_max_in && !q->sw.no_zerocopy) {
+        const void *z = host_zero_copy(iq, (size_t)n_in * sizeof(cfl));
+        if (z) d_iq = (const cfl *)z;
+    }
+    if (n_in && d_iq == sl->d_in) {
         if (!single && sl->used) HIPCHK(hipStreamWaitEvent(s_in, q->ev_fe[sl->par], 0), "wait front end");
         const size_t bytes = (size_t)n_in * (fmt == 0 ? 8 : fmt == 1 ? 4 : 2);
         HIPCHK(hipMemcpyAsync(fmt ? sl->d_raw : (void *)sl->d_in, iq, bytes, hipMemcpyHostToDevice, s_in), "H2D");
@@ -1579,12 +1597,17 @@ static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigne
     }
     sl->used = !single; sl->par = (unsigned)(q->n_calls % PIPE_DEPTH);
     unsigned ns = 0;
-    rc = process_block_device_impl(q, sl->d_in, n_in, (want & PMR_WANT_PCM) ? sl->d_out + sl->off_pcm : NULL,
-                                   (want & PMR_WANT_AUDIO) ? sl->d_out + sl->off_audio : NULL, stride, &ns,
-                                   (want & PMR_WANT_CHAN) ? sl->d_chan : NULL, (want & PMR_WANT_RSSI) ? sl->d_out : NULL, single);
+    const size_t out_hi = (want & PMR_WANT_AUDIO) ? sl->off_audio + n * sizeof(float) : sl->off_pcm + n * sizeof(int16_t);
+    const int zc_out = single && !q->sw.no_zerocopy && sl->hd_out && out_hi <= ZC_MAX_OUT &&
+                       (!(want & PMR_WANT_CHAN) || (sl->hd_chan && n * sizeof(cfl) <= ZC_MAX_OUT));
+    char *o_out = zc_out ? sl->hd_out : sl->d_out;
+    rc = process_block_device_impl(q, d_iq, n_in, (want & PMR_WANT_PCM) ? o_out + sl->off_pcm : NULL,
+                                   (want & PMR_WANT_AUDIO) ? o_out + sl->off_audio : NULL, stride, &ns,
+                                   (want & PMR_WANT_CHAN) ? (zc_out ? sl->hd_chan : sl->d_chan) : NULL,
+                                   (want & PMR_WANT_RSSI) ? o_out : NULL, single);
     if (rc) return rc;
     sl->ns = ns; sl->stride = stride; sl->want = want;
-    if (ns) {
+    if (ns && !zc_out) {
         const size_t lo = (want & PMR_WANT_RSSI) ? 0 : (want & PMR_WANT_PCM) ? sl->off_pcm : sl->off_audio;
         const size_t hi = (want & PMR_WANT_AUDIO) ? sl->off_audio + n * sizeof(float)
                         : (want & PMR_WANT_PCM) ? sl->off_pcm + n * sizeof(int16_t) : (size_t)q->M * sizeof(float);
@@ -1673,13 +1696,50 @@ int pmr_chain_collect_block(pmr_chain q, int16_t *pcm, float *audio, unsigned pc
 unsigned pmr_chain_blocks_in_flight(pmr_chain q) { return q ? q->n_inflight : 0; }
 unsigned pmr_chain_max_in_flight(pmr_chain q) { (void)q; return PIPE_DEPTH; }
 
-/* pinned host memory from THIS library's HIP runtime: what the asynchronous copies of submit / collect need */
+/* pinned host memory from THIS library's HIP runtime: what the asynchronous copies of submit / collect need.  The
+ * allocations are remembered (host range -> address the device sees), so a synchronous call on a SMALL block can let the front
+ * end read the caller's buffer in place over the host link instead of waiting for a copy engine first (host_zero_copy). */
+#define HOST_REG_MAX 256
+static struct { char *h, *d; size_t n; } g_host_reg[HOST_REG_MAX];
+static volatile int g_host_reg_lock;
+static void host_reg_acquire(void) { while (__sync_lock_test_and_set(&g_host_reg_lock, 1)) { } }
+static void host_reg_release(void) { __sync_lock_release(&g_host_reg_lock); }
+
 void *pmr_host_alloc(size_t bytes)
 {
-    void *p = NULL;
-    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : NULL;
+    void *p = NULL, *d = NULL;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return NULL;
+    if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess && d) {
+        host_reg_acquire();
+        for (int i = 0; i < HOST_REG_MAX; i++)
+            if (!g_host_reg[i].h) { g_host_reg[i].h = (char *)p; g_host_reg[i].d = (char *)d; g_host_reg[i].n = bytes ? bytes : 16; break; }
+        host_reg_release();
+    } else {
+        (void)hipGetLastError();
+    }
+    return p;
 }
-void pmr_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+void pmr_host_free(void *p)
+{
+    if (!p) return;
+    host_reg_acquire();
+    for (int i = 0; i < HOST_REG_MAX; i++)
+        if (g_host_reg[i].h == (char *)p) { g_host_reg[i].h = NULL; g_host_reg[i].d = NULL; g_host_reg[i].n = 0; }
+    host_reg_release();
+    (void)hipHostFree(p);
+}
+
+/* device-visible address of [p, p + bytes) if it lies inside a pmr_host_alloc allocation, else NULL */
+static const void *host_zero_copy(const void *p, size_t bytes)
+{
+    const char *c = (const char *)p, *r = NULL;
+    host_reg_acquire();
+    for (int i = 0; i < HOST_REG_MAX && !r; i++)
+        if (g_host_reg[i].h && c >= g_host_reg[i].h && c + bytes <= g_host_reg[i].h + g_host_reg[i].n) r = g_host_reg[i].d + (c - g_host_reg[i].h);
+    host_reg_release();
+    return r;
+}
 
 int pmr_chain_process_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, int16_t *pcm, unsigned pcm_stride,
                             unsigned *n_frames, pmr_cf32 *chan_out, float *rssi_db)

@@ -2,7 +2,8 @@
 // (reference src/sdr_pmr446.c:795-796: iirfilt_crcf_execute_block + msresamp_crcf_execute) for the cascades liquid's
 // As = 60 dB design produces: N3 six-tap stages (m = 3), then the m = 5 and m = 10 stages, then the 256 x 14 polyphase bank.
 //
-//   k_fe_fast<FE_FULL, N3, 1>   whole front end in one pass over the raw block (cfg2: N3 = 1, cfg3: N3 = 2)
+//   k_fe_fast<FE_FULL, N3, 1>   whole front end in one pass over the raw block (cfg2: N3 = 1, cfg3: N3 = 2; N3 = 0: the reference's
+//                               own 1.024 MS/s plan, whose cascade is just m = 5, m = 10)
 //   k_fe_fast<FE_L1,  N3, 0>    level 1 of a deep cascade (cfg5 / dsd_in: N3 = 4): dc-block + N3 six-tap stages -> decimated ring
 //   k_fe_level2                 level 2: ring in (level 1's dc carry applied at load) -> m = 5 -> m = 10 -> resampler
 //
@@ -56,15 +57,19 @@ static __device__ __forceinline__ void fe_publish(uint64_t *rec, float v, uint32
 template <int MODE, int N3, int TAIL, bool LB = false>
 __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 {
-    static_assert(!LB || (MODE == FE_FULL && TAIL == 1), "look-back is for the one-level kernels");
+    static_assert(!LB || (MODE == FE_FULL && TAIL == 1 && N3 >= 1), "look-back is for the one-level kernels");
+    static_assert(N3 >= 1 || (MODE == FE_FULL && TAIL == 1), "a cascade without six-tap stages is (m = 5, m = 10)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256, SPT = 16, N0 = NT * SPT;
     constexpr int H = N3 + 2 * TAIL;
     constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;         // z1 (2048 samples, layout L(8)) fills [0, R1_OFF) of the tile area
     // LDS: [FE_PAD zero pad | raw tile, 4096 samples = 2048 swizzled 16-byte chunks; afterwards R0 (z1, 2304 slots) and
     // R1 (z2, 1280 slots) | scan scratch] = 33.6 KB -> four tiles per CU
+    // N3 == 0 (no six-tap stage: the reference's own 1.024 MS/s plan is m = 5, 10): the dc-blocked tile goes back to LDS in
+    // layout L(16) (4352 slots) and the m = 5 stage runs from there in place; the scan scratch sits behind it
+    constexpr int SCR = N3 == 0 ? N0 + N0 / 16 : N0;
     cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
-    cf *wagg = buf + N0;
+    cf *wagg = buf + SCR;
     cf *bnd = wagg + NT / 64;                                 // [4][10]
     cf *pr = bnd + 40;                                        // LB: [2] probes A, B of this tile
     float *sV = reinterpret_cast<float *>(pr + 2);            // LB: carry (re, im), [2] = ok
@@ -169,6 +174,12 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
         }
         if (tid == p.Hh / SPT - 1) { ((cf *)p.probeA)[c] = v1; if (LB) pr[0] = v1; }      // local v at tile offset Hh-1
         if (tid == NT - 1) { ((cf *)p.probeB)[c] = v1; if (LB) pr[1] = v1; }              // local v at tile offset N0-1
+        if constexpr (N3 == 0) {
+            // no six-tap stage: dc-blocked samples -> LDS, layout L(16) (the raw tile is dead: every thread holds its samples)
+            cf *o = buf + tid * 17;
+#pragma unroll
+            for (int i = 0; i < SPT; i++) o[i] = yb[i];
+        } else {
         // halo of stage 0: the previous thread's yb[6..15] (lane 0: previous wave's lane 63, through LDS)
         cf W[26];
 #pragma unroll
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             o[q] = cadd_scale(W[2 * q + 5], a, scale0);
         }
     }
+        }
     __syncthreads();
 
     // ---- phase C: remaining stages, ping-pong R0 <-> R1; stage e (execution index) has 2048 >> e outputs ----
@@ -236,7 +248,8 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             lb_im = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if constexpr (TAIL) FE_STAGE(N3, 5, 6 * N3);
+    if constexpr (TAIL && N3 == 0) hb_stage_ip<8, 5>(buf, tid, NT, p.taps_k, 1.0f);            // 2048 outputs, L(16) -> L(8), in place
+    else if constexpr (TAIL) FE_STAGE(N3, 5, 6 * N3);
     if constexpr (LB) {
         if (wave == 0) {
             bool ok = !lb_mine || ((uint32_t)(lb_re >> 32) == p.epoch && (uint32_t)(lb_im >> 32) == p.epoch);
@@ -736,7 +749,7 @@ static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, 
 #ifndef FE_EXTRA_LDS
 #define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup (8192 -> three tiles per CU instead of four) */
 #endif
-    const size_t lds = (FE_PAD + 4096 + 4 + 44) * sizeof(cf) + FE_EXTRA_LDS;
+    const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 44) * sizeof(cf) + FE_EXTRA_LDS;
     auto kern = k_fe_fast<MODE, N3, TAIL, LB>;
     PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p);
     return (int)hipGetLastError();
@@ -749,7 +762,7 @@ static int fast_pattern(const pmr_fe_params *p, int *n3, int *tail)
     while (k < p->h && p->m[k] == 3) k++;
     *n3 = k;
     if (k == p->h) { *tail = 0; return k >= 1; }
-    if (k >= 1 && k + 2 == p->h && p->m[k] == 5 && p->m[k + 1] == 10) { *tail = 1; return 1; }
+    if (k + 2 == p->h && p->m[k] == 5 && p->m[k + 1] == 10) { *tail = 1; return 1; }
     return 0;
 }
 
@@ -767,6 +780,7 @@ extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsign
         return (int)hipErrorInvalidValue;                     /* the caller planned on flags only this kernel writes */
     }
     if (p->mode == FE_FULL && tail) {
+        if (n3 == 0) return launch_fast<FE_FULL, 0, 1>(st, p, ntiles, ev);
         if (n3 == 1) return launch_fast<FE_FULL, 1, 1>(st, p, ntiles, ev);
         if (n3 == 2) return launch_fast<FE_FULL, 2, 1>(st, p, ntiles, ev);
         if (n3 == 3) return launch_fast<FE_FULL, 3, 1>(st, p, ntiles, ev);

@@ -100,3 +100,34 @@ def test_integer_ingest_formats_are_converted_on_the_device(fmt):
     for a, b in zip(ref, got):
         assert np.array_equal(a, b) and a.shape[1] > 100
     g.close()
+
+
+@pytest.mark.parametrize("cfg,sizes", [(CFG_REF, [100000, 99999, 7, 0, 100000, 65537]), (CFG2, [250000, 1 << 18, (1 << 18) + 1, 300001]),
+                                       (CFG5, [1 << 18, 200003])],
+                         ids=["ref-point", "cfg2-around-threshold", "cfg5"])
+def test_zero_copy_pinned_input_equals_copied_input(cfg, sizes):
+    """Synchronous calls on small blocks read a pmr_host_alloc'd input in place and write the outputs straight to pinned memory
+    (no copy-engine submissions); blocks above 2^18 samples, pageable inputs and PMR_ZEROCOPY=0 go through the copies.  Same
+    stream fed both ways -- including a view at an odd offset inside the pinned allocation, which takes the front end's unaligned
+    tile path -- must agree bit for bit (pcm, audio, chan) and to rounding in rssi."""
+    from sdr_pmr446_amd import chain
+    fs, M = cfg
+    ks = None if M <= 64 else list(range(0, M, 73))
+    x = synth.synth_iq(sum(sizes), fs, M, channels=ks, dev_hz=1500.0)
+    mb = max(sizes)
+    ga = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb)
+    gb = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb)
+    pin = ga.pinned_array(mb + 1)
+    pos = 0
+    for i, n in enumerate(sizes):
+        blk = x[pos:pos + n]
+        pos += n
+        view = pin[i & 1:(i & 1) + n]                   # odd blocks start 8 bytes into the allocation (not 16-byte aligned)
+        view[:] = blk
+        a = ga.process_block(view, want=("pcm", "audio", "chan", "rssi"))
+        b = gb.process_block(blk.copy(), want=("pcm", "audio", "chan", "rssi"))        # pageable: copy path
+        assert a["n_frames"] == b["n_frames"]
+        for k in ("pcm", "audio", "chan"):
+            assert np.array_equal(a[k], b[k]), (k, i, n)
+        assert np.allclose(a["rssi"], b["rssi"], atol=1e-4, equal_nan=True)
+    ga.close(); gb.close()
