@@ -121,6 +121,7 @@ struct pmr_chain_s {
     int fe2_T_own, fe2_Hh, fe2_HhQ, fe2_TQ;   /* level-2 tile geometry, in level-1 output samples      */
     int fe2_N0, fe2_fast;            /* level-2 tile size; specialised k_fe_level2 (m = 5, 10) selected   */
     float fe1_K;                     /* alpha * prod G_e (e < s1): dc-carry gain at the level-1 output */
+    float *d_fe_G1;                  /* [..] fe1_K * mu^e: level 1's carry gain per tile-local index (level 2's load-time fix) */
     cfl *d_fe_ring1; uint64_t ring1_mask;
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
     int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_tiles_params pend_t2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
@@ -436,6 +437,17 @@ static int fe_init(pmr_chain q)
         for (unsigned i = 0; i < n1; i++) t1[i] = (float)pow(mu, 32.0 * i);
         for (unsigned i = 0; i < 32; i++) t2[i] = (float)pow(mu, (double)i);
         rc = dev_upload(q, &q->d_fe_T1, t1, n1);
+        if (!rc && q->fe_two) {
+            /* level 2 applies level 1's carry while loading: one table of the whole gain K1 * mu^e, the SAME float products
+             * k_fe_carry forms from T1 / T2 (K * (T1[e >> 5] * T2[e & 31])), so both correct a sample identically */
+            float *g1 = (float *)calloc((size_t)n1 * 32, sizeof(float));
+            if (!g1) rc = fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+            else {
+                for (unsigned e = 0; e < n1 * 32; e++) { const float tt = t1[e >> 5] * t2[e & 31]; g1[e] = q->fe1_K * tt; }
+                rc = dev_upload(q, &q->d_fe_G1, g1, (size_t)n1 * 32);
+                free(g1);
+            }
+        }
         free(t1);
         if (rc) return rc;
         if ((rc = dev_upload(q, &q->d_fe_T2, t2, 32))) return rc;
@@ -746,7 +758,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
                      q->d_fe_V[1], q->d_fe_V[2], q->d_fe_tickets, q->d_fe_prec, q->d_fe_fixflag, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events,
-                     q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd };
+                     q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1 };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
         pmr_slot *sl = &q->slot[i];
@@ -1098,7 +1110,8 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     memset(&p2, 0, sizeof(p2));
     p2.mode = 2;
     p2.in_ring = q->d_fe_ring1; p2.in_mask = q->ring1_mask; p2.in_abs0 = (int64_t)A;
-    p2.fixV = q->d_fe_V[slot]; p2.fix_T1 = q->d_fe_T1; p2.fix_T2 = q->d_fe_T2;
+    p2.fixV = q->d_fe_V[slot]; p2.fix_T1 = q->d_fe_T1; p2.fix_T2 = q->d_fe_T2; p2.fix_G = q->d_fe_G1;
+    p2.fix_rTQ = 1.0f / (float)q->fe_TQ;
     p2.fix_TQ = (unsigned)q->fe_TQ; p2.fix_HhQ = (unsigned)q->fe_HhQ; p2.fix_K = q->fe1_K; p2.fix_limit = f.j0;
     p2.out = q->d_xr; p2.out_pos0 = q->xr_abs; p2.out_mask = q->xr_mask;
     p2.hb_taps = q->d_fe_taps; p2.arb_bank = q->d_arb_bank; p2.lam_lane_pow = q->d_fe_lam_lane;

@@ -186,9 +186,16 @@ static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, cons
         const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
         const int qd = (int)((ph >> 24) - qa) + p.HhQ;                            // tile-local decimated index
         const int ql = qd - 13;
+        // window sample ql + k sits at (ql + k) + ((ql + k) >> GS) (layout L(1 << GS)).  With ql = Q 2^GS + r and k = K 2^GS + g that is
+        // [ql + Q + ((r + g) >> GS)] + [k + K]: one base per residue g, every tap a compile-time offset -- three address
+        // instructions per tap otherwise, more than the tap's own multiply-add
+        constexpr int NG = 1 << GS;
+        const cf *bg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) bg[g] = fin + ql + (ql >> GS) + (((ql & (NG - 1)) + g) >> GS);
         cf y = cfm(0.f, 0.f);
 #pragma unroll
-        for (int k = 0; k < 14; k++) y = cfma(bk[k], fin[(ql + k) + ((ql + k) >> GS)], y);
+        for (int k = 0; k < 14; k++) y = cfma(bk[k], bg[k & (NG - 1)][k + (k >> GS)], y);
         if constexpr (FIX) {
             const float u = p.Kgain * (p.GA[(unsigned)(ph & 0xffffffu) >> 16] * (p.T1[qd >> 5] * p.T2[qd & 31]));
             y = cfm(fmaf(-Vr, u, y.x), fmaf(-Vi, u, y.y));

@@ -96,13 +96,19 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
     const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
     if (fast) {
-        const float4 *__restrict__ src = reinterpret_cast<const float4 *>(x + b0);
+        // wave-instruction i of wave w moves slots s0 .. s0 + 63, s0 = 512 w + 64 i (1 KiB).  fe_swz(s0 + lane) - s0 depends on
+        // the parity of i only ((s0 >> 4) & 7 = 4 (i & 1)), so the source address is a UNIFORM base (scalar registers, immediate
+        // i * 1 KiB) plus one of two per-lane byte offsets, and the LDS base (M0) is scalar too: no per-instruction vector
+        // address arithmetic (it was ~5 VALU per DMA instruction)
+        const int ws = __builtin_amdgcn_readfirstlane(wave);
+        const char *srcw = reinterpret_cast<const char *>(x + b0) + (size_t)ws * (N0 / 8) * 16;
+        float4 *ldsw = reinterpret_cast<float4 *>(buf) + ws * (N0 / 8);
+        const unsigned sw0 = (unsigned)((lane & ~7) | ((lane & 7) ^ ((lane >> 4) & 7))) * 16u;
+        const unsigned sw1 = (unsigned)((lane & ~7) | ((lane & 7) ^ (((lane >> 4) + 4) & 7))) * 16u;
 #pragma unroll
-        for (int i = 0; i < N0 / 2 / NT; i++) {
-            const int s0 = wave * (N0 / 8) + i * 64;                       // first slot of this wave-instruction (1 KiB)
-            __builtin_amdgcn_global_load_lds((gptr_t *)(src + fe_swz(s0 + lane)), (lptr_t *)(reinterpret_cast<float4 *>(buf) + s0),
-                                             16, 0, FE_DMA_AUX);
-        }
+        for (int i = 0; i < N0 / 2 / NT; i++)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(srcw + i * 1024 + ((i & 1) ? sw1 : sw0)), (lptr_t *)(ldsw + i * 64), 16, 0,
+                                             FE_DMA_AUX);
     } else {
         // edge tiles (history before the block, zeros beyond it, or an unaligned block): plain loads into the same image
 #pragma unroll 4
@@ -709,15 +715,17 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
         }
 #pragma unroll
         for (int k = 0; k < 14; k++) { bk0[k] = ap.b0p[k]; bk1[k] = ap.b1p[k]; }
-        // level-1 tile index and tile-local offset of a sample advance incrementally over the four pairs (+2 NT samples each):
-        // one 32-bit division per thread
-        unsigned c1 = 0, ql = 0; bool trk = false;
-        const auto fix = [&](long long j, float &re, float &im) {          // j: index among this call's new ring samples
-            if (!V1 || j < 0 || j >= (long long)p.fix_limit) return;
-            if (!trk) { c1 = (unsigned)j / p.fix_TQ; ql = (unsigned)j - c1 * p.fix_TQ; trk = true; }
-            while (ql >= p.fix_TQ) { ql -= p.fix_TQ; c1++; }
-            const unsigned e = ql + p.fix_HhQ;
-            const float g = p.fix_K * (p.fix_T1[e >> 5] * p.fix_T2[e & 31]);
+        // Level-1 carry of a new ring sample j (0 <= j < fix_limit): tile c1 = j / TQ by a float reciprocal with an exact fix-up
+        // (j < 2^24), gain from ONE table.  The pair's second sample is the next tile-local index, or index 0 of the next tile.
+        const unsigned TQ1 = p.fix_TQ;
+        const auto locate = [&](unsigned j, unsigned &c1, unsigned &r) {
+            c1 = (unsigned)((float)j * p.fix_rTQ);
+            int rr = (int)(j - c1 * TQ1);
+            if (rr < 0) { c1--; rr += (int)TQ1; } else if (rr >= (int)TQ1) { c1++; rr -= (int)TQ1; }
+            r = (unsigned)rr;
+        };
+        const auto apply = [&](unsigned c1, unsigned r, float &re, float &im) {
+            const float g = p.fix_G[r + p.fix_HhQ];
             const cf Vc = V1[c1];
             re = fmaf(-Vc.x, g, re); im = fmaf(-Vc.y, g, im);
         };
@@ -727,10 +735,15 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
             const long long jn = b0 + i;
             float4 w = v[k];
             if (jn + 1 >= (long long)p.n_in) { w.z = 0.f; w.w = 0.f; }    // the pair's second sample lies beyond the block
-            fix(jn, w.x, w.y);
-            if (trk) ql += 1;
-            fix(jn + 1, w.z, w.w);
-            if (trk) ql += 2 * NT - 1;
+            if (V1 && jn + 1 >= 0 && jn < (long long)p.fix_limit) {       // the pair touches the range level 2 corrects
+                unsigned c1, r;
+                locate((unsigned)(jn < 0 ? 0 : jn), c1, r);
+                if (jn >= 0) {
+                    apply(c1, r, w.x, w.y);
+                    if (++r == TQ1) { r = 0; c1++; }
+                }
+                if (jn + 1 < (long long)p.fix_limit) apply(c1, r, w.z, w.w);
+            }
             cf *d = R0 + lidx<8>(i);                                       // the pair never straddles an 8-sample chunk
             d[0] = cfm(w.x, w.y);
             d[1] = cfm(w.z, w.w);

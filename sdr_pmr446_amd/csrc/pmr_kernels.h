@@ -180,6 +180,7 @@ typedef struct {
      * of level-1 tile c1 = j / fix_TQ is subtracted at load: V[c1] * fix_K * mu^(j - c1 fix_TQ + fix_HhQ)       */
     const void *in_ring; uint64_t in_mask; int64_t in_abs0;
     const void *fixV; const float *fix_T1, *fix_T2; unsigned fix_TQ, fix_HhQ; float fix_K;
+    const float *fix_G; float fix_rTQ;   /* k_fe_level2: fix_G[e] = fix_K * (fix_T1[e >> 5] * fix_T2[e & 31]) as one table; 1 / fix_TQ */
     unsigned fix_limit;         /* new samples with index >= fix_limit were already corrected in place (k_fe_carry)   */
     uint32_t step_rinv;         /* floor(2^56 / step) clamped to 32 bits: integer ceil-division by the resampler step */
     void *tile_j;               /* nullable [ntiles][2] u64: the tile's resampler output range [ja, jb), for k_fe_tilefix */
