@@ -109,6 +109,9 @@ def load(build_if_missing=True):
     path = _build.LIB
     if build_if_missing:
         path = _build.build()
+    alt = os.environ.get("PMR_LIBRARY")          # another BUILD of this library (same ABI): A/B of two builds on one GPU box
+    if alt:
+        path = alt
     if not os.path.exists(path):
         raise RuntimeError("libpmr446_hip.so is missing: run sdr_pmr446_amd/build.py (no CPU fallback exists)")
     L = C.CDLL(path)
