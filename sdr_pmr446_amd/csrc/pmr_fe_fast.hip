@@ -26,8 +26,13 @@
 
 enum { FE_FULL = 0, FE_L1 = 1 };
 #ifndef FE_DMA_AUX
-#define FE_DMA_AUX 0        /* cache policy of the raw-tile LDS-DMA: 0 default, 2 = nt (streaming, read once) */
+#define FE_DMA_AUX 2        /* cache policy of the raw-tile LDS-DMA: 2 = nt (streaming, read once), 0 = default.  The raw block is read
+                               exactly once: with nt it no longer displaces the back-end kernels' working sets (ring, scratch,
+                               discriminator rows) from L2 / Infinity Cache -- neutral for this kernel alone, +3.5 % for the pipelined
+                               chain (cfg5 486 -> 503, cfg2 313 -> 325 GS/s on one box; sc0 / sc1 on top change nothing; non-temporal loads of
+                               level 2's ring reads or non-temporal PCM stores: neutral to slightly worse, not used) */
 #endif
+
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
