@@ -290,7 +290,8 @@ __global__ __launch_bounds__(CW_NT, 4) void k_channelize_win(pmr_chan_params q)
     const unsigned ns = q.ns, nco_mask = q.nco_period - 1;
     const float fm_ref = q.fm_ref;
     const int tid = threadIdx.x;
-    const long t0 = (long)blockIdx.x * (NFT - 1);         // first NEW frame of this tile, relative to q.frame0
+    const unsigned wg = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
+    const long t0 = (long)wg * (NFT - 1);                 // first NEW frame of this tile, relative to q.frame0
 
     // ---- pass 1: polyphase bank, X[f][brev(c)] ----
     {
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(CW_NT, 4) void k_channelize_win(pmr_chan_params q)
         if (tid < M) {
             float a = 0.f;
             for (int w = 0; w < CW_NT / 64; w++) a += red[w * M + tid];
-            q.rssi_part[(size_t)blockIdx.x * M + tid] = a;
+            q.rssi_part[(size_t)wg * M + tid] = a;
         }
     }
 }

@@ -38,7 +38,7 @@ static __device__ __forceinline__ cf cmul(cf a, cf w) { return __builtin_element
 __global__ __launch_bounds__(256, PW_MINB) void k_pfb_wide(pmr_chan_params q, unsigned log2M, cf *__restrict__ Xg)
 {
     const unsigned M = q.M, nrows = q.ns + 1;                    // row r of Xg <-> frame (frame0 - 1 + r)
-    const unsigned w = blockIdx.x * 256u + threadIdx.x;
+    const unsigned w = pmr_xcd_contiguous(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
     const unsigned c = w & (M - 1), r0 = (w >> log2M) * PW_F;
     if (r0 >= nrows) return;
     const cf *__restrict__ xr = (const cf *)q.xr;
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
     cf *A = reinterpret_cast<cf *>(smem), *tw = A + FPW * M;                        // [FPW][M], [M/2]
     const int tid = threadIdx.x;
     const unsigned ns = q.ns;
-    const unsigned row0 = blockIdx.x * (FPW - 1);                // first row of Xg this workgroup reads (= previous frame)
+    const unsigned wg = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
+    const unsigned row0 = wg * (FPW - 1);                        // first row of Xg this workgroup reads (= previous frame)
     const unsigned nrow = min((unsigned)FPW, ns + 1 - row0);     // valid rows; new frames: nrow - 1
 
     for (int k = tid; k < M / 2; k += 256) tw[k] = ((const cf *)q.fft_tw)[k];
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
         for (unsigned k = tid; k < M; k += 256) {
             float a = 0.f;
             for (unsigned f = 0; f < nnew; f++) { const cf cu = Y[(f + 1) * M + k]; a += hypotf(cu.x, cu.y); }
-            q.rssi_part[(size_t)blockIdx.x * M + k] = a;
+            q.rssi_part[(size_t)wg * M + k] = a;
         }
     }
 }

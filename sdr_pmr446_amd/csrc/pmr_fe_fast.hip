@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
     cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;       // input (layout L(8)), then z1 (L(4)), then z2 (L(2)), all in place
     cf *R0 = buf;
     const int tid = threadIdx.x;
-    const int c = blockIdx.x;
+    const int c = (int)pmr_xcd_contiguous(blockIdx.x, gridDim.x);
     const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // index of tile sample 0 among this call's new ring samples
 
     const unsigned long long qa = (unsigned long long)c * p.TQ;

@@ -60,6 +60,11 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
 {
     static_assert(!GATHER || (TPW == 1 && !GLB), "gathered units: one tile per workgroup, LDS window");
     static_assert(!DUAL || (TPW == 1 && !GLB && SWAP), "dual tap sets: one tile per workgroup (register budget), LDS window");
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (!GATHER) {
+        const unsigned L = pmr_xcd_contiguous(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        bx = L % gridDim.x; by = L / gridDim.x;
+    }
     __shared__ unsigned s_ch[16];                                    // channel of column slot s (relative to the pointers below)
     __shared__ long s_t0[16];                                        // first frame of slot s
     if constexpr (GATHER) {
@@ -69,8 +74,9 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
             s_t0[threadIdx.x] = u < n_units ? (long)(u % nseg) * FM_TILE : (long)ns;      // beyond the block: nothing stored
         }
     } else {
-        // blockIdx.y selects a group of 16 channels: the tile is 16 channels wide whatever M is
-        const unsigned cg0 = blockIdx.y * 16u;
+        // a group of 16 channels per workgroup row: the tile is 16 channels wide whatever M is.  (bx, by) = XCD-contiguous
+        // re-numbering of the launch's workgroups: consecutive time tiles of one channel group, whose windows overlap, share an L2
+        const unsigned cg0 = by * 16u;
         in += cg0;
         if (out_tm) out_tm += cg0;
         if (DUAL) out2_tm += cg0;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(FM_NT, 3) void k_fir_mfma16(const float *__restrict
     // GLB: no sample window in LDS at all -- the B operand comes straight from the time-major ring through the vector L1
     // (a wave-instruction touches four 64-byte rows).  With ~2 KB of LDS and < 128 registers a workgroup of this kernel
     // fits NEXT TO the front end's tiles on a CU.
-    const long tile0 = (long)blockIdx.x * TPW;
+    const long tile0 = (long)bx * TPW;
     if constexpr (GATHER) { __syncthreads(); issue_g(); commit_g(); }
     else if constexpr (!GLB) { issue(tile0 * FM_TILE); commit(); }
     __syncthreads();

@@ -252,4 +252,16 @@ int pmr_launch_spgram(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t
 #ifdef __cplusplus
 }
 #endif
+
+#if defined(__HIPCC__)
+/* XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), so workgroup b takes LOGICAL
+ * index (b % 8) * (n / 8) + b / 8 -- every XCD then works through a CONTIGUOUS range of tiles, and the rows two neighbouring
+ * tiles both read (filter history: 25 of 33 rows in k_pfb_wide, 408 of 664 in the FIR window) are fetched into one L2 once
+ * instead of into two L2s.  Placement only: never changes results. */
+static __device__ __forceinline__ unsigned pmr_xcd_contiguous(unsigned b, unsigned n)
+{
+    const unsigned per = n >> 3, main = per << 3;
+    return b < main ? (b & 7u) * per + (b >> 3) : b;
+}
+#endif
 #endif
