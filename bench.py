@@ -10,7 +10,8 @@ the start/stop barrier and the max-over-ranks of the elapsed time).
 
 Headline workload (N = 1 and N > 1): cfg5 = BASELINE.json configs[4], the largest single-GPU configuration (the metric
 is quoted on no configuration; BASELINE.md calls cfg5 the HBM-roofline config).  At N = 1 the same line carries cfg2
-(configs[1]) and cfg3 (configs[2]) as "also" sub-records, each with its own roofline and parity check.
+(configs[1]) and cfg3 (configs[2]) as "also" sub-records, each with its own roofline and parity check; at N > 1 it carries
+cfg3 on every GPU = cfg4 (configs[3]: N independent 61.44 MS/s streams, one per GPU).
 
 The timed region (W warm-up steps, then exactly K steps between barrier + synchronize) is REPEATED `--regions` times;
 `value` / `ms_per_step` are the median region, `timed_regions` lists first / min / median / max.
@@ -302,8 +303,10 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
             "timed_regions": {"n": len(dts), "steps_each": args.steps, "ms_per_step_first": ms_all[0],
                               "ms_per_step_min": min(ms_all), "ms_per_step_median": statistics.median(ms_all),
                               "ms_per_step_max": max(ms_all), "value_is": "median region"},
-            "config": {"workload": "%s (BASELINE.json configs[%d]): %d-ch PMR446 chain @ %.4g MS/s, one independent IQ "
-                                   "stream per GPU" % (name, cfg_idx, M, fs / 1e6),
+            "config": {"workload": ("cfg4 (BASELINE.json configs[3]): %d independent %d-ch streams @ %.4g MS/s, one per GPU (cfg3 on "
+                                    "every GPU)" % (world, M, fs / 1e6)) if (name == "cfg3" and world > 1) else
+                                   ("%s (BASELINE.json configs[%d]): %d-ch PMR446 chain @ %.4g MS/s, one independent IQ "
+                                    "stream per GPU" % (name, cfg_idx, M, fs / 1e6)),
                        "block_samples": block, "frames_per_step": frames // max(1, args.steps),
                        "channels_demodulated": M,
                        "hbm_frac_of_peak_whole_chain": value * 1e6 * b_alg / 1e9 / world / HBM_PEAK_GBPS},
@@ -428,7 +431,11 @@ def main():
     dist = multigpu.init_dist(args.dist_backend, dev)
 
     if args.also is None:
-        also = [w for w in ("cfg2", "cfg3") if w != args.workload] if (world == 1 and args.workload == HEADLINE) else []
+        # N = 1: cfg2 and cfg3 ride along.  N > 1: cfg3 on every GPU IS BASELINE.json configs[3] ("cfg4": N independent
+        # 61.44 MS/s streams, one per GPU) -- one timed region of it beside the headline
+        also = [w for w in ("cfg2", "cfg3") if w != args.workload] if world == 1 else ["cfg3"]
+        if args.workload != HEADLINE:
+            also = []
     else:
         also = [w for w in args.also.split(",") if w in WORKLOADS and w != args.workload]
 
