@@ -668,7 +668,7 @@ static void read_switches(pmr_switches *w)
     { const char *e = getenv("PMR_FIR_TPW"); w->fir_tpw = e ? atoi(e) : 2; }
     w->fir_nodual = env_is("PMR_FIR_DUAL", "0");
     w->no_overlap = env_is("PMR_OVERLAP", "0");
-    w->be_prio = env_is("PMR_STREAM_PRIO", "1");
+    w->be_prio = env_is("PMR_STREAM_PRIO", "1") ? 1 : env_is("PMR_STREAM_PRIO", "fe") ? 2 : 0;
     w->host_gate = !env_is("PMR_HOST_GATE", "0");
     w->fe_marker = env_is("PMR_FE_EVENT", "marker");
     w->no_zerocopy = env_is("PMR_ZEROCOPY", "0");
@@ -709,12 +709,14 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
     pmr_design_buffer_sizes(&q->d, cfg->max_block, &q->res_size, &q->chan_size);
     /* Stream priorities: equal by default.  Round 1 gave the back end the higher priority (its kernels then were bulky: 77 KB /
      * 45 KB of LDS per workgroup, and starved behind the front end's tiles).  With round 2's kernels that is neutral at cfg2 /
-     * cfg3 and costs 3.6 % at cfg5 (425 vs 440 GS/s, tools/env_ab.sh): PMR_STREAM_PRIO=1 restores it for A/B runs. */
+     * cfg3 and costs 3.6 % at cfg5 (425 vs 440 GS/s, tools/env_ab.sh): PMR_STREAM_PRIO=1 restores it for A/B runs.
+     * PMR_STREAM_PRIO=fe puts the FRONT-END stream high instead: +3 % at cfg3 (354 -> 364 GS/s), -1.7 % at cfg5, and at cfg2
+     * bimodal (regions of 0.191 and 0.21 ms; median 337 vs 343 GS/s) -- not a default. */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       /* numerically lower = higher priority */
-    if (!q->sw.be_prio) prio_hi = prio_lo;
-    if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+    int prio_be = q->sw.be_prio == 1 ? prio_hi : prio_lo, prio_fe = q->sw.be_prio == 2 ? prio_hi : prio_lo;
+    if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_be) != hipSuccess ||
+        hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_fe) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
     }
     if (hipEventCreateWithFlags(&q->ev_switch, hipEventDisableTiming) != hipSuccess ||

@@ -33,7 +33,7 @@ typedef struct {
     int fir_tpw;            /* PMR_FIR_TPW=1: one tile per workgroup in the MFMA FIR (default 2)            */
     int fir_nodual;         /* PMR_FIR_DUAL=0: CTCSS low-pass branch in a FIR pass of its own                */
     int no_overlap;         /* PMR_OVERLAP=0                                                                */
-    int be_prio;            /* PMR_STREAM_PRIO=1: back-end stream at the higher priority (round-1 default)  */
+    int be_prio;            /* PMR_STREAM_PRIO: unset = equal priorities, "1" = 1 back end high (round-1 default), "fe" = 2 front end high */
     int host_gate;          /* default on; PMR_HOST_GATE=0: ring-reuse gating by a wait packet on the front-end stream */
     unsigned zc_max_in;     /* PMR_ZEROCOPY_MAX=n: largest block (samples) a synchronous call reads in place from pinned host memory */
     int no_zerocopy;        /* PMR_ZEROCOPY=0: synchronous host calls always go through the copy engines (H2D / D2H) */
