@@ -116,6 +116,18 @@ def test_cfg5_1024_channels():
     _compare(fs, M, x, [1 << 24, 1 << 24], synth_ch=ks)
 
 
+@pytest.mark.parametrize("fs,M,n", [(819.2e6, 4096, 1 << 24), (409.6e6, 4096, 1 << 23), (102.4e6, 2048, 1 << 22), (6.4e6, 64, 1 << 20),
+                                    (1.6e6, 4, 1 << 18)],
+                         ids=["4096ch-h3", "4096ch-h2-no-six-tap-stage", "2048ch-generic-bank", "64ch", "4ch"])
+def test_other_channel_counts_up_to_the_maximum(fs, M, n):
+    """Runtime M (north_star): the largest bank the wide channelizer takes (M = 4096, LDS-resident 4096-point FFT), a power of two
+    that is not a power of four (generic bank), small banks; cascades with and without six-tap stages."""
+    ks = list(range(0, M, max(1, M // 24)))
+    x = synth.synth_iq(n, fs, M, channels=ks, dev_hz=500.0)
+    ro, _ = _compare(fs, M, x, [n // 2, n - n // 2], synth_ch=ks)
+    assert ro["n_frames"] > 60
+
+
 def test_reset_restarts_the_stream():
     from sdr_pmr446_amd import chain
     fs, M = CFG2
