@@ -124,6 +124,8 @@ struct pmr_chain_s {
     float *d_fe_G1;                  /* [..] fe1_K * mu^e: level 1's carry gain per tile-local index (level 2's load-time fix) */
     cfl *d_fe_ring1; uint64_t ring1_mask;
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
+    int tf_on_backend, pend_tf; unsigned pend_tf_Q;    /* one-level form: k_fe_tilefix deferred to the back-end stream (uses pend_t2 / pend_f2) */
+    int tf_last_be;                  /* the previous pipelined call's carry pass ran on the back-end stream */
     int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_tiles_params pend_t2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     /* persistent one-level kernel (k_fe_persist): ticket counters, published carry records, fallback flags */
@@ -641,6 +643,7 @@ static int chain_init(pmr_chain q)
     q->chan_wide = !q->sw.chan_generic && !q->chan_small && pmr_channelize_wide_supported(M, p, d->nco_period);
     if (q->chan_wide && (rc = dev_alloc(q, (void **)&q->d_chan_x, ((size_t)q->chan_size + 2) * M * sizeof(cfl)))) return rc;
     q->l2_on_backend = !q->sw.l2_on_fe;
+    q->tf_on_backend = 0;
 
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "init sync");
@@ -671,6 +674,7 @@ static void read_switches(pmr_switches *w)
     w->be_prio = env_is("PMR_STREAM_PRIO", "1") ? 1 : env_is("PMR_STREAM_PRIO", "fe") ? 2 : 0;
     w->host_gate = !env_is("PMR_HOST_GATE", "0");
     w->fe_marker = env_is("PMR_FE_EVENT", "marker");
+    w->tf_on_be = env_is("PMR_TILEFIX_STREAM", "be") ? 1 : env_is("PMR_TILEFIX_STREAM", "fe") ? 2 : 0;
     w->no_zerocopy = env_is("PMR_ZEROCOPY", "0");
     { const char *e = getenv("PMR_ZEROCOPY_MAX"); w->zc_max_in = e && atol(e) > 0 ? (unsigned)atol(e) : ZC_MAX_IN; }
 }
@@ -814,7 +818,7 @@ int pmr_chain_reset(pmr_chain q)
     }
     q->fe_sel = 0;
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
-    q->pend_l2 = 0;
+    q->pend_l2 = 0; q->pend_tf = 0; q->tf_last_be = 0;
     q->reset_pending = 0; memset(q->h_reset_flags, 0, M);
     HIPCHK(hipStreamSynchronize(q->stream_h2d), "reset");
     q->slot_head = 0; q->n_inflight = 0;                   /* blocks submitted but not collected are dropped */
@@ -1023,7 +1027,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
             p.GA = q->d_fe_GA; p.T1 = q->d_fe_T1; p.T2 = q->d_fe_T2; p.Kgain = q->fe_Kgain;
         }
         pmr_launch_events ev; prof_pending pe;
-        fe_launch_events(q, K_FE, 0, &ev, &pe);
+        fe_launch_events(q, K_FE, q->tf_on_backend && !q->fe_lb && ntiles != 0, &ev, &pe);
         LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic, &ev));
         prof_push(q, &pe);
     }
@@ -1034,7 +1038,11 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
     f.Kgain = q->fe_Kgain;
     /* persistent kernel: only the tiles it flagged (carry not available in time) are corrected here -- normally none */
-    {
+    if (q->tf_on_backend && !q->fe_persist && !q->fe_lb) {
+        /* PMR_TILEFIX_STREAM=be: the carry pass heads the back-end stream's work for this block; the front-end stream then
+         * carries front-end kernels only, back to back */
+        q->pend_t2 = t; q->pend_f2 = f; q->pend_tf_Q = Q; q->pend_tf = 1;
+    } else {
         pmr_launch_events ev; prof_pending pe;
         fe_launch_events(q, K_FE_TILEFIX, t.ntiles != 0, &ev, &pe);
         LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, (q->fe_persist || q->fe_lb) ? q->d_fe_fixflag : NULL, &ev));
@@ -1148,13 +1156,14 @@ int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsig
     plan_counts(q, n_in, &ny_plan, &ns_plan);
     if (ny_plan > q->res_size) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
     *xr_abs0 = q->xr_abs;
-    const int keep_l2 = q->l2_on_backend;
+    const int keep_l2 = q->l2_on_backend, keep_tf = q->tf_on_backend;
     q->l2_on_backend = 0;                         /* this entry point has no back-end stream: everything on stream_fe */
+    q->tf_on_backend = 0;
     q->sfe = q->stream_fe;
     q->fe_done_ev = NULL; q->fe_done_used = 0;
     int rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                        : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny);
-    q->l2_on_backend = keep_l2;
+    q->l2_on_backend = keep_l2; q->tf_on_backend = keep_tf;
     if (rc) return rc;
     if (ny != ny_plan) return fail(q, PMR_EINVAL, "internal: resampler count mismatch", hipSuccess);
     q->n_raw += n_in;
@@ -1375,6 +1384,23 @@ static int ring_to_linear(pmr_chain q, void *dst, const void *ring, uint64_t mas
     return PMR_OK;
 }
 
+/* Which stream carries the one-level form's carry pass (k_fe_tilefix, 0.022 ms + a kernel boundary)?  It only needs the block's
+ * front end before it and the channelizer after it, so it can close the front-end stream's work for the block or open the
+ * back-end stream's.  The two streams are balanced within a few per cent, so it belongs on the lighter one.  Front-end load per
+ * input sample is constant; back-end load grows with the resampled rate r = M * 12.5 kHz / fs_in and with the share of channels
+ * that are demodulated to audio (the FIR is ~3/4 of it; twice the work with the CTCSS detector on).  Measured on MI355X
+ * (tools/env_ab2.sh, 2^26-sample blocks):   cfg3 all channels (r = 0.052): 356 -> 378 GS/s on the back-end stream;
+ * cfg2 all channels (r = 0.083): 352 -> 317;   one open channel: cfg2 404 -> 422, cfg3 408 -> 415.
+ * PMR_TILEFIX_STREAM=be / =fe force it. */
+static int tilefix_on_backend(const pmr_chain q)
+{
+    if (q->sw.tf_on_be) return q->sw.tf_on_be == 1;
+    const double r = (double)q->M * q->cfg.channel_width_hz / q->cfg.fs_in;
+    const double f_open = q->mask_on ? (double)q->n_enabled / (double)q->M : 1.0;
+    const double load = r * (1.0 + 3.0 * f_open) * (q->ct_on ? 2.0 : 1.0);
+    return load < 0.25;
+}
+
 /* `single`: queue the whole block on ONE stream (no cross-stream events): what a caller that synchronises after every
  * block wants -- the two-stream pipeline only pays when consecutive blocks are in flight together. */
 static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
@@ -1421,6 +1447,12 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     }
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
+    if (q->fe_on && !q->fe_two && !q->fe_persist && !q->fe_lb) {
+        q->tf_on_backend = !single && tilefix_on_backend(q);
+        if (!single && !q->tf_on_backend && q->tf_last_be)    /* this block's carry pass reads the dc state the previous one (back-end stream) wrote */
+            HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[(par + PIPE_DEPTH - 1) % PIPE_DEPTH], 0), "wait previous carry pass");
+        q->tf_last_be = q->tf_on_backend;
+    }
     q->fe_done_ev = (single || q->sw.fe_marker) ? NULL : q->ev_fe[par];
     q->fe_done_used = 0;
     if ((rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
@@ -1435,6 +1467,10 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
 
     /* ---- back end on q->stream ---- */
     if (!single) HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
+    if (q->pend_tf) {
+        q->pend_tf = 0;
+        LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t2, &q->pend_f2, q->pend_tf_Q, NULL, NULL));
+    }
     if (q->pend_l2) {
         q->pend_l2 = 0;
         LAUNCH(K_FE_TILES, pmr_launch_fe_carry(q->stream, &q->pend_t2, &q->pend_f2));

@@ -37,6 +37,7 @@ typedef struct {
     int host_gate;          /* default on; PMR_HOST_GATE=0: ring-reuse gating by a wait packet on the front-end stream */
     unsigned zc_max_in;     /* PMR_ZEROCOPY_MAX=n: largest block (samples) a synchronous call reads in place from pinned host memory */
     int no_zerocopy;        /* PMR_ZEROCOPY=0: synchronous host calls always go through the copy engines (H2D / D2H) */
+    int tf_on_be;           /* PMR_TILEFIX_STREAM: unset = by load (pmr_chain.c tilefix_on_backend), "be" = 1 back-end stream, "fe" = 2 front-end stream */
     int fe_marker;          /* PMR_FE_EVENT=marker: "front end done" as a separate event-record packet (default: the last
                                front-end launch's own completion signal) */
 } pmr_switches;

@@ -117,6 +117,8 @@ CASES = [
     ({"PMR_FE_LOOKBACK": "1"}, CFG3, RAGGED3, False),       # look-back carry, fallback flags, blocks in flight
     ({"PMR_FE_EVENT": "marker"}, CFG2, RAGGED2, False),     # "front end done" as a record packet instead of the launch's own signal
     ({"PMR_STREAM_PRIO": "fe"}, CFG3, RAGGED3, False),      # front-end stream at the higher priority
+    ({"PMR_TILEFIX_STREAM": "be"}, CFG2, RAGGED2, True),    # carry pass at the head of the back-end stream (CTCSS on)
+    ({"PMR_TILEFIX_STREAM": "be"}, CFG3, RAGGED3, False),
     ({"PMR_HOST_GATE": "0"}, CFG5, RAGGED5, False),         # ring-reuse gating by a wait packet instead of the host
 ]
 

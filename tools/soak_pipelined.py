@@ -32,12 +32,21 @@ while time.time() < t_end:
         g._check(g._L.pmr_chain_ctcss_enable(g.h, 1))
     if spec:
         g.spectrum_enable(64)
-    if mask:
-        g.set_channel_mask([int(c) for c in rng.choice(M, size=min(M, 3), replace=False)])
+    mask0 = [int(c) for c in rng.choice(M, size=min(M, 3), replace=False)]
+
+    # the open-channel set changes in mid-stream in some cases (the carry pass of the one-level front end then changes streams)
+    toggles = {int(b): ([int(c) for c in rng.choice(M, size=min(M, int(rng.integers(1, 4))), replace=False)] if rng.integers(2) else None)
+               for b in rng.choice(nblk, size=int(rng.integers(0, 4)), replace=False)}
 
     def run(sync_each):
         pos, ns, extra = 0, [], []
+        if mask:
+            g.set_channel_mask(mask0)
+        else:
+            g.set_channel_mask(None)
         for b, n in enumerate(sizes):
+            if b in toggles:
+                g.set_channel_mask(toggles[b])
             ns.append(g.process_block_device(iq.ptr + pos * 8, n, d_pcm=outs[b].ptr, stride=S))
             pos += n
             if sync_each:
@@ -48,6 +57,8 @@ while time.time() < t_end:
         psd = g.spectrum_read() if spec else None
         return ns, pcm, ev, psd
 
+    for o in outs:
+        o.upload(np.zeros(M * S, np.int16))                   # rows of closed channels are left untouched by the chain
     pmr.device_synchronize()
     a = run(False)
     g.reset()
