@@ -3,12 +3,14 @@
  *   pmr446_file chan <in.cf32|-> <out.wav> [fs_in] [num_channels] [channel|-1] [waterfall]
  *       the block loop of src/sdr_pmr446.c:788-908: read a chunk (:789) -> pmr_chain_process_block_f32 -> squelch state
  *       machine on the GPU's RSSI (:828-874) -> float32 WAV at 12.5 kHz.  channel >= 0 writes that channel (mono, like
- *       the RtAudio sink :585); -1 writes all channels (multi-channel WAV).  waterfall = W > 0 (a power of two): the
+ *       the RtAudio sink :585) and, like the reference, demodulates ONLY that channel (:876-877) and logs its CTCSS tone
+ *       (ctcss_execute :605-628); -1 writes all channels (multi-channel WAV).  waterfall = W > 0 (a power of two): the
  *       reference's waterfall line per block (asgramcf of the resampled stream, :910-915) on stderr, W characters wide.
  *   pmr446_file dsd <in.cf32|-> <out.s16|-> [fs_in]
  *       the loop of src/dsd_in.c:159-179: s16le mono 48 kHz, ready for `dsd -i -`.
  *
  * Everything numerical happens in libpmr446_hip.so; this file is plumbing. */
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,6 +35,17 @@ static int run_chan(const char *in, const char *out, double fs, unsigned M, int 
     if (!r || !w || !iq || !audio || !rssi || !pcm) { fprintf(stderr, "pmr446_file: cannot open / allocate\n"); return 3; }
     pmr_squelch sq;
     pmr_squelch_init(&sq);
+    /* one channel selected: the reference's semantics -- only it is demodulated to audio, its CTCSS tone is tracked (:893) */
+    pmr_ctcss_event *ct = NULL; unsigned ct_cap = 0; int ct_on = 0, ct_code = -1;
+    if (only >= 0) {
+        uint64_t mask[64] = {0};
+        mask[(unsigned)only >> 6] = 1ull << ((unsigned)only & 63);
+        ct_cap = S / 2441 + 2;
+        ct = (pmr_ctcss_event *)malloc((size_t)M * ct_cap * sizeof(*ct));
+        if (!ct || (unsigned)only >= M || M > 4096 || pmr_chain_set_channel_mask(q, mask, (M + 63) / 64) || pmr_chain_ctcss_enable(q, 1)) {
+            fprintf(stderr, "pmr446_file: %s\n", pmr_chain_last_error(q)); return 3;
+        }
+    }
     float *psd = NULL; char *ascii = NULL;
     if (waterfall) {                                                                  /* :473-477 */
         psd = (float *)malloc((size_t)4 * waterfall * sizeof(float)); ascii = (char *)malloc(waterfall + 1);
@@ -49,6 +62,17 @@ static int run_chan(const char *in, const char *out, double fs, unsigned M, int 
                         sq.active_chan + 1, sq.rssi);
         rc = pmr_wav_writer_write_f32(w, only >= 0 ? audio + (size_t)only * S : audio, ns, S);
         if (rc) break;
+        if (ct) {                                                                     /* the log lines of ctcss_execute, :613-626 */
+            unsigned nev = 0;
+            if ((rc = pmr_chain_ctcss_read(q, ct, ct_cap, &nev))) break;
+            for (unsigned e = 0; e < nev; e++) {
+                const pmr_ctcss_event *v = &ct[(size_t)only * ct_cap + e];
+                if (v->detected && !ct_on) fprintf(stderr, "Acquired CTCSS code: %d (frequency: %3.2fHz)\n", v->index + 1, pmr_ctcss_freq(v->index));
+                else if (v->detected && v->index != ct_code) fprintf(stderr, "CTCSS code change: %d (frequency: %3.2fHz)\n", v->index + 1, pmr_ctcss_freq(v->index));
+                else if (!v->detected && ct_on) fprintf(stderr, "Lost CTCSS code\n");
+                ct_on = v->detected; ct_code = v->index;
+            }
+        }
         if (waterfall) {                                                              /* :910-915 */
             unsigned ntr = 0; float maxval = 0.f, maxfreq = 0.f;
             if ((rc = pmr_chain_spectrum_read(q, psd, 4 * waterfall, &ntr))) break;
@@ -59,7 +83,7 @@ static int run_chan(const char *in, const char *out, double fs, unsigned M, int 
     }
     fprintf(stderr, "pmr446_file: %lu blocks, %lu frames per channel\n", blocks, frames);
     pmr_wav_writer_close(w); pmr_iq_reader_close(r); pmr_chain_destroy(q);
-    free(iq); free(audio); free(rssi); free(pcm); free(psd); free(ascii);
+    free(iq); free(audio); free(rssi); free(pcm); free(psd); free(ascii); free(ct);
     return rc || n < 0 ? 1 : 0;
 }
 

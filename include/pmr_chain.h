@@ -175,6 +175,8 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on);
 /* events of the LAST process_block call: events[k * cap + e], e < *n_events (same count for every channel).
  * Synchronises the chain's streams.                                                                       */
 int pmr_chain_ctcss_read(pmr_chain q, pmr_ctcss_event *events, unsigned cap, unsigned *n_events);
+/* frequency in Hz of tone `index` (0..37: ctcss_freqs, src/sdr_pmr446.c:138-141; what :611 stores in chain->ctcss_freq), 0 outside */
+float pmr_ctcss_freq(int index);
 
 /* ---- the waterfall line -- asgramcf of the resampled stream (asgramcf_create(width) +
  * set_scale(-40, 2) src/sdr_pmr446.c:473-477; asgramcf_write(resamp_buf, ny) + asgramcf_execute per block :911-912).

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
     "pmr_chain_spectrum_enable", "pmr_chain_spectrum_read", "pmr_asgram_ascii",
-    "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read", "pmr_chain_set_channel_mask", "pmr_chain_reset_channel",
+    "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read", "pmr_ctcss_freq", "pmr_chain_set_channel_mask", "pmr_chain_reset_channel",
     "pmr_chain_submit_block", "pmr_chain_submit_block_fmt", "pmr_chain_collect_block", "pmr_chain_blocks_in_flight", "pmr_chain_max_in_flight",
     "pmr_host_alloc", "pmr_host_free", "pmr_chain_wait_input_event", "pmr_chain_synchronize_input",
     # include/pmr_mem.h
@@ -193,6 +193,8 @@ def load(build_if_missing=True):
     L.pmr_chain_ctcss_enable.restype = i
     L.pmr_chain_ctcss_read.argtypes = [vp, vp, u, C.POINTER(u)]
     L.pmr_chain_ctcss_read.restype = i
+    L.pmr_ctcss_freq.argtypes = [i]
+    L.pmr_ctcss_freq.restype = C.c_float
     L.pmr_chain_spectrum_enable.argtypes = [vp, u]
     L.pmr_chain_spectrum_enable.restype = i
     L.pmr_chain_spectrum_read.argtypes = [vp, vp, u, C.POINTER(u)]

@@ -1355,6 +1355,8 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on)
     return PMR_OK;
 }
 
+float pmr_ctcss_freq(int index) { return index >= 0 && index < (int)PMR_CT_TONES ? pmr446_ctcss_freqs[index] : 0.0f; }
+
 int pmr_chain_ctcss_read(pmr_chain q, pmr_ctcss_event *events, unsigned cap, unsigned *n_events)
 {
     if (!q || !q->d_ct_events) return PMR_EINVAL;

@@ -87,7 +87,10 @@ def test_headless_harness_end_to_end(tmp_path):
     x = synth.synth_iq(n, fs, M)
     (tmp_path / "in.cf32").write_bytes(x.tobytes())
     subprocess.run([exe, "chan", str(tmp_path / "in.cf32"), str(tmp_path / "all.wav"), str(fs), str(M), "-1"], check=True)
-    subprocess.run([exe, "chan", str(tmp_path / "in.cf32"), str(tmp_path / "ch2.wav"), str(fs), str(M), "2"], check=True)
+    r2 = subprocess.run([exe, "chan", str(tmp_path / "in.cf32"), str(tmp_path / "ch2.wav"), str(fs), str(M), "2"], check=True,
+                        capture_output=True, text=True)
+    # one channel selected = the reference's mode: only it is demodulated, its CTCSS tone is logged like ctcss_execute does (:613-626)
+    assert "Acquired CTCSS code: 3 (frequency: %3.2fHz)" % chain.load().pmr_ctcss_freq(2) in r2.stderr, r2.stderr[-300:]
     ch = chain.PmrChain(fs_in=fs, num_channels=M, max_block=100000)
     audio = np.concatenate([ch.process_block(x[i:i + 100000], want=("pcm", "audio"))["audio"] for i in range(0, n, 100000)], axis=1)
     rate, data = wavfile.read(str(tmp_path / "all.wav"))
