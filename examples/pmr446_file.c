@@ -6,6 +6,11 @@
  *       the RtAudio sink :585) and, like the reference, demodulates ONLY that channel (:876-877) and logs its CTCSS tone
  *       (ctcss_execute :605-628); -1 writes all channels (multi-channel WAV).  waterfall = W > 0 (a power of two): the
  *       reference's waterfall line per block (asgramcf of the resampled stream, :910-915) on stderr, W characters wide.
+ *   pmr446_file scan <in.cf32|-> <out.wav> [fs_in] [num_channels]
+ *       the reference's own behaviour end to end: the squelch state machine (:828-874) on the GPU's RSSI picks the active
+ *       channel, ONLY that channel is demodulated (channel mask, :876-877), its discriminator / CTCSS state is reset when the
+ *       squelch closes (:866-867), mono float32 WAV of whatever channel is open (silence is not written, like :903-906).  The
+ *       mask follows the decision taken on the PREVIOUS block's RSSI (the reference decides and demodulates within one block).
  *   pmr446_file dsd <in.cf32|-> <out.s16|-> [fs_in]
  *       the loop of src/dsd_in.c:159-179: s16le mono 48 kHz, ready for `dsd -i -`.
  *
@@ -87,6 +92,51 @@ static int run_chan(const char *in, const char *out, double fs, unsigned M, int 
     return rc || n < 0 ? 1 : 0;
 }
 
+static int run_scan(const char *in, const char *out, double fs, unsigned M)
+{
+    pmr_chain_cfg cfg;
+    pmr_chain_default_cfg(&cfg);
+    cfg.fs_in = fs; cfg.num_channels = M;
+    pmr_chain q = pmr_chain_create(&cfg);
+    if (!q || M > 4096) return 2;
+    const unsigned S = pmr_chain_max_frames(q), W = (M + 63) / 64;
+    pmr_iq_reader r = pmr_iq_reader_open(in, PMR_IQ_CF32);
+    pmr_wav_writer w = pmr_wav_writer_open(out, PMR_WAV_F32, (unsigned)cfg.channel_width_hz, 1);
+    pmr_cf32 *iq = (pmr_cf32 *)malloc((size_t)cfg.max_block * sizeof(pmr_cf32));
+    float *audio = (float *)malloc((size_t)M * S * sizeof(float)), *rssi = (float *)malloc(M * sizeof(float));
+    int16_t *pcm = (int16_t *)malloc((size_t)M * S * sizeof(int16_t));
+    if (!r || !w || !iq || !audio || !rssi || !pcm) { fprintf(stderr, "pmr446_file: cannot open / allocate\n"); return 3; }
+    uint64_t mask[64] = {0};
+    int rc = pmr_chain_set_channel_mask(q, mask, W);                                    /* scanning: nothing is demodulated */
+    pmr_squelch sq;
+    pmr_squelch_init(&sq);
+    int n;
+    unsigned long blocks = 0, frames = 0;
+    while (!rc && (n = pmr_iq_reader_read(r, iq, cfg.max_block)) > 0) {                 /* :789 */
+        unsigned ns = 0;
+        const int open_chan = sq.state == PMR_TUNED ? sq.active_chan : -1;              /* decided on the previous block */
+        rc = pmr_chain_process_block_f32(q, iq, (unsigned)n, pcm, audio, S, &ns, NULL, rssi);
+        if (rc) { fprintf(stderr, "pmr446_file: %s\n", pmr_chain_last_error(q)); break; }
+        if (open_chan >= 0) { rc = pmr_wav_writer_write_f32(w, audio + (size_t)open_chan * S, ns, S); frames += ns; }   /* :903-906 */
+        if (pmr_squelch_update(&sq, rssi, M, ~0ull, 18.0f, 0)) {                        /* :828-874 */
+            memset(mask, 0, sizeof(mask));
+            if (sq.state == PMR_TUNED) {
+                mask[(unsigned)sq.active_chan >> 6] = 1ull << ((unsigned)sq.active_chan & 63);
+                fprintf(stderr, "block %lu: tuned to channel %d (%.1f dB)\n", blocks, sq.active_chan + 1, sq.rssi);
+            } else {
+                fprintf(stderr, "block %lu: left channel %d\n", blocks, open_chan + 1);
+                if (open_chan >= 0 && !rc) rc = pmr_chain_reset_channel(q, (unsigned)open_chan);      /* :866-867 */
+            }
+            if (!rc) rc = pmr_chain_set_channel_mask(q, mask, W);
+        }
+        blocks++;
+    }
+    fprintf(stderr, "pmr446_file: %lu blocks, %lu audio frames written\n", blocks, frames);
+    pmr_wav_writer_close(w); pmr_iq_reader_close(r); pmr_chain_destroy(q);
+    free(iq); free(audio); free(rssi); free(pcm);
+    return rc ? 1 : 0;
+}
+
 static int run_dsd(const char *in, const char *out, double fs)
 {
     pmr_dsd_cfg cfg;
@@ -117,9 +167,12 @@ int main(int argc, char **argv)
     if (argc >= 4 && !strcmp(argv[1], "chan"))
         return run_chan(argv[2], argv[3], argc > 4 ? atof(argv[4]) : 1024000.0, argc > 5 ? (unsigned)atoi(argv[5]) : 16,
                         argc > 6 ? atoi(argv[6]) : -1, argc > 7 ? (unsigned)atoi(argv[7]) : 0);
+    if (argc >= 4 && !strcmp(argv[1], "scan"))
+        return run_scan(argv[2], argv[3], argc > 4 ? atof(argv[4]) : 1024000.0, argc > 5 ? (unsigned)atoi(argv[5]) : 16);
     if (argc >= 4 && !strcmp(argv[1], "dsd"))
         return run_dsd(argv[2], argv[3], argc > 4 ? atof(argv[4]) : 1024000.0);
     fprintf(stderr, "usage: %s chan <in.cf32|-> <out.wav> [fs_in] [num_channels] [channel|-1] [waterfall]\n"
-                    "       %s dsd  <in.cf32|-> <out.s16|-> [fs_in]\n", argv[0], argv[0]);
+                    "       %s scan <in.cf32|-> <out.wav> [fs_in] [num_channels]\n"
+                    "       %s dsd  <in.cf32|-> <out.s16|-> [fs_in]\n", argv[0], argv[0], argv[0]);
     return 64;
 }

@@ -118,3 +118,26 @@ def test_headless_harness_end_to_end(tmp_path):
     d = chain.PmrDsd()
     pcm = np.concatenate([d.process_block(xd[i:i + 200000])["pcm"] for i in range(0, 450000, 200000)])
     assert np.array_equal(np.fromfile(str(tmp_path / "d.s16"), dtype="<i2"), pcm)
+
+
+@pytest.mark.gpu
+def test_scan_mode_follows_the_squelch(tmp_path):
+    """examples/pmr446_file.c scan = the reference's loop end to end (squelch state machine :828-874 on the GPU's RSSI, only the
+    open channel demodulated :876-877, reset on detune :866-867): noise, then a carrier on channel 5, then noise again."""
+    from sdr_pmr446_amd import build
+    exe = build.build_example()
+    fs, M, nb = 1.024e6, 16, 100000
+    quiet = lambda n, sid: synth.synth_iq(n, fs, M, stream_id=sid, channels=[])
+    x = np.concatenate([quiet(3 * nb, 1), synth.synth_iq(5 * nb, fs, M, stream_id=2, channels=[5], dev_hz=1500.0), quiet(3 * nb, 3)])
+    (tmp_path / "in.cf32").write_bytes(x.tobytes())
+    r = subprocess.run([exe, "scan", str(tmp_path / "in.cf32"), str(tmp_path / "scan.wav"), str(fs), str(M)], check=True,
+                       capture_output=True, text=True)
+    log = r.stderr
+    assert "block 3: tuned to channel 6" in log, log[-400:]            # first block that carries the signal
+    assert "block 8: left channel 6" in log, log[-400:]                # first quiet block after it
+    rate, data = wavfile.read(str(tmp_path / "scan.wav"))
+    # the mask follows the decision of the previous block: blocks 4..8 are written (block 8 still with the old decision)
+    ch = chain.PmrChain(fs_in=fs, num_channels=M, max_block=nb)
+    frames = [ch.process_block(x[i:i + nb], want=("pcm",))["n_frames"] for i in range(0, len(x), nb)]
+    assert rate == 12500 and len(data) == sum(frames[4:9])
+    assert np.abs(data[2000:len(data) - frames[8]]).max() > 0.05        # audible audio while the carrier is there
