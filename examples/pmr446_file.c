@@ -9,8 +9,9 @@
  *   pmr446_file scan <in.cf32|-> <out.wav> [fs_in] [num_channels]
  *       the reference's own behaviour end to end: the squelch state machine (:828-874) on the GPU's RSSI picks the active
  *       channel, ONLY that channel is demodulated (channel mask, :876-877), its discriminator / CTCSS state is reset when the
- *       squelch closes (:866-867), mono float32 WAV of whatever channel is open (silence is not written, like :903-906).  The
- *       mask follows the decision taken on the PREVIOUS block's RSSI (the reference decides and demodulates within one block).
+ *       squelch closes (:866-867), mono float32 WAV of whatever channel is open (silence is not written, like :903-906).  Like
+ *       the reference it decides on a block's channelizer output and demodulates that same block: pmr_chain_channelize_block,
+ *       squelch update, pmr_chain_demodulate_block.
  *   pmr446_file dsd <in.cf32|-> <out.s16|-> [fs_in]
  *       the loop of src/dsd_in.c:159-179: s16le mono 48 kHz, ready for `dsd -i -`.
  *
@@ -114,21 +115,23 @@ static int run_scan(const char *in, const char *out, double fs, unsigned M)
     unsigned long blocks = 0, frames = 0;
     while (!rc && (n = pmr_iq_reader_read(r, iq, cfg.max_block)) > 0) {                 /* :789 */
         unsigned ns = 0;
-        const int open_chan = sq.state == PMR_TUNED ? sq.active_chan : -1;              /* decided on the previous block */
-        rc = pmr_chain_process_block_f32(q, iq, (unsigned)n, pcm, audio, S, &ns, NULL, rssi);
+        rc = pmr_chain_channelize_block(q, iq, (unsigned)n, &ns, NULL, 0, rssi);        /* :795-823 + average_power */
         if (rc) { fprintf(stderr, "pmr446_file: %s\n", pmr_chain_last_error(q)); break; }
-        if (open_chan >= 0) { rc = pmr_wav_writer_write_f32(w, audio + (size_t)open_chan * S, ns, S); frames += ns; }   /* :903-906 */
+        const int was = sq.state == PMR_TUNED ? sq.active_chan : -1;
         if (pmr_squelch_update(&sq, rssi, M, ~0ull, 18.0f, 0)) {                        /* :828-874 */
             memset(mask, 0, sizeof(mask));
             if (sq.state == PMR_TUNED) {
                 mask[(unsigned)sq.active_chan >> 6] = 1ull << ((unsigned)sq.active_chan & 63);
                 fprintf(stderr, "block %lu: tuned to channel %d (%.1f dB)\n", blocks, sq.active_chan + 1, sq.rssi);
             } else {
-                fprintf(stderr, "block %lu: left channel %d\n", blocks, open_chan + 1);
-                if (open_chan >= 0 && !rc) rc = pmr_chain_reset_channel(q, (unsigned)open_chan);      /* :866-867 */
+                fprintf(stderr, "block %lu: left channel %d\n", blocks, was + 1);
+                if (was >= 0) rc = pmr_chain_reset_channel(q, (unsigned)was);          /* :866-867 */
             }
             if (!rc) rc = pmr_chain_set_channel_mask(q, mask, W);
         }
+        if (!rc) rc = pmr_chain_demodulate_block(q, pcm, audio, S, &ns);                /* :876-902, the channel open NOW */
+        if (rc) { fprintf(stderr, "pmr446_file: %s\n", pmr_chain_last_error(q)); break; }
+        if (sq.state == PMR_TUNED) { rc = pmr_wav_writer_write_f32(w, audio + (size_t)sq.active_chan * S, ns, S); frames += ns; }   /* :903-906 */
         blocks++;
     }
     fprintf(stderr, "pmr446_file: %lu blocks, %lu audio frames written\n", blocks, frames);

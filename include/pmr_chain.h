@@ -84,6 +84,18 @@ int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in,
                                 int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames,
                                 pmr_cf32 *chan_out, float *rssi_db);
 
+/* Two-step synchronous form, for a squelch that decides on THIS block before it is demodulated -- the reference's order: state
+ * machine on chan_bufs (:828-874), then freqdem .. audio of the active channel (:876-906).  pmr_chain_channelize_block runs the
+ * block up to channelizer / discriminator / RSSI (chan_out, rssi_db: as in pmr_chain_process_block); the caller updates
+ * pmr_chain_set_channel_mask / pmr_chain_reset_channel; pmr_chain_demodulate_block then runs the audio part (high-pass ..
+ * PCM, CTCSS branch) of that same block for the channels open NOW.  With an unchanged mask the pair returns exactly what
+ * pmr_chain_process_block_f32 returns.  A channelized block that is never demodulated is still pushed through the stateful
+ * audio stages (CTCSS detector, follow-on FIR passes) by the next call. */
+int   pmr_chain_channelize_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, unsigned *n_frames,
+                                 pmr_cf32 *chan_out /*nullable [M][chan_stride]*/, unsigned chan_stride, float *rssi_db /*nullable [M]*/);
+int   pmr_chain_demodulate_block(pmr_chain q, int16_t *pcm /*nullable*/, float *audio /*nullable*/, unsigned pcm_stride,
+                                 unsigned *n_frames);
+
 /* Asynchronous host-buffer pair: the call pattern of the reference's loop (one readStream block per iteration,
  * src/sdr_pmr446.c:789-796) with the sink one or two blocks behind.  submit queues H2D copy -> chain -> D2H copy of one block
  * and returns at once; collect waits for the OLDEST submitted block and hands over its outputs (arguments as for

@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
     "pmr_chain_spectrum_enable", "pmr_chain_spectrum_read", "pmr_asgram_ascii",
+    "pmr_chain_channelize_block", "pmr_chain_demodulate_block",
     "pmr_chain_ctcss_enable", "pmr_chain_ctcss_read", "pmr_ctcss_freq", "pmr_chain_set_channel_mask", "pmr_chain_reset_channel",
     "pmr_chain_submit_block", "pmr_chain_submit_block_fmt", "pmr_chain_collect_block", "pmr_chain_blocks_in_flight", "pmr_chain_max_in_flight",
     "pmr_host_alloc", "pmr_host_free", "pmr_chain_wait_input_event", "pmr_chain_synchronize_input",
@@ -193,6 +194,10 @@ def load(build_if_missing=True):
     L.pmr_chain_ctcss_enable.restype = i
     L.pmr_chain_ctcss_read.argtypes = [vp, vp, u, C.POINTER(u)]
     L.pmr_chain_ctcss_read.restype = i
+    L.pmr_chain_channelize_block.argtypes = [vp, vp, u, C.POINTER(u), vp, u, vp]
+    L.pmr_chain_channelize_block.restype = i
+    L.pmr_chain_demodulate_block.argtypes = [vp, vp, vp, u, C.POINTER(u)]
+    L.pmr_chain_demodulate_block.restype = i
     L.pmr_ctcss_freq.argtypes = [i]
     L.pmr_ctcss_freq.restype = C.c_float
     L.pmr_chain_spectrum_enable.argtypes = [vp, u]
@@ -537,6 +542,38 @@ class PmrChain:
         n = C.c_uint(0)
         self._check(self._L.pmr_chain_ctcss_read(self.h, ev.ctypes.data, cap, C.byref(n)))
         return ev[:, :n.value].copy()
+
+    # -- two-step form: squelch decision on THIS block before it is demodulated (reference :828-877) -----
+    def channelize_block(self, iq, want=("rssi",)):
+        """Front end + channelizer + discriminator + RSSI of one block; the audio part stays pending.  Returns n_frames + rssi / chan."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        M, S = self.M, self.max_frames
+        rssi = np.zeros(M, dtype=np.float32) if "rssi" in want else None
+        chan = np.zeros((M, S), dtype=np.complex64) if "chan" in want else None
+        ns = C.c_uint(0)
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        self._check(self._L.pmr_chain_channelize_block(self.h, iq.ctypes.data if len(iq) else None, len(iq), C.byref(ns), ptr(chan), S, ptr(rssi)))
+        out = {"n_frames": ns.value}
+        if rssi is not None:
+            out["rssi"] = rssi
+        if chan is not None:
+            out["chan"] = chan[:, :ns.value].copy()
+        return out
+
+    def demodulate_block(self, want=("pcm",)):
+        """Audio part of the block channelized last, for the channels the mask has open now."""
+        M, S = self.M, self.max_frames
+        pcm = np.zeros((M, S), dtype=np.int16) if "pcm" in want else None
+        audio = np.zeros((M, S), dtype=np.float32) if "audio" in want else None
+        ns = C.c_uint(0)
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        self._check(self._L.pmr_chain_demodulate_block(self.h, ptr(pcm), ptr(audio), S, C.byref(ns)))
+        out = {"n_frames": ns.value}
+        if pcm is not None:
+            out["pcm"] = pcm[:, :ns.value].copy()
+        if audio is not None:
+            out["audio"] = audio[:, :ns.value].copy()
+        return out
 
     # -- waterfall line (SURVEY s8 f4; reference src/sdr_pmr446.c:473-477, :911-915) -----------------
     def spectrum_enable(self, nfft):

@@ -126,6 +126,8 @@ struct pmr_chain_s {
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
     int tf_on_backend, pend_tf; unsigned pend_tf_Q;    /* one-level form: k_fe_tilefix deferred to the back-end stream (uses pend_t2 / pend_f2) */
     int tf_last_be;                  /* the previous pipelined call's carry pass ran on the back-end stream */
+    /* two-step synchronous form (pmr_chain_channelize_block / _demodulate_block): the audio part of the block channelized last */
+    int pend_audio; int64_t pend_audio_frame0; unsigned pend_audio_ns;
     int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_tiles_params pend_t2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
     /* persistent one-level kernel (k_fe_persist): ticket counters, published carry records, fallback flags */
@@ -818,7 +820,7 @@ int pmr_chain_reset(pmr_chain q)
     }
     q->fe_sel = 0;
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
-    q->pend_l2 = 0; q->pend_tf = 0; q->tf_last_be = 0;
+    q->pend_l2 = 0; q->pend_tf = 0; q->tf_last_be = 0; q->pend_audio = 0;
     q->reset_pending = 0; memset(q->h_reset_flags, 0, M);
     HIPCHK(hipStreamSynchronize(q->stream_h2d), "reset");
     q->slot_head = 0; q->n_inflight = 0;                   /* blocks submitted but not collected are dropped */
@@ -1386,6 +1388,56 @@ static int ring_to_linear(pmr_chain q, void *dst, const void *ring, uint64_t mas
     return PMR_OK;
 }
 
+/* Audio part of one block (frames frame0 .. frame0 + ns of the discriminator ring): HP (:882) -> gain (:890) -> de-emphasis
+ * (:895-899) -> optional LP (:900-902) -> sink (:903-906), the CTCSS branch when the detector is on -- for the channels the
+ * mask has open NOW. */
+static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, void *d_audio, unsigned pcm_stride)
+{
+    const unsigned M = q->M;
+    int rc;
+    /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906); with the CTCSS
+     * detector on, its low-pass branch delay188(x) - hp(x) (:884-889) is a second tap set over the same samples: one pass */
+    int ct_fir_done = 0;
+    if (q->ct_on && q->d_ct_taps_ext && !q->sw.fir_nodual && (d_pcm || d_audio) && !q->cfg.deemph_fir && !q->cfg.lowpass) {
+        prof_pending pp_; prof_begin(q, K_FIR_HP, &pp_, q->stream);
+        const int rd = pmr_launch_fir_dual(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->d_ct_taps_ext,
+                                           q->hp_len, (int16_t *)d_pcm, (float *)d_audio, pcm_stride, q->d_ctlp,
+                                           q->mask_on ? q->d_chan_list : NULL, q->n_enabled);
+        prof_end(q, &pp_, q->stream);
+        if (rd > 0) return fail(q, PMR_EHIP, k_names[K_FIR_HP], (hipError_t)rd);
+        ct_fir_done = rd == 0;
+    }
+    if (q->ct_on && (rc = ctcss_run(q, frame0, ns, ct_fir_done))) return rc;
+
+    if (!ct_fir_done && (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass)) {
+        const int more = q->cfg.deemph_fir || q->cfg.lowpass;
+        /* only the open channels are demodulated to audio.  With follow-on FIR passes (deemph_fir / lowpass) the mask
+         * applies to the LAST pass only: the intermediate rings must keep every channel's history current, or a channel
+         * opened later would start from a cold filter */
+        const unsigned *sel = q->mask_on ? q->d_chan_list : NULL;
+        LAUNCH(K_FIR_HP, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
+                                           1.0f, 0, 0.f, 0.f, 0.f,      /* gain + de-emphasis are in the taps */
+                                           more ? q->d_aux1 : NULL, more ? NULL : (int16_t *)d_pcm,
+                                           more ? NULL : (float *)d_audio, pcm_stride, more ? NULL : sel, q->n_enabled));
+        const float *cur = q->d_aux1;
+        const int sink = d_pcm || d_audio;                 /* (none: a pending block is only pushed through the stateful passes) */
+        if (q->cfg.deemph_fir && (sink || q->cfg.lowpass)) {
+            const int last = !q->cfg.lowpass;
+            LAUNCH(K_FIR_DE, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
+                                               1.0f, 0, 0.f, 0.f, 0.f, last ? NULL : q->d_aux2,
+                                               last ? (int16_t *)d_pcm : NULL, last ? (float *)d_audio : NULL,
+                                               pcm_stride, last ? sel : NULL, q->n_enabled));
+            cur = q->d_aux2;
+        }
+        if (q->cfg.lowpass && sink) {
+            LAUNCH(K_FIR_LP, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
+                                               1.0f, 0, 0.f, 0.f, 0.f, NULL, (int16_t *)d_pcm, (float *)d_audio,
+                                               pcm_stride, sel, q->n_enabled));
+        }
+    }
+    return PMR_OK;
+}
+
 /* Which stream carries the one-level form's carry pass (k_fe_tilefix, 0.022 ms + a kernel boundary)?  It only needs the block's
  * front end before it and the channelizer after it, so it can close the front-end stream's work for the block or open the
  * back-end stream's.  The two streams are balanced within a few per cent, so it belongs on the lighter one.  Front-end load per
@@ -1406,9 +1458,20 @@ static int tilefix_on_backend(const pmr_chain q)
 /* `single`: queue the whole block on ONE stream (no cross-stream events): what a caller that synchronises after every
  * block wants -- the two-stream pipeline only pays when consecutive blocks are in flight together. */
 static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
-                                     unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db, int single)
+                                     unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db, int single,
+                                     int phase /*0: whole block; 1: up to channelizer + RSSI, audio part left pending*/)
 {
     if (!q) return PMR_EINVAL;
+    if (phase == 1 && !single) return fail(q, PMR_EINVAL, "two-step form is synchronous", hipSuccess);
+    if (q->pend_audio) {
+        /* a channelized block was never demodulated: filters that carry state of their own through the audio part (CTCSS
+         * detector, follow-on FIR passes) must still see it */
+        q->pend_audio = 0;
+        if (q->ct_on || q->cfg.deemph_fir || q->cfg.lowpass) {
+            int rc_ = audio_part(q, q->pend_audio_frame0, q->pend_audio_ns, NULL, NULL, 0);
+            if (rc_) return rc_;
+        }
+    }
     if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
     if (n_in && !d_iq) return fail(q, PMR_EINVAL, "null input", hipSuccess);
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
@@ -1517,46 +1580,9 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
         if (d_rssi_db)
             LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->d_rssi_part, ntiles, M, ns, (float *)d_rssi_db));
 
-        /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906); with the CTCSS
-         * detector on, its low-pass branch delay188(x) - hp(x) (:884-889) is a second tap set over the same samples: one pass */
-        int ct_fir_done = 0;
-        if (q->ct_on && q->d_ct_taps_ext && !q->sw.fir_nodual && (d_pcm || d_audio) && !q->cfg.deemph_fir && !q->cfg.lowpass) {
-            prof_pending pp_; prof_begin(q, K_FIR_HP, &pp_, q->stream);
-            const int rd = pmr_launch_fir_dual(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->d_ct_taps_ext,
-                                               q->hp_len, (int16_t *)d_pcm, (float *)d_audio, pcm_stride, q->d_ctlp,
-                                               q->mask_on ? q->d_chan_list : NULL, q->n_enabled);
-            prof_end(q, &pp_, q->stream);
-            if (rd > 0) return fail(q, PMR_EHIP, k_names[K_FIR_HP], (hipError_t)rd);
-            ct_fir_done = rd == 0;
-        }
-        if (q->ct_on && (rc = ctcss_run(q, frame0, ns, ct_fir_done))) return rc;
-
-        if (!ct_fir_done && (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass)) {
-            const int more = q->cfg.deemph_fir || q->cfg.lowpass;
-            /* only the open channels are demodulated to audio.  With follow-on FIR passes (deemph_fir / lowpass) the mask
-             * applies to the LAST pass only: the intermediate rings must keep every channel's history current, or a channel
-             * opened later would start from a cold filter */
-            const unsigned *sel = q->mask_on ? q->d_chan_list : NULL;
-            LAUNCH(K_FIR_HP, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
-                                               1.0f, 0, 0.f, 0.f, 0.f,      /* gain + de-emphasis are in the taps */
-                                               more ? q->d_aux1 : NULL, more ? NULL : (int16_t *)d_pcm,
-                                               more ? NULL : (float *)d_audio, pcm_stride, more ? NULL : sel, q->n_enabled));
-            const float *cur = q->d_aux1;
-            if (q->cfg.deemph_fir) {
-                const int last = !q->cfg.lowpass;
-                LAUNCH(K_FIR_DE, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
-                                                   1.0f, 0, 0.f, 0.f, 0.f, last ? NULL : q->d_aux2,
-                                                   last ? (int16_t *)d_pcm : NULL, last ? (float *)d_audio : NULL,
-                                                   pcm_stride, last ? sel : NULL, q->n_enabled));
-                cur = q->d_aux2;
-            }
-            if (q->cfg.lowpass) {
-                LAUNCH(K_FIR_LP, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
-                                                   1.0f, 0, 0.f, 0.f, 0.f, NULL, (int16_t *)d_pcm, (float *)d_audio,
-                                                   pcm_stride, sel, q->n_enabled));
-            }
-        }
+        if (phase != 1 && (rc = audio_part(q, frame0, ns, d_pcm, d_audio, pcm_stride))) return rc;
     }
+    if (phase == 1) { q->pend_audio = 1; q->pend_audio_frame0 = frame0; q->pend_audio_ns = ns; }
     q->frames_done += ns;
     if (!single) HIPCHK(hipEventRecord(q->ev_be[par], q->stream), "record");
     q->n_calls++;
@@ -1567,7 +1593,7 @@ int pmr_chain_process_block_device(pmr_chain q, const void *d_iq, unsigned n_in,
                                    unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db)
 {
     return process_block_device_impl(q, d_iq, n_in, d_pcm, d_audio, pcm_stride, n_frames, d_chan_out, d_rssi_db,
-                                     q ? !q->overlap : 0);
+                                     q ? !q->overlap : 0, 0);
 }
 
 /* ---- host-buffer entry points ---------------------------------------------------------------------------------
@@ -1615,7 +1641,7 @@ static const void *host_zero_copy(const void *p, size_t bytes);
  * Synchronous calls on SMALL blocks skip both copy engines (each copy is a submission of its own with ~10 us of hand-over on
  * either side, 100 us -> 70 us per 100 000-sample call): the front end reads the caller's pinned buffer in place and the last
  * kernels write the slot's pinned output buffer directly (PMR_ZEROCOPY=0 restores the copies). */
-static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigned n_in, unsigned want, int single)
+static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigned n_in, unsigned want, int single, int phase)
 {
     pmr_slot *sl = &q->slot[i];
     int rc = slot_prepare(q, i, (want & PMR_WANT_CHAN) != 0);
@@ -1657,7 +1683,7 @@ static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigne
     rc = process_block_device_impl(q, d_iq, n_in, (want & PMR_WANT_PCM) ? o_out + sl->off_pcm : NULL,
                                    (want & PMR_WANT_AUDIO) ? o_out + sl->off_audio : NULL, stride, &ns,
                                    (want & PMR_WANT_CHAN) ? (zc_out ? sl->hd_chan : sl->d_chan) : NULL,
-                                   (want & PMR_WANT_RSSI) ? o_out : NULL, single);
+                                   (want & PMR_WANT_RSSI) ? o_out : NULL, single, phase);
     if (rc) return rc;
     sl->ns = ns; sl->stride = stride; sl->want = want;
     if (ns && !zc_out) {
@@ -1707,9 +1733,61 @@ int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, 
     if (ns_plan > pcm_stride && (pcm || audio || chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
     const unsigned want = ((pcm || audio) ? PMR_WANT_PCM : 0) | (audio ? PMR_WANT_AUDIO : 0) | (chan_out ? PMR_WANT_CHAN : 0) |
                           (rssi_db ? PMR_WANT_RSSI : 0);
-    int rc = slot_submit(q, 0, iq, 0, n_in, want, 1);
+    int rc = slot_submit(q, 0, iq, 0, n_in, want, 1, 0);
     if (rc) return rc;
     rc = slot_collect(q, 0, pcm, audio, pcm_stride, n_frames, chan_out, rssi_db);      /* waits for the block's last copy */
+    if (rc) return rc;
+    if (q->prof_on) prof_resolve(q);
+    return PMR_OK;
+}
+
+/* Two-step synchronous form: the reference decides the squelch on THIS block's channelizer output (:828-874) before it
+ * demodulates the block (:876-906).  pmr_chain_channelize_block runs the block up to the channelizer / discriminator / RSSI and
+ * returns; the caller updates the channel mask; pmr_chain_demodulate_block runs the audio part of that block for the channels
+ * open NOW.  Together they produce what pmr_chain_process_block_f32 produces with the same mask. */
+int pmr_chain_channelize_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, unsigned *n_frames, pmr_cf32 *chan_out,
+                               unsigned chan_stride, float *rssi_db)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    if (q->n_inflight) return fail(q, PMR_EINVAL, "collect the submitted blocks first", hipSuccess);
+    unsigned ny_plan = 0, ns_plan = 0;
+    plan_counts(q, n_in, &ny_plan, &ns_plan);
+    if (n_frames) *n_frames = ns_plan;
+    if (ns_plan > chan_stride && chan_out) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
+    const unsigned want = (chan_out ? PMR_WANT_CHAN : 0) | (rssi_db ? PMR_WANT_RSSI : 0);
+    int rc = slot_submit(q, 0, iq, 0, n_in, want, 1, 1);
+    if (rc) return rc;
+    return slot_collect(q, 0, NULL, NULL, chan_stride, n_frames, chan_out, rssi_db);
+}
+
+int pmr_chain_demodulate_block(pmr_chain q, int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames)
+{
+    if (!q) return PMR_EINVAL;
+    HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    if (!q->pend_audio) return fail(q, PMR_EINVAL, "no channelized block is waiting for its audio part", hipSuccess);
+    const unsigned ns = q->pend_audio_ns;
+    if (n_frames) *n_frames = ns;
+    if (ns > pcm_stride && (pcm || audio)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
+    pmr_slot *sl = &q->slot[0];
+    int rc = slot_prepare(q, 0, 0);
+    if (rc) return rc;
+    const unsigned want = ((pcm || audio) ? PMR_WANT_PCM : 0) | (audio ? PMR_WANT_AUDIO : 0);
+    const unsigned stride = ns ? (ns + 7u) & ~7u : 8u;
+    const size_t n = (size_t)q->M * stride;
+    sl->off_pcm = SLOT_ALIGN((size_t)q->M * sizeof(float));
+    sl->off_audio = sl->off_pcm + SLOT_ALIGN(n * sizeof(int16_t));
+    const size_t out_hi = (want & PMR_WANT_AUDIO) ? sl->off_audio + n * sizeof(float) : sl->off_pcm + n * sizeof(int16_t);
+    const int zc_out = !q->sw.no_zerocopy && sl->hd_out && out_hi <= ZC_MAX_OUT;
+    char *o_out = zc_out ? sl->hd_out : sl->d_out;
+    q->pend_audio = 0;
+    if (ns && (rc = audio_part(q, q->pend_audio_frame0, ns, (want & PMR_WANT_PCM) ? o_out + sl->off_pcm : NULL,
+                               (want & PMR_WANT_AUDIO) ? o_out + sl->off_audio : NULL, stride))) return rc;
+    sl->ns = ns; sl->stride = stride; sl->want = want;
+    if (ns && !zc_out && want)
+        HIPCHK(hipMemcpyAsync(sl->h_out + sl->off_pcm, sl->d_out + sl->off_pcm, out_hi - sl->off_pcm, hipMemcpyDeviceToHost, q->stream), "D2H");
+    HIPCHK(hipEventRecord(sl->done, q->stream), "record");
+    rc = slot_collect(q, 0, pcm, audio, pcm_stride, n_frames, NULL, NULL);
     if (rc) return rc;
     if (q->prof_on) prof_resolve(q);
     return PMR_OK;
@@ -1722,7 +1800,7 @@ int pmr_chain_submit_block_fmt(pmr_chain q, const void *iq, int iq_format, unsig
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
     if (q->n_inflight >= PIPE_DEPTH) return fail(q, PMR_ERANGE, "PIPE_DEPTH blocks already in flight: collect one first", hipSuccess);
     const unsigned i = (q->slot_head + q->n_inflight) % PIPE_DEPTH;
-    int rc = slot_submit(q, i, iq, iq_format, n_in, want ? want : PMR_WANT_PCM, !q->overlap);
+    int rc = slot_submit(q, i, iq, iq_format, n_in, want ? want : PMR_WANT_PCM, !q->overlap, 0);
     if (rc) return rc;
     q->n_inflight++;
     return PMR_OK;

@@ -131,3 +131,77 @@ def test_zero_copy_pinned_input_equals_copied_input(cfg, sizes):
             assert np.array_equal(a[k], b[k]), (k, i, n)
         assert np.allclose(a["rssi"], b["rssi"], atol=1e-4, equal_nan=True)
     ga.close(); gb.close()
+
+
+@pytest.mark.parametrize("cfg,sizes,opts,ctcss", [(CFG_REF, [100000, 99999, 7, 0, 100000, 65537, 100000], {}, False),
+                                                    (CFG_REF, [100000] * 6, {}, True),
+                                                    (CFG2, [250000, 1 << 18, 300001], {"lowpass": True}, False),
+                                                    (CFG5, [1 << 22, 3000001, 1 << 21], {}, False)],
+                         ids=["ref-ragged", "ref-ctcss", "cfg2-lowpass", "cfg5"])
+def test_two_step_form_equals_the_single_call(cfg, sizes, opts, ctcss):
+    """pmr_chain_channelize_block + pmr_chain_demodulate_block (the reference's order: squelch decision between channelizer and
+    demodulator, :828-877) with an unchanged mask return what pmr_chain_process_block_f32 returns, bit for bit -- also when a
+    channelized block is never demodulated (its audio part is still pushed through the stateful stages by the next call)."""
+    from sdr_pmr446_amd import chain
+    fs, M = cfg
+    ks = None if M <= 64 else list(range(0, M, 73))
+    x = synth.synth_iq(sum(sizes), fs, M, channels=ks, dev_hz=1500.0)
+    mb = max(sizes)
+    ga = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb, **opts)
+    gb = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb, **opts)
+    if ctcss:
+        for g in (ga, gb):
+            g._check(g._L.pmr_chain_ctcss_enable(g.h, 1))
+    pos = 0
+    for i, n in enumerate(sizes):
+        blk = x[pos:pos + n]
+        pos += n
+        a = ga.process_block(blk, want=("pcm", "audio", "chan", "rssi"))
+        c = gb.channelize_block(blk, want=("rssi", "chan"))
+        assert c["n_frames"] == a["n_frames"]
+        assert np.array_equal(c["chan"], a["chan"]) and np.allclose(c["rssi"], a["rssi"], atol=1e-4, equal_nan=True)
+        if i == 1:
+            continue                                    # this block is never demodulated in the two-step chain
+        b = gb.demodulate_block(want=("pcm", "audio"))
+        assert b["n_frames"] == a["n_frames"]
+        assert np.array_equal(a["pcm"], b["pcm"]) and np.array_equal(a["audio"], b["audio"]), (i, n)
+        if ctcss:
+            ea, eb = ga.ctcss_read(), gb.ctcss_read()
+            assert ea.shape == eb.shape and ea.tobytes() == eb.tobytes(), i
+    with pytest.raises(chain.PmrError):
+        gb.demodulate_block()                           # nothing pending
+    ga.close(); gb.close()
+
+
+def test_two_step_form_opens_the_squelch_on_the_same_block():
+    """The reference demodulates the block whose RSSI opened the squelch.  Noise, then a carrier on channel 5: with the two-step
+    form the first block that carries the signal already yields its audio, +-1 LSB of the oracle demodulating channel 5."""
+    from sdr_pmr446_amd import chain
+    fs, M, nb = CFG_REF[0], CFG_REF[1], 100000
+    x = np.concatenate([synth.synth_iq(2 * nb, fs, M, stream_id=1, channels=[]),
+                        synth.synth_iq(3 * nb, fs, M, stream_id=2, channels=[5], dev_hz=1500.0)])
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=nb)
+    o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=nb, only_channel=5)
+    L = g._L
+    import ctypes as C
+    st = chain.Squelch()
+    L.pmr_squelch_init(C.byref(st))
+    g.set_channel_mask([])
+    opened_at = None
+    for b in range(5):
+        blk = x[b * nb:(b + 1) * nb]
+        ref = o.process_block(blk, want=("pcm",))["pcm"]
+        c = g.channelize_block(blk, want=("rssi",))
+        if L.pmr_squelch_update(C.byref(st), c["rssi"].ctypes.data, M, (1 << 64) - 1, 18.0, 0):
+            g.set_channel_mask([st.active_chan] if st.state == 1 else [])
+            if st.state == 1 and opened_at is None:
+                opened_at = b
+        d = g.demodulate_block(want=("pcm",))
+        if st.state == 1:
+            assert st.active_chan == 5
+            got, want = d["pcm"][5].astype(np.int32), ref[5].astype(np.int32)
+            skip = 700 if b == opened_at else 0         # the carrier starts inside the filters' history
+            assert np.abs(got[skip:] - want[skip:]).max() <= 1
+            assert np.abs(got).max() > 1000
+    assert opened_at == 2
+    g.close(); o.close()
