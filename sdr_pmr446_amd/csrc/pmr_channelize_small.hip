@@ -272,11 +272,15 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 //   pass 2  thread = frame: FFT-16 in registers, previous frame through LDS, discriminator, stores (as above).
 // Same products and the same oldest-first accumulation order as k_channelize_small / the oracle.
 // ---------------------------------------------------------------------------------------------------------------
-#define CW_NT 256
+#ifndef CW_NT
+#define CW_NT 256                         /* threads = frames per tile (LDS 36 B x CW_NT).  cfg2, all channels: 128 (fits beside four front-end
+                                             tiles) 338 GS/s, 256: 346, 512: 351, 768: 350, 1024: 348 -- but with ONE open channel 512 costs
+                                             17 % (350 vs 424 GS/s) and 3 us at the reference point: 256 stays */
+#endif
 #define CW_F 16                          /* frames per (channel, group) work item */
 
 template <int M, int P>
-__global__ __launch_bounds__(CW_NT, 4) void k_channelize_win(pmr_chan_params q)
+__global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) void k_channelize_win(pmr_chan_params q)
 {
     constexpr int L2M = log2c<M>::v;
     constexpr int FS = M + 2;                             // padded frame row in LDS (cf elements)
@@ -421,6 +425,10 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
     if (p->M != 16) return (int)hipErrorInvalidValue;
     if (win) {
         const size_t lds_w = (size_t)CW_NT * (16 + 2) * sizeof(cf);
+        static unsigned long long attr_w = 0;
+        if (lds_w > 64 * 1024 && pmr_attr_needed(attr_w))
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL((k_channelize_win<16, 26>), dim3(ntiles), dim3(CW_NT), lds_w, (hipStream_t)s, *p);
         return (int)hipGetLastError();
     }
