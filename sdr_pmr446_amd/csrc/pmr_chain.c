@@ -666,6 +666,7 @@ static void read_switches(pmr_switches *w)
     w->l2_on_fe = env_is("PMR_L2_STREAM", "fe");
     w->chan_generic = env_is("PMR_CHANNELIZER", "generic");
     w->chan_pair = env_is("PMR_CHANNELIZER_SMALL", "pair");
+    w->chan_unfused = env_is("PMR_CHAN_FUSED", "0");
     { const char *e = getenv("PMR_CHAN_FT"); w->chan_ft = e ? atoi(e) : 0; }
     w->fir_mode = env_is("PMR_FIR", "pair") ? PMR_FIR_PAIR : env_is("PMR_FIR", "lds") ? PMR_FIR_LDS
                 : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
@@ -1569,7 +1570,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
             c.reset_flags = q->d_reset_flags;
         }
         if (q->chan_small) LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles, q->sw.chan_pair));
-        else if (q->chan_wide) LAUNCH(K_CHANNELIZE, pmr_launch_channelize_wide(q->stream, &c, q->d_chan_x, &ntiles));
+        else if (q->chan_wide) LAUNCH(K_CHANNELIZE, pmr_launch_channelize_wide(q->stream, &c, q->d_chan_x, &ntiles, q->sw.chan_unfused));
         else LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles, q->sw.chan_ft));
         if (q->reset_pending) { q->reset_pending = 0; memset(q->h_reset_flags, 0, M); }
         if (q->dbg_on) {

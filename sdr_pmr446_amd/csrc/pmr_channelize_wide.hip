@@ -162,6 +162,119 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
     }
 }
 
+// M = 256: filter bank, FFT and discriminator in ONE kernel -- a workgroup is the 256 channels of G = 8 consecutive new frames
+// (+ the frame before them, recomputed, for the discriminator): thread = channel, the nine bank outputs go to LDS instead of the
+// scratch array, the nine 256-point FFTs run there (same radix-4 passes as k_fft_disc), then the discriminator.  Saves the
+// scratch array's round trip (8 * rate B per input sample written and read: 54 MB per 2^26-sample block at cfg3) and a kernel
+// boundary; the arithmetic is that of k_pfb_wide + k_fft_disc, operation for operation.
+#define PF_G 8
+__global__ __launch_bounds__(256, 4) void k_chan_fused256(pmr_chan_params q)
+{
+    constexpr int M = 256, NF = PF_G + 1, NROW = NF + PW_P - 1;             // frames per workgroup (first = previous); input rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf *A = reinterpret_cast<cf *>(smem), *tw = A + NF * M;                 // [NF][M], [M/2]
+    const int tid = threadIdx.x;
+    const unsigned ns = q.ns;
+    const unsigned wg = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
+    const unsigned R0 = wg * PF_G;                                          // row R0 <-> frame frame0 - 1 + R0 (the previous frame)
+    if (tid < M / 2) tw[tid] = ((const cf *)q.fft_tw)[tid];
+    // ---- filter bank (k_pfb_wide's arithmetic), thread = channel ----
+    {
+        const unsigned c = (unsigned)tid;
+        const cf *__restrict__ xr = (const cf *)q.xr;
+        const cf *__restrict__ nco_cs = (const cf *)q.nco_cs;
+        const unsigned nco_mask = q.nco_period - 1, xr_mask32 = (unsigned)q.xr_mask;
+        float h[PW_P];
+#pragma unroll
+        for (int k = 0; k < PW_P; k++) h[k] = q.taps_t[k * M + c];
+        cf acc[NF];
+#pragma unroll
+        for (int f = 0; f < NF; f++) acc[f] = cfm(0.f, 0.f);
+        const long long fbase = (long long)q.frame0 - 1 + R0 - (PW_P - 1);
+        const unsigned a0 = (unsigned)((unsigned long long)fbase * (unsigned long long)M) + c;
+        const cf cs_e = nco_cs[a0 & nco_mask], cs_o = nco_cs[(a0 + M) & nco_mask];
+        constexpr int RB = 9;
+#pragma unroll
+        for (int rr0 = 0; rr0 < NROW; rr0 += RB) {
+            cf xm[RB];
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int r = rr0 + u;
+                if (r < NROW) {
+                    const unsigned a = a0 + (unsigned)r * M;
+                    const cf x = xr[a & xr_mask32];
+                    const cf cs = (r & 1) ? cs_o : cs_e;
+                    xm[u] = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int r = rr0 + u;
+                if (r < NROW) {
+#pragma unroll
+                    for (int f = (r - PW_P + 1 > 0 ? r - PW_P + 1 : 0); f <= (r < NF - 1 ? r : NF - 1); f++)
+                        acc[f] = __builtin_elementwise_fma(cf{h[r - f], h[r - f]}, xm[u], acc[f]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; f++) A[f * M + c] = acc[f];
+    }
+    __syncthreads();
+    // ---- NF forward FFTs of M points, radix-4 Stockham in place (k_fft_disc's passes) ----
+    const auto twid = [&](int i) { const cf w = tw[i & (M / 2 - 1)]; return i >= M / 2 ? -w : w; };
+    constexpr int NB = NF * (M / 4), NPT = (NB + 255) / 256;
+#pragma unroll
+    for (int Ns = 1; Ns < M; Ns *= 4) {
+        cf y[NPT][4];
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int idx = tid + 256 * u;
+            if (idx < NB) {
+                const int f = idx / (M / 4), j = idx % (M / 4), k = j & (Ns - 1);
+                const cf *x = A + f * M + j;
+                cf v0 = x[0], v1 = x[M / 4], v2 = x[M / 2], v3 = x[3 * M / 4];
+                if (Ns > 1) {
+                    const int ti = k * (M / (4 * Ns));
+                    v1 = cmul(v1, twid(ti)); v2 = cmul(v2, twid(2 * ti)); v3 = cmul(v3, twid(3 * ti));
+                }
+                const cf t0 = v0 + v2, t1 = v0 - v2, t2 = v1 + v3, d = v1 - v3, t3 = cfm(d.y, -d.x);
+                y[u][0] = t0 + t2; y[u][1] = t1 + t3; y[u][2] = t0 - t2; y[u][3] = t1 - t3;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+            const int idx = tid + 256 * u;
+            if (idx < NB) {
+                const int f = idx / (M / 4), j = idx % (M / 4), k = j & (Ns - 1);
+                cf *o = A + f * M + (j - k) * 4 + k;
+                o[0] = y[u][0]; o[Ns] = y[u][1]; o[2 * Ns] = y[u][2]; o[3 * Ns] = y[u][3];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- discriminator, tap-off, RSSI partial sums (k_fft_disc's epilogue) ----
+    cf *__restrict__ chan_out = (cf *)q.chan_out;
+    const unsigned nnew = R0 >= ns ? 0u : min((unsigned)PF_G, ns - R0);
+    for (unsigned wi = tid; wi < nnew * M; wi += 256) {
+        const unsigned f = wi / M, k = wi % M;
+        const cf pv = A[f * M + k], cu = A[(f + 1) * M + k];
+        const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
+        const unsigned t = R0 + f;
+        const bool rst = t == 0 && q.reset_flags && q.reset_flags[k];
+        q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = rst ? 0.f : atan2f(im, re) * q.fm_ref;
+        if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
+    }
+    if (q.rssi_part) {
+        const unsigned k = (unsigned)tid;
+        float a = 0.f;
+        for (unsigned f = 0; f < nnew; f++) { const cf cu = A[(f + 1) * M + k]; a += hypotf(cu.x, cu.y); }
+        q.rssi_part[(size_t)wg * M + k] = a;
+    }
+}
+
 template <int M, int FPW>
 static int launch_fft_disc(hipStream_t st, const pmr_chan_params *p, const cf *Xg, unsigned *ntiles_out)
 {
@@ -185,11 +298,18 @@ extern "C" int pmr_channelize_wide_supported(unsigned M, unsigned p, unsigned nc
 }
 
 /* scratch: (ns_max + 1) * M complex floats */
-extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out)
+extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out, int unfused)
 {
     if (ntiles_out) *ntiles_out = 0;
     if (!p->ns) return 0;
     hipStream_t st = (hipStream_t)s;
+    if (p->M == 256 && !unfused) {
+        const unsigned ntiles = (p->ns + PF_G - 1) / PF_G;
+        if (ntiles_out) *ntiles_out = ntiles;
+        const size_t lds = ((size_t)(PF_G + 1) * 256 + 128) * sizeof(cf);
+        hipLaunchKernelGGL(k_chan_fused256, dim3(ntiles), dim3(256), lds, st, *p);
+        return (int)hipGetLastError();
+    }
     unsigned log2M = 0;
     while ((1u << log2M) < p->M) log2M++;
     const unsigned groups = (p->ns + 1 + PW_F - 1) / PW_F;

@@ -27,6 +27,7 @@ typedef struct {
     int l2_on_fe;           /* PMR_L2_STREAM=fe: level 2 on the front-end stream                            */
     int chan_generic;       /* PMR_CHANNELIZER=generic: k_channelize for M = 16 too                         */
     int chan_pair;          /* PMR_CHANNELIZER_SMALL=pair: two-frames-per-thread small-M channelizer        */
+    int chan_unfused;       /* PMR_CHAN_FUSED=0: M = 256 through k_pfb_wide + k_fft_disc instead of the fused kernel */
     int chan_ft;            /* PMR_CHAN_FT=n: tile height of the generic channelizer (0 = automatic)        */
     int fir_mode;           /* PMR_FIR=pair|lds|global: VALU versions of the audio FIR (PMR_FIR_*)          */
     int fir_mfma_global;    /* PMR_FIR_MFMA=global: MFMA FIR without the LDS sample window                  */
@@ -105,7 +106,8 @@ int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntil
 /* wide banks (pmr_channelize_wide.hip, M = 64 / 256 / 1024 / 4096): filter-bank kernel parallel over channels, then radix-4
  * FFT + discriminator kernel parallel over frames; x_scratch holds (ns + 1) * M complex floats.  Same outputs. */
 int pmr_channelize_wide_supported(unsigned M, unsigned p, unsigned nco_period);
-int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out);
+int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out,
+                               int unfused /*M = 256: separate filter-bank and FFT kernels instead of the fused one*/);
 
 /* small-M specialisation (pmr_channelize_small.hip): thread-per-frame-pair, FFT in registers.  n_valid = valid
  * samples in xr (zeros are read beyond).  Same outputs as pmr_launch_channelize.                       */

@@ -49,6 +49,7 @@ VARIANTS = [
     ({"PMR_CHANNELIZER": "generic"}, CFG2),
     ({"PMR_CHANNELIZER": "generic"}, CFG5),
     ({"PMR_CHANNELIZER": "generic", "PMR_CHAN_FT": "7"}, CFG3),
+    ({"PMR_CHAN_FUSED": "0"}, CFG3),                          # 256 channels through k_pfb_wide + k_fft_disc instead of the fused kernel
     ({"PMR_CHANNELIZER_SMALL": "pair"}, CFG2),
     ({"PMR_FIR": "pair"}, CFG2),
     ({"PMR_FIR_MFMA": "global"}, CFG2),
