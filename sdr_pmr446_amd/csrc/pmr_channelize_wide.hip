@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
 // scratch array's round trip (8 * rate B per input sample written and read: 54 MB per 2^26-sample block at cfg3) and a kernel
 // boundary; the arithmetic is that of k_pfb_wide + k_fft_disc, operation for operation.
 #define PF_G 8
-__global__ __launch_bounds__(256, 4) void k_chan_fused256(pmr_chan_params q)
+__global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params q)
 {
     constexpr int M = 256, NF = PF_G + 1, NROW = NF + PW_P - 1;             // frames per workgroup (first = previous); input rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -307,7 +307,7 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
         const unsigned ntiles = (p->ns + PF_G - 1) / PF_G;
         if (ntiles_out) *ntiles_out = ntiles;
         const size_t lds = ((size_t)(PF_G + 1) * 256 + 128) * sizeof(cf);
-        hipLaunchKernelGGL(k_chan_fused256, dim3(ntiles), dim3(256), lds, st, *p);
+        hipLaunchKernelGGL(k_channelize_fused256, dim3(ntiles), dim3(256), lds, st, *p);
         return (int)hipGetLastError();
     }
     unsigned log2M = 0;

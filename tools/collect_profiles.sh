@@ -7,21 +7,21 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --host-io 2>/dev/null | grep '^{' > $O/bench.json
+[ -n "$SKIP_BENCH" ] || python3 $R/bench.py --host-io 2>/dev/null | grep '^{' > $O/bench.json
 B="--also none --regions 2 --steps 50 --warmup 2 --no-cpu-baseline --no-kernel-events --parity-blocks 0"
-for W in cfg5 cfg3 cfg2; do
+for W in ${WORKLOADS:-cfg5 cfg3 cfg2}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 $R/bench.py --workload $W $B > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$W -- python3 $R/bench.py --workload $W $B > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$W -- python3 $R/bench.py --workload $W $B > /dev/null 2>&1
 done
 # instruction mix of the front-end kernels (blocks not pipelined: clean attribution)
 export PMR_OVERLAP=0
-for W in cfg5 cfg2; do
+for W in ${INST_WORKLOADS:-cfg5 cfg2}; do
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d $O/insts_$W -- python3 $R/bench.py --workload $W $B > /dev/null 2>&1
 done
 unset PMR_OVERLAP
 # two ranks on this one GPU (gloo for the barrier / max): the N > 1 code path of bench.py for the record -- NOT a scaling figure
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 \
+[ -n "$SKIP_BENCH" ] || python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 \
     --dist-backend gloo --no-cpu-baseline --regions 5 2>/dev/null | grep '^{' > $O/bench_2rank_1gpu.json
 # keep the merged-back payload small: only this library's kernels
 for f in $(find $O -name '*_kernel_trace.csv' -o -name '*_counter_collection.csv'); do
