@@ -245,7 +245,6 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
         dts.append(dt)
     ch.profile_enable(0)
     prof_roof = ch.profile()
-    fe_fallback = ch.fe_fallback_tiles()          # last block of the last timed region (pipelined, un-synchronised)
     breakdown_steps = 0
     if not args.no_kernel_events:
         # separate pass, outside the timed region: every kernel, blocks NOT pipelined (uncontended kernel times)
@@ -287,9 +286,6 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
                     "events": "start/stop events carried by every %d-th launch of the kernel inside the timed regions" % EVENT_EVERY,
                     "algorithmic_bytes_per_sample": b_alg, "algorithmic_bytes_per_launch": b_alg * block,
                     "kernel_symbols": KERNEL_SYMBOLS,
-                    "carry_fallback_tiles": {"flagged": fe_fallback[0], "tiles": fe_fallback[1],
-                                             "note": "tiles of the last timed block whose dc carry did not arrive in-kernel "
-                                                     "(corrected by k_fe_tilefix); 0/0 = no in-kernel carry in this config"},
                     "kernels_ms_per_step_isolated": {k: v[0] / max(1, breakdown_steps) for k, v in sorted(prof.items())}}
             iso = prof.get(kname)
             if iso and iso[1]:

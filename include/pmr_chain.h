@@ -158,9 +158,6 @@ void *pmr_chain_stream(pmr_chain q);                       /* hipStream_t the ke
  * (hipExtLaunchKernel: the kernel's own begin..end, ~5 us per sampled launch and nothing on the others) */
 int         pmr_chain_profile_enable(pmr_chain q, int mode);
 int         pmr_chain_profile_reset(pmr_chain q);
-/* tiles of the LAST block's front end that did not get their dc carry in-kernel and were corrected by the fallback pass
- * (synchronises; both 0 when the configuration's front end has no in-kernel carry) */
-int         pmr_chain_fe_fallback_tiles(pmr_chain q, unsigned *flagged, unsigned *tiles);
 unsigned    pmr_chain_profile_count(pmr_chain q);                          /* number of distinct kernels   */
 const char *pmr_chain_profile_name(pmr_chain q, unsigned i);
 int         pmr_chain_profile_get(pmr_chain q, unsigned i, double *total_ms, unsigned *launches);

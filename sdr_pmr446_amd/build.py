@@ -52,7 +52,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

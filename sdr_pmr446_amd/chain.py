@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "pmr_chain_default_cfg", "pmr_chain_create", "pmr_chain_reset", "pmr_chain_destroy", "pmr_chain_max_frames",
     "pmr_chain_num_channels", "pmr_chain_last_error", "pmr_chain_process_block", "pmr_chain_process_block_f32",
     "pmr_chain_process_block_device", "pmr_chain_synchronize", "pmr_chain_set_overlap", "pmr_chain_stream", "pmr_chain_profile_enable",
-    "pmr_chain_profile_reset", "pmr_chain_fe_fallback_tiles", "pmr_chain_profile_count", "pmr_chain_profile_name", "pmr_chain_profile_get",
+    "pmr_chain_profile_reset", "pmr_chain_profile_count", "pmr_chain_profile_name", "pmr_chain_profile_get",
     "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read",
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
@@ -127,8 +127,6 @@ def load(build_if_missing=True):
     for name in ("pmr_chain_max_frames", "pmr_chain_num_channels", "pmr_chain_profile_count"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = u
-    L.pmr_chain_fe_fallback_tiles.argtypes = [vp, C.POINTER(u), C.POINTER(u)]
-    L.pmr_chain_fe_fallback_tiles.restype = i
     L.pmr_chain_last_error.argtypes = [vp]
     L.pmr_chain_last_error.restype = C.c_char_p
     L.pmr_chain_stream.argtypes = [vp]
@@ -592,12 +590,6 @@ class PmrChain:
     def profile_enable(self, mode=1):
         """0 off, 1 every kernel, m >= 2 only the front-end (roofline) kernel, every (m-1)-th launch (include/pmr_chain.h)."""
         self._check(self._L.pmr_chain_profile_enable(self.h, int(mode)))
-
-    def fe_fallback_tiles(self):
-        """(flagged, tiles) of the last block's front end: tiles whose dc carry came from the fallback pass."""
-        a, b = C.c_uint(0), C.c_uint(0)
-        self._check(self._L.pmr_chain_fe_fallback_tiles(self.h, C.byref(a), C.byref(b)))
-        return a.value, b.value
 
     def profile_reset(self):
         self._check(self._L.pmr_chain_profile_reset(self.h))

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -130,13 +131,8 @@ struct pmr_chain_s {
     int pend_audio; int64_t pend_audio_frame0; unsigned pend_audio_ns;
     int l2_on_backend, pend_l2; pmr_fe_params pend_p2; pmr_fe_tiles_params pend_t2; pmr_fe_fix_params pend_f2; unsigned pend_ntiles2;
     int fe_sel;                      /* which of the ping-pong history / state buffers is current     */
-    /* persistent one-level kernel (k_fe_persist): ticket counters, published carry records, fallback flags */
-    unsigned fe_last_ntiles;         /* tiles of the last fused front-end launch */
     /* waterfall periodogram (pmr_spectrum.hip): display width (0 = off), window / twiddle tables, per-workgroup partial rows, PSD */
     unsigned spec_nfft, spec_ntr_last; float *d_spec_win, *d_spec_tw, *d_spec_part, *d_spec_psd;
-    int fe_lb;                       /* k_fe_fast<.., LB>: carry applied in-kernel by look-back (default where covered) */
-    int fe_persist; unsigned fe_nwg; uint32_t *d_fe_tickets; uint32_t fe_ticket_base[8]; uint64_t *d_fe_prec; uint8_t *d_fe_fixflag;
-    uint32_t fe_epoch;
     unsigned fe_max_tiles;
 
     /* host-side counters (all closed form in the number of samples consumed) */
@@ -493,45 +489,6 @@ static int fe_init(pmr_chain q)
     }
     q->fe_sel = 0;
     q->fe_on = 1;
-    /* PMR_FE_PERSIST=1 (A/B switch, off by default): persistent kernel with the dc carry applied in-kernel, for the one-level
-     * cascades the specialised kernels cover (N3 six-tap stages + m = 5, 10) with at most 2 x 256 resampler outputs per tile.
-     * Correct (parity-tested) and it removes the 90 MB read-modify-write of k_fe_tilefix, but measured SLOWER on MI355X at
-     * cfg2 (isolated front end): one tile per workgroup 0.125 ms + k_fe_tilefix 0.024 ms  vs  persistent loop alone 0.150 ms,
-     * + carry hand-off 0.186 ms, + ticket atomics 0.243 ms -- so the two-kernel form stays the product. */
-    q->fe_persist = 0; q->fe_lb = 0;
-    /* PMR_FE_LOOKBACK=1 (A/B switch, off by default): one tile per workgroup, the tile applies its own dc carry before it stores
-     * its outputs (k_fe_fast<.., LB>: look-back over its predecessors' published records); k_fe_tilefix then only visits the
-     * tiles that raised their flag (the heads of the XCD ranges: 105 of 17 698 at cfg2).  Correct and parity-tested, removes
-     * the read-modify-write of the resampled stream -- and measured SLOWER (profiles/r02_fe_lookback_experiment.txt): the 15
-     * predecessors of a tile run CONCURRENTLY with it (1024 tiles are resident, a block has 16 384), so their records are
-     * read with agent-scope loads that miss L2 by construction, at loaded-HBM latency, late in the tile's life: front end
-     * 0.123 -> 0.198 ms at cfg2. */
-    if (!q->fe_two && nt == 256 && !q->sw.fe_generic && !q->sw.fe_persist && q->sw.fe_lookback && h >= 3 && h <= 5) {
-        int ok = q->fe_m[h - 2] == 5 && q->fe_m[h - 1] == 10;
-        for (unsigned e = 0; e + 2 < h; e++) if (q->fe_m[e] != 3) ok = 0;
-        if (ok) {
-            if ((rc = dev_alloc(q, (void **)&q->d_fe_prec, (size_t)q->fe_max_tiles * 2 * sizeof(uint64_t)))) return rc;
-            if ((rc = dev_alloc(q, (void **)&q->d_fe_fixflag, q->fe_max_tiles))) return rc;
-            q->fe_epoch = 0;
-            q->fe_lb = 1;
-        }
-    }
-    if (!q->fe_two && nt == 256 && !q->sw.fe_generic && q->sw.fe_persist && h >= 3 && h <= 5) {
-        int ok = q->fe_m[h - 2] == 5 && q->fe_m[h - 1] == 10;
-        for (unsigned e = 0; e + 2 < h; e++) if (q->fe_m[e] != 3) ok = 0;
-        const uint64_t max_out = ((uint64_t)q->fe_TQ << 24) / d->arb_step + 2;
-        if (ok && max_out <= 512) {
-            int ncu = 0, dev = q->device;
-            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-            q->fe_nwg = 4u * (unsigned)ncu;                   /* 39.9 KB of LDS per workgroup: four per CU */
-            if ((rc = dev_alloc(q, (void **)&q->d_fe_tickets, 8 * sizeof(uint32_t)))) return rc;
-            if ((rc = dev_alloc(q, (void **)&q->d_fe_prec, (size_t)q->fe_max_tiles * 2 * sizeof(uint64_t)))) return rc;
-            if ((rc = dev_alloc(q, (void **)&q->d_fe_fixflag, q->fe_max_tiles))) return rc;
-            memset(q->fe_ticket_base, 0, sizeof(q->fe_ticket_base));
-            q->fe_epoch = 0;
-            q->fe_persist = 1;
-        }
-    }
     return PMR_OK;
 }
 
@@ -659,9 +616,6 @@ static void read_switches(pmr_switches *w)
     memset(w, 0, sizeof(*w));
     w->fe_staged = env_is("PMR_FRONTEND", "staged");
     w->fe_generic = env_is("PMR_FE_KERNEL", "generic");
-    w->fe_persist = env_is("PMR_FE_PERSIST", "1");
-    w->fe_lookback = env_is("PMR_FE_LOOKBACK", "1");
-    { const char *e = getenv("PMR_FE_STAGGER"); w->fe_stagger = e ? atoi(e) : 2; }
     { const char *e = getenv("PMR_FE_LEVELS"); w->fe_levels = e ? atoi(e) : 0; }
     w->l2_on_fe = env_is("PMR_L2_STREAM", "fe");
     w->chan_generic = env_is("PMR_CHANNELIZER", "generic");
@@ -765,7 +719,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_dbg_ct, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_tickets, q->d_fe_prec, q->d_fe_fixflag, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events,
                      q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1 };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
@@ -814,10 +768,6 @@ int pmr_chain_reset(pmr_chain q)
     if (q->fe_on) for (int i = 0; i < 2; i++) {
         HIPCHK(hipMemsetAsync(q->d_fe_hist[i], 0, (size_t)q->fe_hcap * sizeof(cfl), q->stream), "reset");
         HIPCHK(hipMemsetAsync(q->d_fe_vstate[i], 0, sizeof(cfl), q->stream), "reset");
-    }
-    if (q->d_fe_tickets) {
-        HIPCHK(hipMemsetAsync(q->d_fe_tickets, 0, 8 * sizeof(uint32_t), q->stream), "reset");
-        memset(q->fe_ticket_base, 0, sizeof(q->fe_ticket_base));
     }
     q->fe_sel = 0;
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0; q->last_ny = q->last_ns = 0;
@@ -1004,33 +954,9 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     p.dc_a1 = d->dc_a1; p.zeta = d->zeta; p.lam_wave = q->fe_lam_wave;
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     fe_fill_taps(q, &p, 0, h);
-    if (q->fe_persist) {
-        const unsigned CH = 64, nwg = ntiles < q->fe_nwg ? ntiles : q->fe_nwg;
-        p.tickets = q->d_fe_tickets; memcpy(p.ticket_base, q->fe_ticket_base, sizeof(p.ticket_base));
-        p.chunk = CH; p.stagger = (unsigned)q->sw.fe_stagger; p.ntiles = ntiles; p.prec = q->d_fe_prec; p.epoch = ++q->fe_epoch; p.fixflag = q->d_fe_fixflag;
-        if (p.epoch == 0) p.epoch = ++q->fe_epoch;            /* 0 is what freshly zeroed records carry */
-        p.v_in = t.v_in; p.v_out = t.v_out; p.rho_pow = t.rho_pow; p.carry_K = t.K; p.rho = t.rho; p.lamHh = t.lamHh;
-        p.inv_lamHh = t.inv_lamHh; p.inv_lamL = t.inv_lamL; p.lamEnd = t.lamEnd;
-        p.GA = q->d_fe_GA; p.T1 = q->d_fe_T1; p.T2 = q->d_fe_T2; p.Kgain = q->fe_Kgain;
-        LAUNCH_FE(K_FE, pmr_launch_fe_persist(q->sfe, &p, nwg));
-        /* every workgroup takes tickets until one falls beyond the last tile: counter x hands out (tiles of its chunks) + (its
-         * workgroups) tickets per launch -- the host tracks the bases, the counters are never reset */
-        for (unsigned xc = 0; xc < 8; xc++) {
-            unsigned tiles_x = 0;
-            for (unsigned ch0 = xc; (uint64_t)ch0 * CH < ntiles; ch0 += 8)
-                tiles_x += (uint64_t)(ch0 + 1) * CH <= ntiles ? CH : ntiles - ch0 * CH;
-            q->fe_ticket_base[xc] += tiles_x + (nwg + 7 - xc) / 8;
-        }
-    } else {
-        if (q->fe_lb) {
-            p.ntiles = ntiles; p.prec = q->d_fe_prec; p.epoch = ++q->fe_epoch; p.fixflag = q->d_fe_fixflag;
-            if (p.epoch == 0) p.epoch = ++q->fe_epoch;        /* 0 is what freshly zeroed records carry */
-            p.v_in = t.v_in; p.v_out = t.v_out; p.rho_pow = t.rho_pow; p.carry_K = t.K; p.rho = t.rho; p.lamHh = t.lamHh;
-            p.inv_lamHh = t.inv_lamHh; p.inv_lamL = t.inv_lamL; p.lamEnd = t.lamEnd;
-            p.GA = q->d_fe_GA; p.T1 = q->d_fe_T1; p.T2 = q->d_fe_T2; p.Kgain = q->fe_Kgain;
-        }
+    {
         pmr_launch_events ev; prof_pending pe;
-        fe_launch_events(q, K_FE, q->tf_on_backend && !q->fe_lb && ntiles != 0, &ev, &pe);
+        fe_launch_events(q, K_FE, q->tf_on_backend && ntiles != 0, &ev, &pe);
         LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic, &ev));
         prof_push(q, &pe);
     }
@@ -1040,17 +966,15 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[slot]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
     f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
     f.Kgain = q->fe_Kgain;
-    /* persistent kernel: only the tiles it flagged (carry not available in time) are corrected here -- normally none */
-    if (q->tf_on_backend && !q->fe_persist && !q->fe_lb) {
+    if (q->tf_on_backend) {
         /* PMR_TILEFIX_STREAM=be: the carry pass heads the back-end stream's work for this block; the front-end stream then
          * carries front-end kernels only, back to back */
         q->pend_t2 = t; q->pend_f2 = f; q->pend_tf_Q = Q; q->pend_tf = 1;
     } else {
         pmr_launch_events ev; prof_pending pe;
         fe_launch_events(q, K_FE_TILEFIX, t.ntiles != 0, &ev, &pe);
-        LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, (q->fe_persist || q->fe_lb) ? q->d_fe_fixflag : NULL, &ev));
+        LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, &ev));
     }
-    q->fe_last_ntiles = ntiles;
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
     *ny_out = ny;
@@ -1513,7 +1437,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     }
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
-    if (q->fe_on && !q->fe_two && !q->fe_persist && !q->fe_lb) {
+    if (q->fe_on && !q->fe_two) {
         q->tf_on_backend = !single && tilefix_on_backend(q);
         if (!single && !q->tf_on_backend && q->tf_last_be)    /* this block's carry pass reads the dc state the previous one (back-end stream) wrote */
             HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[(par + PIPE_DEPTH - 1) % PIPE_DEPTH], 0), "wait previous carry pass");
@@ -1535,7 +1459,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     if (!single) HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
     if (q->pend_tf) {
         q->pend_tf = 0;
-        LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t2, &q->pend_f2, q->pend_tf_Q, NULL, NULL));
+        LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t2, &q->pend_f2, q->pend_tf_Q, NULL));
     }
     if (q->pend_l2) {
         q->pend_l2 = 0;
@@ -1833,9 +1757,9 @@ unsigned pmr_chain_max_in_flight(pmr_chain q) { (void)q; return PIPE_DEPTH; }
  * end read the caller's buffer in place over the host link instead of waiting for a copy engine first (host_zero_copy). */
 #define HOST_REG_MAX 256
 static struct { char *h, *d; size_t n; } g_host_reg[HOST_REG_MAX];
-static volatile int g_host_reg_lock;
-static void host_reg_acquire(void) { while (__sync_lock_test_and_set(&g_host_reg_lock, 1)) { } }
-static void host_reg_release(void) { __sync_lock_release(&g_host_reg_lock); }
+static pthread_mutex_t g_host_reg_lock = PTHREAD_MUTEX_INITIALIZER;
+static void host_reg_acquire(void) { pthread_mutex_lock(&g_host_reg_lock); }
+static void host_reg_release(void) { pthread_mutex_unlock(&g_host_reg_lock); }
 
 void *pmr_host_alloc(size_t bytes)
 {
@@ -1933,26 +1857,6 @@ int pmr_chain_set_overlap(pmr_chain q, int on)
     int rc = pmr_chain_synchronize(q);
     q->overlap = on ? 1 : 0;
     return rc;
-}
-
-int pmr_chain_fe_fallback_tiles(pmr_chain q, unsigned *flagged, unsigned *tiles)
-{
-    if (!q) return PMR_EINVAL;
-    if (flagged) *flagged = 0;
-    if (tiles) *tiles = 0;
-    if (!(q->fe_lb || q->fe_persist) || !q->fe_last_ntiles) return PMR_OK;
-    int rc = pmr_chain_synchronize(q);
-    if (rc) return rc;
-    uint8_t *h = (uint8_t *)malloc(q->fe_last_ntiles);
-    if (!h) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
-    const hipError_t e = hipMemcpy(h, q->d_fe_fixflag, q->fe_last_ntiles, hipMemcpyDeviceToHost);
-    unsigned n = 0;
-    for (unsigned i = 0; i < q->fe_last_ntiles; i++) n += h[i] != 0;
-    free(h);
-    if (e != hipSuccess) return fail(q, PMR_EHIP, "hipMemcpy", e);
-    if (flagged) *flagged = n;
-    if (tiles) *tiles = q->fe_last_ntiles;
-    return PMR_OK;
 }
 
 int pmr_chain_profile_reset(pmr_chain q)

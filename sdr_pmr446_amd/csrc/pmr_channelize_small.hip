@@ -19,17 +19,6 @@
 
 #include "pmr_kernels.h"
 
-// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
-// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
-static inline bool pmr_attr_needed(unsigned long long &mask)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    if (mask >> dev & 1ull) return false;
-    mask |= 1ull << dev;
-    return true;
-}
-
 // complex = ext-vector pair: real-tap MACs and butterflies map onto v_pk_fma_f32 / v_pk_add_f32 (~1.8x the FLOP rate of
 // the scalar forms on gfx950, tools/ubench/valu_rate.hip)
 typedef float cf __attribute__((ext_vector_type(2)));
@@ -425,7 +414,7 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
     if (p->M != 16) return (int)hipErrorInvalidValue;
     if (win) {
         const size_t lds_w = (size_t)CW_NT * (16 + 2) * sizeof(cf);
-        static unsigned long long attr_w = 0;
+        static pmr_attr_flags attr_w{0};
         if (lds_w > 64 * 1024 && pmr_attr_needed(attr_w))
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -433,7 +422,7 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
         return (int)hipGetLastError();
     }
     const size_t lds = (size_t)(CS_NT * CS_FPT + p->p - 1) * (p->M + 2) * sizeof(cf);
-    static unsigned long long attr_set = 0;
+    static pmr_attr_flags attr_set{0};
     if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_small<16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

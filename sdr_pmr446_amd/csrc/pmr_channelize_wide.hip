@@ -281,10 +281,8 @@ static int launch_fft_disc(hipStream_t st, const pmr_chan_params *p, const cf *X
     const unsigned ntiles = (p->ns + FPW - 2) / (FPW - 1);
     if (ntiles_out) *ntiles_out = ntiles;
     const size_t lds = ((size_t)FPW * M + M / 2) * sizeof(cf);
-    static unsigned long long attr_set = 0;
-    int dev = 0;
-    if (lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(attr_set >> dev & 1ull)) {
-        attr_set |= 1ull << dev;
+    static pmr_attr_flags attr_set{0};
+    if (lds > 64 * 1024 && pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_disc<M, FPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     hipLaunchKernelGGL((k_fft_disc<M, FPW>), dim3(ntiles), dim3(256), lds, st, *p, Xg);

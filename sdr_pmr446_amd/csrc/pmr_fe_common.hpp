@@ -10,17 +10,6 @@
 
 #include "pmr_kernels.h"
 
-// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
-// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
-static inline bool pmr_attr_needed(unsigned long long &mask)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    if (mask >> dev & 1ull) return false;
-    mask |= 1ull << dev;
-    return true;
-}
-
 // complex sample = clang ext-vector pair: (re, im) arithmetic with a real scalar tap maps onto v_pk_fma_f32 with the tap
 // broadcast from one SGPR.  Measured on MI355X (tools/ubench/valu_rate.hip): v_fma_f32 peaks at ~67 TFLOP/s,
 // v_pk_fma_f32 at ~115-120 TFLOP/s, so packed math is worth ~1.8x wherever the kernel is VALU-bound.
@@ -174,12 +163,9 @@ static __device__ __forceinline__ fe_arb_plan fe_arb_prepare(const pmr_fe_params
     return a;
 }
 
-// FIX: the tile's dc carry (Vr, Vi) is known -- every output leaves corrected, y - V * K * GA[branch] * mu^q' (the expression and
-// its rounding are k_fe_tilefix's: a tile corrected here and one corrected there agree bit for bit).
-template <int NT, int GS, bool FIX = false>
+template <int NT, int GS>
 static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, const fe_arb_plan &a, unsigned long long qa,
-                                                    const cf *fin, const float (&bk0)[14], const float (&bk1)[14], int tid,
-                                                    float Vr = 0.f, float Vi = 0.f)
+                                                    const cf *fin, const float (&bk0)[14], const float (&bk1)[14], int tid)
 {
     cf *__restrict__ out = (cf *)p.out;
     const auto resamp = [&](unsigned long long j, const float *bk) {
@@ -196,10 +182,6 @@ static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, cons
         cf y = cfm(0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 14; k++) y = cfma(bk[k], bg[k & (NG - 1)][k + (k >> GS)], y);
-        if constexpr (FIX) {
-            const float u = p.Kgain * (p.GA[(unsigned)(ph & 0xffffffu) >> 16] * (p.T1[qd >> 5] * p.T2[qd & 31]));
-            y = cfm(fmaf(-Vr, u, y.x), fmaf(-Vi, u, y.y));
-        }
         return y;
     };
     if (a.pairs && a.j0 + 1 < a.jb) {

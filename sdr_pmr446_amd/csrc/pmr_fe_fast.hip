@@ -40,29 +40,9 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // slot of 16-byte chunk g (and chunk of slot g: the map is an involution)
 static __device__ __forceinline__ int fe_swz(int g) { return (g & ~7) | ((g & 7) ^ ((g >> 4) & 7)); }
 
-// a tile's published carry record: 8-byte {value, epoch} granules, agent-scope relaxed atomics (see k_fe_persist below)
-static __device__ __forceinline__ void fe_publish(uint64_t *rec, float v, uint32_t epoch)
-{
-    __hip_atomic_store(rec, (uint64_t)__builtin_bit_cast(uint32_t, v) | ((uint64_t)epoch << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-#ifndef FEP_SPINS
-#define FEP_SPINS 48        /* bounded wait for a predecessor's record: 48 x s_sleep(16) ~ 20 us, then the tile falls back */
-#endif
-
-// LB ("look-back", FE_FULL only): the tile applies its OWN dc carry to its outputs before they are stored, so no pass over the
-// resampled stream follows.  The carry V_c = (W_c - A_c) lambda^-Hh, W_c = sum_{k=1..K} rho^(k-1) P_{c-k}, needs the records
-// P = probeB - rho probeA of the K ~ 15 preceding tiles, and each of those is known as soon as ITS tile has run its dc scan
-// (phase B) -- there is no chain.  Tiles are dealt to the XCDs in contiguous ranges (below), workgroups of an XCD start in
-// blockIdx order, so a tile's predecessors were started just before it on the same XCD and have published by the time this
-// tile reaches its last stage (the records are requested before the m = 5 stage and summed before the m = 10 stage).
-// Correctness never depends on that timing: the wait is bounded; a tile whose records did not arrive (and the first K tiles of
-// an XCD's range, whose predecessors run at the END of another XCD's range) stores its outputs uncorrected and raises its
-// flag, and k_fe_tilefix(flags) corrects exactly those tiles from the probes -- in the same arithmetic, bit for bit.
-template <int MODE, int N3, int TAIL, bool LB = false>
+template <int MODE, int N3, int TAIL>
 __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 {
-    static_assert(!LB || (MODE == FE_FULL && TAIL == 1 && N3 >= 1), "look-back is for the one-level kernels");
     static_assert(N3 >= 1 || (MODE == FE_FULL && TAIL == 1), "a cascade without six-tap stages is (m = 5, m = 10)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256, SPT = 16, N0 = NT * SPT;
@@ -76,8 +56,6 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
     cf *wagg = buf + SCR;
     cf *bnd = wagg + NT / 64;                                 // [4][10]
-    cf *pr = bnd + 40;                                        // LB: [2] probes A, B of this tile
-    float *sV = reinterpret_cast<float *>(pr + 2);            // LB: carry (re, im), [2] = ok
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const cf *__restrict__ x = (const cf *)p.x;
@@ -87,13 +65,9 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     // CONTIGUOUS range of tiles -- a tile's halo is its left neighbour's tail and can then be an L2 hit instead of a second
     // HBM read (PMC: 8 % extra fetch without it).  Placement only affects speed, never results.
     int c = blockIdx.x;
-    bool lb_try = LB;                                      // LB: this tile's predecessors run before it (wave-uniform)
     {
         const int nt_all = gridDim.x, per = nt_all >> 3, main = per << 3;
-        if (c < main) {
-            if (LB && (c & 7) != 0 && (c >> 3) < (int)p.carry_K) lb_try = false;     // head of an XCD's range (not XCD 0's)
-            c = (c & 7) * per + (c >> 3);
-        }
+        if (c < main) c = (c & 7) * per + (c >> 3);
     }
     const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // block-relative index of tile sample 0
 
@@ -183,8 +157,8 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
                 if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = v0;
             }
         }
-        if (tid == p.Hh / SPT - 1) { ((cf *)p.probeA)[c] = v1; if (LB) pr[0] = v1; }      // local v at tile offset Hh-1
-        if (tid == NT - 1) { ((cf *)p.probeB)[c] = v1; if (LB) pr[1] = v1; }              // local v at tile offset N0-1
+        if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;      // local v at tile offset Hh-1
+        if (tid == NT - 1) ((cf *)p.probeB)[c] = v1;              // local v at tile offset N0-1
         if constexpr (N3 == 0) {
             // no six-tap stage: dc-blocked samples -> LDS, layout L(16) (the raw tile is dead: every thread holds its samples)
             cf *o = buf + tid * 17;
@@ -202,20 +176,6 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             for (int i = 0; i < 10; i++) bnd[wave * 10 + i] = yb[6 + i];
         }
         __syncthreads();
-        if (LB && tid == 0) {
-            // PUBLISH this tile's record (k_fe_persist's arithmetic): tile 0 folds the previous call's state in, P'_0 = P_0 + rho W_0
-            const cf A = pr[0], B = pr[1];
-            float Pr = fmaf(-p.rho, A.x, B.x), Pi = fmaf(-p.rho, A.y, B.y);
-            if (c == 0) {
-                const cf vs = *(const cf *)p.v_in, pl = *(const cf *)p.probeL;
-                const float V0r = (vs.x - pl.x) * p.inv_lamL, V0i = (vs.y - pl.y) * p.inv_lamL;
-                Pr = fmaf(p.rho, fmaf(p.lamHh, V0r, A.x), Pr); Pi = fmaf(p.rho, fmaf(p.lamHh, V0i, A.y), Pi);
-            }
-#ifndef FEL_NOPUB            /* experiment (results wrong): nothing published */
-            fe_publish(p.prec + 2 * (size_t)c, Pr, p.epoch);
-            fe_publish(p.prec + 2 * (size_t)c + 1, Pi, p.epoch);
-#endif
-        }
         if (lane == 0 && wave > 0) {
 #pragma unroll
             for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * 10 + i];
@@ -244,56 +204,8 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
     if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
     if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
-    // LB, wave 0: lane k-1 fetches the record of tile c - k before the m = 5 stage and the wave sums them before the m = 10
-    // stage, whose barrier publishes the carry to the workgroup
-    uint64_t lb_re = 0, lb_im = 0;
-    const int lbk = lane + 1;
-#ifdef FEL_NOLOAD            /* experiment (results wrong): no record loads */
-    const bool lb_mine = false;
-#else
-    const bool lb_mine = LB && wave == 0 && lb_try && lbk <= (int)p.carry_K && lbk <= c;
-#endif
-    if constexpr (LB) {
-        if (lb_mine) {
-            lb_re = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lb_im = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     if constexpr (TAIL && N3 == 0) hb_stage_ip<8, 5>(buf, tid, NT, p.taps_k, 1.0f);            // 2048 outputs, L(16) -> L(8), in place
     else if constexpr (TAIL) FE_STAGE(N3, 5, 6 * N3);
-    if constexpr (LB) {
-        if (wave == 0) {
-            bool ok = !lb_mine || ((uint32_t)(lb_re >> 32) == p.epoch && (uint32_t)(lb_im >> 32) == p.epoch);
-            if (lb_try) {
-                for (int spin = 0; spin < FEP_SPINS && !__all(ok); spin++) {   // bounded: a late predecessor costs this tile the fallback
-                    __builtin_amdgcn_s_sleep(16);
-                    if (!ok) {
-                        lb_re = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        lb_im = __hip_atomic_load(p.prec + 2 * (size_t)(c - lbk) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = (uint32_t)(lb_re >> 32) == p.epoch && (uint32_t)(lb_im >> 32) == p.epoch;
-                    }
-                }
-            }
-            const bool all_ok = lb_try && __all(ok);
-            float wr = 0.f, wi = 0.f;
-            if (lb_mine && all_ok) {
-                const float pw = p.rho_pow[lbk - 1];
-                wr = pw * __builtin_bit_cast(float, (uint32_t)lb_re); wi = pw * __builtin_bit_cast(float, (uint32_t)lb_im);
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { wr += __shfl_xor(wr, d); wi += __shfl_xor(wi, d); }
-            if (lane == 0) {
-                if (c == 0) {                                  // tile 0: its carry comes from the previous call's state
-                    const cf vs = *(const cf *)p.v_in, pl = *(const cf *)p.probeL;
-                    sV[0] = (vs.x - pl.x) * p.inv_lamL; sV[1] = (vs.y - pl.y) * p.inv_lamL;
-                } else {
-                    const cf A = pr[0];
-                    sV[0] = (wr - A.x) * p.inv_lamHh; sV[1] = (wi - A.y) * p.inv_lamHh;
-                }
-                sV[2] = all_ok ? 1.f : 0.f;
-            }
-        }
-    }
     if constexpr (TAIL) FE_STAGE(N3 + 1, 10, 6 * N3 + 10);
 #undef FE_STAGE
     constexpr int NLAST = (N0 / 2) >> (H - 1);
@@ -316,21 +228,6 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             *reinterpret_cast<float4 *>(out + ((p.out_pos0 + qa + i) & p.out_mask)) = make_float4(a.x, a.y, b.x, b.y);
         }
         if (((nown - head) & 1) && tid == 0) out[(p.out_pos0 + qa + nown - 1) & p.out_mask] = ld(nown - 1);
-    } else if constexpr (LB) {
-        const bool ok = sV[2] != 0.f;
-        const float Vr = ok ? sV[0] : 0.f, Vi = ok ? sV[1] : 0.f;
-#ifdef FEL_NOFIX             /* experiment (results wrong): outputs stored uncorrected */
-        fe_arb_store<NT, GS, false>(p, ap, qa, fin, bk0, bk1, tid);
-#else
-        fe_arb_store<NT, GS, true>(p, ap, qa, fin, bk0, bk1, tid, Vr, Vi);
-#endif
-        if (tid == 0) {
-            p.fixflag[c] = ok ? 0 : 1;
-            if (ok && c == p.c_end) {                           // dc state handed to the next call
-                const cf pe = *(const cf *)p.probeE;
-                *(cf *)p.v_out = cfm(fmaf(p.lamEnd, Vr, pe.x), fmaf(p.lamEnd, Vi, pe.y));
-            }
-        }
     } else {
         fe_arb_store<NT, GS>(p, ap, qa, fin, bk0, bk1, tid);
     }
@@ -342,348 +239,6 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             nh[i] = sb < 0 ? hist[(long)i + p.n_in] : x[sb];
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// PERSISTENT one-level front end: the whole chain dc-block -> cascade -> resampler WITH the dc carry applied before the outputs
-// are stored -- no read-modify-write pass over the resampled stream afterwards (k_fe_tilefix moved 2 x 8 * rate bytes per input
-// sample and 11 % of a cfg2 step).
-//
-// The carry of tile c is V_c = (W_c - A_c) lambda^-Hh with W_c = sum_{k=1..K} rho^(k-1) P_{c-k}: a short sum over the records
-// P = probeB - rho probeA of its K ~ 15 predecessors (rho^K < 1e-12), each known as soon as that predecessor has run its dc scan.
-// Making a tile WAIT for them inside a one-tile-per-workgroup launch stalls every tile on its slowest neighbour (tried in
-// round 1: -35 %).  Here a workgroup is persistent and walks a sequence of tiles; it HOLDS a tile's finished outputs in
-// registers and stores them one iteration later, behind the dc scan of its next tile.  By then the predecessors' records were
-// published a whole tile-time ago, so the look-back is one L2 read that has long landed:
-//     iteration i:  take ticket -> tile c;  DMA tile c;  [wave 0: request the records tile c_prev needs]
-//                   dc scan of c, PUBLISH P_c;  [wave 0: sum the records -> V_cprev]
-//                   store the held outputs of c_prev, corrected;  cascade + resampler of c -> hold.
-// Tiles are handed out by monotonic ticket counters (8, one per blockIdx & 7 ~ XCD; chunks of `chunk` consecutive tiles go
-// round-robin to the counters, so an XCD's L2 sees contiguous tiles and the predecessors of any tile are held by workgroups
-// that are running).  Records are 8-byte {value, epoch} granules written and read with agent-scope relaxed atomics (sc1: L2 is
-// the point of coherence inside an XCD and the stores write through; MI355X_MICROARCH.md, handoff-1to1); the epoch makes stale
-// records of earlier launches unmistakable, nothing is ever cleared.
-// Correctness never depends on timing or residency: the wait for a record is BOUNDED; a tile whose carry did not arrive is
-// stored uncorrected and flagged, and k_fe_tilefix (launched after every block, one early-exit wave per tile) corrects exactly
-// the flagged tiles from the probes, as before.
-// ---------------------------------------------------------------------------------------------
-template <int N3>
-__global__ __launch_bounds__(256, 4) void k_fe_persist(pmr_fe_params p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = 256, SPT = 16, N0 = NT * SPT, H = N3 + 2;
-    constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;
-    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
-    cf *wagg = buf + N0;
-    cf *bnd = wagg + NT / 64;                                 // [4][10]
-    cf *pr = bnd + 40;                                        // [2] probes A, B of the current tile
-    float *sV = reinterpret_cast<float *>(pr + 2);            // [2] carry of the held tile, [2] = ok flag
-    int *s_next = reinterpret_cast<int *>(sV + 4);            // next tile of this workgroup (-1: none)
-
-    const int tid0 = threadIdx.x;
-    int tid = tid0, lane = tid & 63, wave = tid >> 6;
-    const cf *__restrict__ x = (const cf *)p.x;
-    const cf *__restrict__ hist = (const cf *)p.hist;
-    const float lam = -p.dc_a1;
-    const unsigned xc = blockIdx.x & 7u;
-#ifdef FEP_STATIC
-    unsigned st_m = blockIdx.x >> 3;
-#endif
-    const auto take = [&]() {                                  // thread 0: one ticket -> tile index or -1
-#ifdef FEP_STATIC
-        const unsigned m = st_m; st_m += (gridDim.x + 7u) >> 3;
-#else
-        const unsigned m = atomicAdd(&p.tickets[xc], 1u) - p.ticket_base[xc];
-#endif
-        const unsigned long long t = ((unsigned long long)(m / p.chunk) * 8u + xc) * p.chunk + m % p.chunk;
-        return t < p.ntiles ? (int)t : -1;
-    };
-    if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
-    // Workgroups that share a CU start out of phase (the k-th quarter of the grid k * stagger us late): persistent workgroups
-    // launched together otherwise move in lockstep -- all four of a CU wait for HBM at once, then all compute at once with the
-    // memory pipe idle (measured: 2x the time of one-tile-per-workgroup launches, whose dispatch staggers them for free).
-    {
-        // whichever way the dispatcher fills the CUs (one workgroup per CU per round, or a CU at a time), its four get four slots
-        const unsigned slot = ((blockIdx.x >> 3) + blockIdx.x / ((gridDim.x + 3u) / 4u)) & 3u;
-        for (unsigned i = 0; i < slot * p.stagger; i++) __builtin_amdgcn_s_sleep(32);          // 32 x 64 cycles ~ 1 us
-    }
-    if (tid == 0) *s_next = take();
-    const float lp = p.lam_lane_pow[lane], l15 = p.lam_lane_pow[(lane & 15) + 1], l31 = p.lam_lane_pow[(lane & 31) + 1];
-
-    // Outputs of the previous tile, held until its carry is known -- in LDS (6 KB), not in registers: phase B of the next tile is
-    // the register peak of the kernel.  Per thread: two outputs (y0, y1) and the gains (u0, u1) of the carry's exponential at
-    // them; thread 0 also the odd head output.  Which outputs a thread owns is recomputed from the tile index when they are stored.
-    float4 *hold_y = reinterpret_cast<float4 *>(s_next + 4);   // [256] (y0.re, y0.im, y1.re, y1.im)
-    float2 *hold_u = reinterpret_cast<float2 *>(hold_y + NT);  // [256] (u0, u1)
-    float *hold_h = reinterpret_cast<float *>(hold_u + NT);    // [3] head output (re, im, gain), [3..4] probe A of the held tile
-    // Branch taps live in LDS here, not in scalar registers: kept in SGPRs across the loop (48 of them beside ~80 pointers and
-    // constants) they spill, and every spilled tap costs a v_readlane per use (PMC: +370 vector instructions per wave and tile).
-    float *tapsL = hold_h + 8;                                 // [48]
-    if (tid0 < 48) tapsL[tid0] = p.taps_k[tid0];
-    int h_c = -1;                                              // held tile (-1: none); wave-uniform
-    uint64_t lb_re = 0, lb_im = 0;                            // wave 0, lane k-1: record of tile h_c - k
-
-    const auto lookback_request = [&]() {                     // wave 0: one record per lane
-        const int k = lane + 1;
-#ifdef FEP_NOLB
-        return;
-#endif
-        if (wave == 0 && h_c >= 0 && k <= (int)p.carry_K && k <= h_c) {
-            lb_re = __hip_atomic_load(p.prec + 2 * (size_t)(h_c - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lb_im = __hip_atomic_load(p.prec + 2 * (size_t)(h_c - k) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    const auto lookback_finish = [&]() {                      // wave 0: V of the held tile -> LDS (or: not available)
-        if (wave != 0 || h_c < 0) return;
-#ifdef FEP_NOLB
-        if (lane == 0) sV[2] = 0.f;
-        return;
-#endif
-        const int k = lane + 1;
-        const bool mine = k <= (int)p.carry_K && k <= h_c;
-        bool ok = !mine || ((uint32_t)(lb_re >> 32) == p.epoch && (uint32_t)(lb_im >> 32) == p.epoch);
-        for (int spin = 0; spin < FEP_SPINS && !__all(ok); spin++) {      // bounded: a late predecessor costs this tile the fallback, nothing more
-            __builtin_amdgcn_s_sleep(16);
-            if (!ok) {
-                lb_re = __hip_atomic_load(p.prec + 2 * (size_t)(h_c - k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                lb_im = __hip_atomic_load(p.prec + 2 * (size_t)(h_c - k) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (uint32_t)(lb_re >> 32) == p.epoch && (uint32_t)(lb_im >> 32) == p.epoch;
-            }
-        }
-        const bool all_ok = __all(ok);
-        float wr = 0.f, wi = 0.f;
-        if (mine && all_ok) {
-            const float pw = p.rho_pow[k - 1];
-            wr = pw * __builtin_bit_cast(float, (uint32_t)lb_re); wi = pw * __builtin_bit_cast(float, (uint32_t)lb_im);
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { wr += __shfl_xor(wr, d); wi += __shfl_xor(wi, d); }
-        if (lane == 0) {
-            if (h_c == 0) {                                    // tile 0: its carry comes from the previous call's state
-                const cf vs = *(const cf *)p.v_in, pl = *(const cf *)p.probeL;
-                sV[0] = (vs.x - pl.x) * p.inv_lamL; sV[1] = (vs.y - pl.y) * p.inv_lamL;
-            } else {
-                sV[0] = (wr - hold_h[3]) * p.inv_lamHh; sV[1] = (wi - hold_h[4]) * p.inv_lamHh;
-            }
-            sV[2] = all_ok ? 1.f : 0.f;
-        }
-    };
-    const auto flush = [&]() {                                 // all threads: store the held tile (after a barrier behind lookback_finish)
-        if (h_c < 0) return;
-        cf *__restrict__ out = (cf *)p.out;
-        const fe_arb_plan hp = fe_arb_prepare<NT>(p, (unsigned long long)h_c * p.TQ, tid);
-        const bool ok = sV[2] != 0.f;
-        const float Vr = ok ? sV[0] : 0.f, Vi = ok ? sV[1] : 0.f;
-        const float4 y = hold_y[tid];
-        const float2 u = hold_u[tid];
-        if (hp.pairs && hp.j0 + 1 < hp.jb) {
-            *reinterpret_cast<float4 *>(out + ((p.out_pos0 + hp.j0) & p.out_mask)) =
-                make_float4(fmaf(-Vr, u.x, y.x), fmaf(-Vi, u.x, y.y), fmaf(-Vr, u.y, y.z), fmaf(-Vi, u.y, y.w));
-        } else if (hp.j0 < hp.jb) {
-            out[(p.out_pos0 + hp.j0) & p.out_mask] = cfm(fmaf(-Vr, u.x, y.x), fmaf(-Vi, u.x, y.y));
-        }
-        if (tid == 0) {
-            if (hp.jh > hp.ja && hp.ja < hp.jb)
-                out[(p.out_pos0 + hp.ja) & p.out_mask] = cfm(fmaf(-Vr, hold_h[2], hold_h[0]), fmaf(-Vi, hold_h[2], hold_h[1]));
-            p.fixflag[h_c] = ok ? 0 : 1;
-            if (ok && h_c == p.c_end) {                         // dc state handed to the next call
-                const cf pe = *(const cf *)p.probeE;
-                *(cf *)p.v_out = cfm(fmaf(p.lamEnd, Vr, pe.x), fmaf(p.lamEnd, Vi, pe.y));
-            }
-        }
-    };
-
-    for (;;) {
-        __syncthreads();                                       // ticket visible; everyone is done with the previous tile's LDS image
-        const int c = *s_next;
-        if (c < 0) break;
-        // Every per-thread address below is loop-invariant; hoisted out of the loop they would stay live across it (~110 extra
-        // VGPRs: the kernel spills).  An opaque copy of the thread index per iteration keeps them where they are used.
-        tid = tid0;
-        asm volatile("" : "+v"(tid));
-        lane = tid & 63; wave = tid >> 6;
-        int zt = 0;
-        asm volatile("" : "+v"(zt));                           // (the taps' LDS reads are loop-invariant too)
-        const float *tl = tapsL + zt;
-        const long b0 = (long)c * p.T_own - p.Hh - p.pend;
-
-        // ---- phase A: raw tile -> LDS by LDS-DMA (source-side swizzle, see k_fe_fast) ----
-        const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
-        if (fast) {
-            const float4 *__restrict__ src = reinterpret_cast<const float4 *>(x + b0);
-#pragma unroll
-            for (int i = 0; i < N0 / 2 / NT; i++) {
-                const int s0 = wave * (N0 / 8) + i * 64;
-                __builtin_amdgcn_global_load_lds((gptr_t *)(src + fe_swz(s0 + lane)), (lptr_t *)(reinterpret_cast<float4 *>(buf) + s0), 16, 0, FE_DMA_AUX);
-            }
-        } else {
-#pragma unroll 4
-            for (int i = tid; i < N0; i += NT) {
-                const long b = b0 + i;
-                cf w = cfm(0.f, 0.f);
-                if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) w = hist[hi]; }
-                else if (b < (long)p.n_in) w = x[b];
-                buf[2 * fe_swz(i >> 1) + (i & 1)] = w;
-            }
-        }
-        int c_next = -1;
-        if (tid == 0) c_next = take();                         // the next ticket travels while this tile is processed
-        lookback_request();
-        const unsigned long long qa = (unsigned long long)c * p.TQ;
-        const fe_arb_plan ap = fe_arb_prepare<NT>(p, qa, tid);
-        if (p.tile_j && tid == 0) { ((unsigned long long *)p.tile_j)[2 * c] = ap.ja; ((unsigned long long *)p.tile_j)[2 * c + 1] = ap.jb; }
-        float bk0[14], bk1[14];
-#pragma unroll
-        for (int k = 0; k < 14; k++) { bk0[k] = ap.b0p[k]; bk1[k] = ap.b1p[k]; }
-        __syncthreads();
-
-        cf xs[SPT];
-        {
-            const float4 *rb = reinterpret_cast<const float4 *>(buf) + 8 * tid;
-            const int sw = (tid >> 1) & 7;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float4 v = rb[j ^ sw];
-                xs[2 * j] = cfm(v.x, v.y); xs[2 * j + 1] = cfm(v.z, v.w);
-            }
-        }
-        // ---- phase B: dc blocker from zero state, probes, first stage from registers (as k_fe_fast) ----
-        {
-            cf yb[SPT];
-            cf v = cfm(0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < SPT; j++) v = cfma(lam, v, xs[j]);
-            v = cfma(p.lam_pow16[0], dpp0c<0x111>(v), v);
-            v = cfma(p.lam_pow16[1], dpp0c<0x112>(v), v);
-            v = cfma(p.lam_pow16[2], dpp0c<0x114>(v), v);
-            v = cfma(p.lam_pow16[3], dpp0c<0x118>(v), v);
-            v = cfma(l15, dpp0c<0x142, 0xA>(v), v);
-            v = cfma(l31, dpp0c<0x143, 0xC>(v), v);
-            if (lane == 63) wagg[wave] = v;
-            const cf ex = dpp0c<0x138>(v);
-            __syncthreads();
-            cf cw = cfm(0.f, 0.f);
-            for (int w = 0; w < wave; w++) cw = cfma(p.lam_wave, cw, wagg[w]);
-            cf v1 = cfma(lp, cw, ex);
-            const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
-            const int pE = (c == p.c_end) ? p.off_end : -1;
-            const bool stray = (pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid);
-#pragma unroll
-            for (int j = 0; j < SPT; j++) {
-                const cf v0 = cfma(lam, v1, xs[j]);
-                yb[j] = csub(v0, v1);
-                v1 = v0;
-                if (stray) {
-                    if (SPT * tid + j == pL) ((cf *)p.probeL)[0] = v0;
-                    if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = v0;
-                }
-            }
-            if (tid == p.Hh / SPT - 1) { ((cf *)p.probeA)[c] = v1; pr[0] = v1; }
-            if (tid == NT - 1) { ((cf *)p.probeB)[c] = v1; pr[1] = v1; }
-            cf W[26];
-#pragma unroll
-            for (int i = 0; i < 10; i++) W[i] = dpp0c<0x138>(yb[6 + i]);
-#pragma unroll
-            for (int i = 0; i < 16; i++) W[10 + i] = yb[i];
-            if (lane == 63) {
-#pragma unroll
-                for (int i = 0; i < 10; i++) bnd[wave * 10 + i] = yb[6 + i];
-            }
-            __syncthreads();                                   // probes of this tile are in LDS (and, for tile 0 / c_end, in memory)
-            if (tid == 0) {
-                // PUBLISH this tile's record before anything can make this workgroup wait
-                const cf A = pr[0], B = pr[1];
-                float Pr = fmaf(-p.rho, A.x, B.x), Pi = fmaf(-p.rho, A.y, B.y);
-                if (c == 0) {                                  // tile 0 folds the previous call's state in: P'_0 = P_0 + rho W_0
-                    const cf vs = *(const cf *)p.v_in, pl = *(const cf *)p.probeL;
-                    const float V0r = (vs.x - pl.x) * p.inv_lamL, V0i = (vs.y - pl.y) * p.inv_lamL;
-                    Pr = fmaf(p.rho, fmaf(p.lamHh, V0r, A.x), Pr); Pi = fmaf(p.rho, fmaf(p.lamHh, V0i, A.y), Pi);
-                }
-                fe_publish(p.prec + 2 * (size_t)c, Pr, p.epoch);
-                fe_publish(p.prec + 2 * (size_t)c + 1, Pi, p.epoch);
-                *s_next = c_next;
-            }
-            lookback_finish();
-            if (lane == 0 && wave > 0) {
-#pragma unroll
-                for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * 10 + i];
-            }
-            float h0[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) h0[j] = tl[j];
-            cf *o = buf + tid * 9;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                cf a = cfm(0.f, 0.f);
-#pragma unroll
-                for (int j = 0; j < 6; j++) a = cfma(h0[j], W[2 * q + 2 * j], a);
-                o[q] = cadd_scale(W[2 * q + 5], a, 1.0f);
-            }
-        }
-        const cf A_c = pr[0];                                  // (read before the barrier below lets a later iteration overwrite it)
-        __syncthreads();                                       // z1 complete; the held tile's carry is in LDS
-        flush();
-
-        // ---- phase C ----
-        cf *R0 = buf, *R1 = buf + R1_OFF;
-#define FE_STAGE(E, MM, TOFF) do { constexpr int NOUT = (N0 / 2) >> (E); constexpr int PP = NOUT >= NT ? NOUT / NT : 1;          \
-        hb_stage_pp<PP, MM>(((E) & 1) ? R0 : R1, ((E) & 1) ? R1 : R0, tid, NOUT / PP, tl + (TOFF),                         \
-                            (E) == H - 1 ? p.zeta : 1.0f); } while (0)
-        if constexpr (N3 >= 2) FE_STAGE(1, 3, 6);
-        if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
-        FE_STAGE(N3, 5, 6 * N3); FE_STAGE(N3 + 1, 10, 6 * N3 + 10);
-#undef FE_STAGE
-        constexpr int GS = 1;                                  // the m = 10 stage leaves <= 512 outputs: layout L(2)
-        const cf *fin = ((H - 1) & 1) ? R1 : R0;
-
-        // ---- phase D: resampler outputs of this tile -> registers (held), with the gain of the carry's exponential for each ----
-        {
-            const auto resamp = [&](unsigned long long j, const float *bk, float &u) {
-                const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
-                const int qd = (int)((ph >> 24) - qa) + p.HhQ;                       // tile-local decimated index
-                const int ql = qd - 13;
-                cf y = cfm(0.f, 0.f);
-#pragma unroll
-                for (int k = 0; k < 14; k++) y = cfma(bk[k], fin[(ql + k) + ((ql + k) >> GS)], y);
-                u = p.Kgain * (p.GA[(unsigned)(ph & 0xffffffu) >> 16] * (p.T1[qd >> 5] * p.T2[qd & 31]));
-                return y;
-            };
-#ifdef FEP_DIRECT
-            fe_arb_store<NT, GS>(p, ap, qa, fin, bk0, bk1, tid);
-            if (tid == 0) p.fixflag[c] = 1;
-            continue;
-#endif
-            float u0 = 0.f, u1 = 0.f;
-            cf y0 = cfm(0.f, 0.f), y1 = y0;
-            if (ap.pairs && ap.j0 + 1 < ap.jb) { y0 = resamp(ap.j0, bk0, u0); y1 = resamp(ap.j0 + 1, bk1, u1); }
-            else if (ap.j0 < ap.jb) y0 = resamp(ap.j0, bk0, u0);
-            hold_y[tid] = make_float4(y0.x, y0.y, y1.x, y1.y);
-            hold_u[tid] = make_float2(u0, u1);
-            if (tid == 0) {
-                if (ap.jh > ap.ja && ap.ja < ap.jb) {
-                    const unsigned long long ph = (unsigned long long)p.phi0 + ap.ja * p.step;
-                    float uh = 0.f;
-                    const cf yh = resamp(ap.ja, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u, uh);
-                    hold_h[0] = yh.x; hold_h[1] = yh.y; hold_h[2] = uh;
-                }
-                hold_h[3] = A_c.x; hold_h[4] = A_c.y;
-            }
-            h_c = c;
-        }
-        // raw history for the next call, by the workgroup that ran tile 0
-        if (c == 0 && p.new_hist) {
-            cf *__restrict__ nh = (cf *)p.new_hist;
-            for (int i = tid; i < p.hcap; i += NT) {
-                const long sb = (long)i + (long)p.n_in - (long)p.hcap;
-                nh[i] = sb < 0 ? hist[(long)i + p.n_in] : x[sb];
-            }
-        }
-    }
-    // ---- the last held tile: its predecessors published at least one tile-time ago ----
-    lookback_request();
-    lookback_finish();
-    __syncthreads();
-    flush();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -761,14 +316,14 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int N3, int TAIL, bool LB = false>
+template <int MODE, int N3, int TAIL>
 static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
 #ifndef FE_EXTRA_LDS
 #define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup (8192 -> three tiles per CU instead of four) */
 #endif
-    const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 44) * sizeof(cf) + FE_EXTRA_LDS;
-    auto kern = k_fe_fast<MODE, N3, TAIL, LB>;
+    const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS;
+    auto kern = k_fe_fast<MODE, N3, TAIL>;
     PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p);
     return (int)hipGetLastError();
 }
@@ -789,14 +344,6 @@ extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsign
     hipStream_t st = (hipStream_t)s;
     int n3 = 0, tail = 0;
     if (!p->taps_valid || !fast_pattern(p, &n3, &tail)) return -1;
-    if (p->prec) {                                            /* look-back records given: carry applied in-kernel */
-        if (p->mode == FE_FULL && tail) {
-            if (n3 == 1) return launch_fast<FE_FULL, 1, 1, true>(st, p, ntiles, ev);
-            if (n3 == 2) return launch_fast<FE_FULL, 2, 1, true>(st, p, ntiles, ev);
-            if (n3 == 3) return launch_fast<FE_FULL, 3, 1, true>(st, p, ntiles, ev);
-        }
-        return (int)hipErrorInvalidValue;                     /* the caller planned on flags only this kernel writes */
-    }
     if (p->mode == FE_FULL && tail) {
         if (n3 == 0) return launch_fast<FE_FULL, 0, 1>(st, p, ntiles, ev);
         if (n3 == 1) return launch_fast<FE_FULL, 1, 1>(st, p, ntiles, ev);
@@ -810,18 +357,6 @@ extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsign
         if (n3 == 5) return launch_fast<FE_L1, 5, 0>(st, p, ntiles, ev);
     }
     return -1;
-}
-
-extern "C" int pmr_launch_fe_persist(pmr_stream_t s, const pmr_fe_params *p, unsigned nwg)
-{
-    int n3 = 0, tail = 0;
-    if (!p->taps_valid || p->mode != FE_FULL || !fast_pattern(p, &n3, &tail) || !tail || n3 < 1 || n3 > 3) return -1;
-    const size_t lds = (FE_PAD + 4096 + 4 + 40 + 2 + 4) * sizeof(cf) + 256 * 24 + 32 + 48 * 4;      /* + held outputs + taps */
-    hipStream_t st = (hipStream_t)s;
-    if (n3 == 1) hipLaunchKernelGGL(k_fe_persist<1>, dim3(nwg), dim3(256), lds, st, *p);
-    else if (n3 == 2) hipLaunchKernelGGL(k_fe_persist<2>, dim3(nwg), dim3(256), lds, st, *p);
-    else hipLaunchKernelGGL(k_fe_persist<3>, dim3(nwg), dim3(256), lds, st, *p);
-    return (int)hipGetLastError();
 }
 
 extern "C" int pmr_launch_fe_level2_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles)

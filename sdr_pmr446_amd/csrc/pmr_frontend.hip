@@ -443,17 +443,14 @@ __global__ __launch_bounds__(256) void k_fe_carry(pmr_fe_tiles_params t, pmr_fe_
 // its tile produced, in place:  xr[j] -= V_c * K * mu^q' * GA[idx_j]   (q' = tile-local decimated index, idx_j = polyphase
 // branch of output j; K, mu, GA: closed-form gains of the cascade for the exponential the missing carry adds).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_fe_fix_params f, unsigned n_q /*decimated samples of the block*/,
-                                                    const uint8_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_fe_fix_params f, unsigned n_q /*decimated samples of the block*/)
 {
     const unsigned lane = threadIdx.x & 63u;
     const unsigned c = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (c >= t.ntiles) return;
-    if (flags && !flags[c]) return;                              // fallback mode: k_fe_persist already corrected this tile
     const cf *pa = (const cf *)t.probeA, *pb = (const cf *)t.probeB;
-    // ---- V_c: the K-term sum spread over the lanes, in EXACTLY the arithmetic of k_fe_persist's in-kernel look-back (record of
-    // tile 0 = P_0 + rho W_0, lane k-1 holds term k, xor-butterfly reduction), so a tile corrected here as the persistent kernel's
-    // fallback gets bit for bit the carry it would have got there ----
+    // ---- V_c: the K-term sum spread over the lanes (record of tile 0 = P_0 + rho W_0, lane k-1 holds term k, xor-butterfly
+    // reduction) ----
     const unsigned kmax = c < t.K ? c : t.K;
     float ar = 0.f, ai = 0.f;
     float V0r = 0.f, V0i = 0.f;
@@ -541,7 +538,7 @@ static int launch_frontend_t(hipStream_t st, const pmr_fe_params *p, unsigned nt
 {
     const size_t n0 = (size_t)NT * SPT;
     const size_t lds = (FE_PAD + n0 + n0 / SPT + 32 + 10 * (NT / 64 + 1)) * sizeof(cf);   /* pad + tile + scan scratch + halo exchange */
-    static unsigned long long attr_set = 0;
+    static pmr_attr_flags attr_set{0};
     if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_frontend<NT, SPT, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -589,9 +586,9 @@ extern "C" int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t,
 }
 
 extern "C" int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q,
-                                     const uint8_t *flags, const pmr_launch_events *ev)
+                                     const pmr_launch_events *ev)
 {
     if (!t->ntiles) return 0;
-    PMR_LAUNCH_EV(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, ev, *t, *f, n_q, flags);
+    PMR_LAUNCH_EV(k_fe_tilefix, dim3((t->ntiles + 3) / 4), dim3(256), 0, (hipStream_t)s, ev, *t, *f, n_q);
     return (int)hipGetLastError();
 }

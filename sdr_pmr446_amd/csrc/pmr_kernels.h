@@ -20,9 +20,6 @@ enum { PMR_FIR_MFMA = 0, PMR_FIR_PAIR = 1, PMR_FIR_LDS = 2, PMR_FIR_TM = 3 };
 typedef struct {
     int fe_staged;          /* PMR_FRONTEND=staged: one kernel per front-end stage                         */
     int fe_generic;         /* PMR_FE_KERNEL=generic: run-time-parameterised k_frontend                     */
-    int fe_persist;         /* PMR_FE_PERSIST=1: persistent one-level kernel, dc carry applied in-kernel      */
-    int fe_lookback;        /* PMR_FE_LOOKBACK=1: one tile per workgroup with the dc carry applied in-kernel (look-back) */
-    int fe_stagger;         /* PMR_FE_STAGGER=n: start-up phase shift of the persistent kernel's workgroups  */
     int fe_levels;          /* PMR_FE_LEVELS=1|2: force the one- / two-level front end (0 = automatic)      */
     int l2_on_fe;           /* PMR_L2_STREAM=fe: level 2 on the front-end stream                            */
     int chan_generic;       /* PMR_CHANNELIZER=generic: k_channelize for M = 16 too                         */
@@ -187,20 +184,6 @@ typedef struct {
     unsigned fix_limit;         /* new samples with index >= fix_limit were already corrected in place (k_fe_carry)   */
     uint32_t step_rinv;         /* floor(2^56 / step) clamped to 32 bits: integer ceil-division by the resampler step */
     void *tile_j;               /* nullable [ntiles][2] u64: the tile's resampler output range [ja, jb), for k_fe_tilefix */
-    /* ---- persistent one-level kernel (k_fe_persist): tiles are handed out by tickets, the dc carry of a tile is summed from
-     * the records its predecessors publish IN THE SAME LAUNCH and applied before the tile's outputs are stored ---- */
-    uint32_t *tickets;          /* [8] monotonic ticket counters (one per XCD guess = blockIdx & 7), never reset            */
-    uint32_t ticket_base[8];    /* value of tickets[x] when this launch starts (the host knows it: see fe_persist_advance)   */
-    unsigned chunk;             /* tiles per chunk; chunks go round-robin to the 8 counters                                  */
-    unsigned stagger;           /* start-up phase shift between the workgroups of a CU, ~us per quarter of the grid           */
-    unsigned ntiles;            /* tiles of this launch                                                                      */
-    uint64_t *prec;             /* [max tiles][2] published carry records {value bits, epoch}: re, im                        */
-    uint32_t epoch;             /* tag of this launch's records                                                              */
-    uint8_t *fixflag;           /* [ntiles] 1 = the carry of this tile was not available in time: k_fe_tilefix corrects it   */
-    const void *v_in; void *v_out;                          /* dc state before / after the block                             */
-    const float *rho_pow; unsigned carry_K;                 /* rho^k table, look-back length                                 */
-    float rho, lamHh, inv_lamHh, inv_lamL, lamEnd;          /* as pmr_fe_tiles_params                                        */
-    const float *GA, *T1, *T2; float Kgain;                 /* closed-form gains of the cascade for the carry's exponential */
     int m[PMR_FE_MAX_STAGES], tap_off[PMR_FE_MAX_STAGES];
     float dc_a1, zeta, lam_wave;
     float lam_pow16[6];         /* lambda^(spt * 2^j)                                                */
@@ -238,14 +221,11 @@ int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles,
 int pmr_launch_frontend_l2(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int fast);
 /* specialised kernels of pmr_fe_fast.hip; return -1 when the cascade is not one they cover */
 int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev);
-/* persistent one-level kernel; `nwg` workgroups.  Returns -1 when the cascade is not covered. */
-int pmr_launch_fe_persist(pmr_stream_t s, const pmr_fe_params *p, unsigned nwg);
 /* tile carries of a level-1 launch (V[c], next call's dc state) + in-place dc fix of the ring samples [f->j0, f->ny) */
 int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f);
-/* one-level front end, carries + correction of the resampled stream in place, one wave per tile.  `flags` (nullable): only
- * tiles whose flag is set are handled (fallback of the persistent kernel); NULL: every tile */
+/* one-level front end, carries + correction of the resampled stream in place, one wave per tile */
 int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q,
-                          const uint8_t *flags, const pmr_launch_events *ev);
+                          const pmr_launch_events *ev);
 
 /* waterfall periodogram (pmr_spectrum.hip): PSD (linear, averaged, fft-shifted, 4 wlen bins) of ny ring samples from pos0 */
 unsigned pmr_spgram_max_workgroups(void);
@@ -257,6 +237,17 @@ int pmr_launch_spgram(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t
 #endif
 
 #if defined(__HIPCC__)
+#include <atomic>
+/* hipFuncSetAttribute is per device, and a process may hold handles on several GPUs driven from several threads
+ * (pmr_chain_cfg.device): the "dynamic-LDS limit already raised" flag is one bit per device ordinal in an ATOMIC word.
+ * Two threads racing on the same bit both raise the limit -- harmless; none ever skips it. */
+typedef std::atomic<unsigned long long> pmr_attr_flags;
+static inline bool pmr_attr_needed(pmr_attr_flags &mask)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    return !(mask.fetch_or(1ull << dev, std::memory_order_relaxed) >> dev & 1ull);
+}
 /* XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), so workgroup b takes LOGICAL
  * index (b % 8) * (n / 8) + b / 8 -- every XCD then works through a CONTIGUOUS range of tiles, and the rows two neighbouring
  * tiles both read (filter history: 25 of 33 rows in k_pfb_wide, 408 of 664 in the FIR window) are fetched into one L2 once

@@ -13,17 +13,6 @@
 
 #include "pmr_kernels.h"
 
-// hipFuncSetAttribute is per device: a process may hold handles on several GPUs (pmr_chain_cfg.device), so the
-// "already raised the dynamic-LDS limit" flag is one bit per device ordinal, not one bool per process
-static inline bool pmr_attr_needed(unsigned long long &mask)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    if (mask >> dev & 1ull) return false;
-    mask |= 1ull << dev;
-    return true;
-}
-
 typedef float2 cf;
 
 static __device__ __forceinline__ cf cf_make(float r, float i) { cf v; v.x = r; v.y = i; return v; }
@@ -754,7 +743,7 @@ extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, u
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
     const size_t lds = ((size_t)ft * p->M + p->M / 2) * sizeof(cf);
-    static unsigned long long attr_set = 0;
+    static pmr_attr_flags attr_set{0};
     if (pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -801,7 +790,7 @@ extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const f
     if (mode == PMR_FIR_LDS && M >= 16 && ntaps <= 512) {
         const unsigned rows = FL_T + PMR_AUDIO_J + ntaps - 1;
         const size_t lds = ((size_t)rows * 16 + 16 * ((rows >> 5) + 1)) * sizeof(float);
-        static unsigned long long attr_set = 0;
+        static pmr_attr_flags attr_set{0};
         if (pmr_attr_needed(attr_set)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_lds),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -100,12 +100,9 @@ extern "C" int pmr_launch_spgram(pmr_stream_t s, const void *xr, uint64_t xr_mas
     const unsigned maxwg = pmr_spgram_max_workgroups();
     const unsigned chunk = (n_tr + maxwg - 1) / maxwg, nwg = (n_tr + chunk - 1) / chunk;
     const size_t lds = (size_t)(2 * P + P / 2) * sizeof(cf);               /* <= 80 KB at P = 4096 */
-    static unsigned long long attr_set = 0;
-    int dev = 0;
-    if (lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !(attr_set >> dev & 1ull)) {
+    static pmr_attr_flags attr_set{0};
+    if (lds > 64 * 1024 && pmr_attr_needed(attr_set))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgram), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set |= 1ull << dev;
-    }
     hipStream_t st = (hipStream_t)s;
     hipLaunchKernelGGL(k_spgram, dim3(nwg), dim3(SG_NT), lds, st, (const cf *)xr, (unsigned long long)xr_mask, (unsigned long long)pos0,
                        ny, wlen, log2P, n_tr, chunk, win, (const cf *)tw, partial);

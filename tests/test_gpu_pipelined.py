@@ -113,8 +113,6 @@ CASES = [
     ({}, CFG2, RAGGED2, True),                         # CTCSS branch enabled (second FIR pass + detector kernels in the back end)
     ({"PMR_L2_STREAM": "fe"}, CFG5, RAGGED5, False),
     ({"PMR_FRONTEND": "staged"}, CFG2, RAGGED2, False),
-    ({"PMR_FE_PERSIST": "1"}, CFG2, RAGGED2, False),        # in-kernel carry hand-off with blocks in flight
-    ({"PMR_FE_LOOKBACK": "1"}, CFG3, RAGGED3, False),       # look-back carry, fallback flags, blocks in flight
     ({"PMR_FE_EVENT": "marker"}, CFG2, RAGGED2, False),     # "front end done" as a record packet instead of the launch's own signal
     ({"PMR_STREAM_PRIO": "fe"}, CFG3, RAGGED3, False),      # front-end stream at the higher priority
     ({"PMR_TILEFIX_STREAM": "be"}, CFG2, RAGGED2, True),    # carry pass at the head of the back-end stream (CTCSS on)

@@ -38,10 +38,6 @@ CFG3 = (61.44e6, 256, [1 << 21, 1500000])
 VARIANTS = [
     ({"PMR_FRONTEND": "staged"}, CFG2),
     ({"PMR_FE_KERNEL": "generic"}, CFG2),
-    ({"PMR_FE_PERSIST": "1"}, CFG2),
-    ({"PMR_FE_PERSIST": "1", "PMR_FE_STAGGER": "0"}, CFG3),
-    ({"PMR_FE_LOOKBACK": "1"}, CFG2),                        # one tile per workgroup, dc carry by in-kernel look-back
-    ({"PMR_FE_LOOKBACK": "1"}, CFG3),
     ({"PMR_FE_LEVELS": "2"}, CFG3),
     ({"PMR_L2_STREAM": "fe"}, CFG5),
     ({"PMR_FE_KERNEL": "generic"}, CFG5),

@@ -9,6 +9,6 @@ import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']
-        print('value %.1f GS/s  ms/step %.4f  fe(contended) %.4f' % (d['value']/1e3,d['ms_per_step'],r['avg_kernel_ms']), {k:round(v,4) for k,v in r['kernels_ms_per_step_isolated'].items()}, 'fallback', r.get('carry_fallback_tiles',{}).get('flagged'))
+        print('value %.1f GS/s  ms/step %.4f  fe(contended) %.4f' % (d['value']/1e3,d['ms_per_step'],r['avg_kernel_ms']), {k:round(v,4) for k,v in r['kernels_ms_per_step_isolated'].items()})
 "
 done
