@@ -164,7 +164,9 @@ int         pmr_chain_profile_get(pmr_chain q, unsigned i, double *total_ms, uns
 
 /* ---- introspection (tests): designed coefficients / integers, and the last block's intermediates ---- */
 enum { PMR_INFO_NUM_STAGES = 0, PMR_INFO_M_STAGE = 1, PMR_INFO_ARB_STEP = 2, PMR_INFO_NCO_DTHETA = 3,
-       PMR_INFO_ARB_NPFB = 4, PMR_INFO_ARB_M = 5, PMR_INFO_PFB_P = 6 };
+       PMR_INFO_ARB_NPFB = 4, PMR_INFO_ARB_M = 5, PMR_INFO_PFB_P = 6,
+       PMR_INFO_CARRY_AT_LOAD = 7 /* 1: the front end's dc carry is applied where the channelizer loads the resampled stream
+                                     (one-level front ends with the 16- / 256-channel kernels); handle only */ };
 enum { PMR_DESIGN_HALFBAND = 0, PMR_DESIGN_ARB = 1, PMR_DESIGN_PFB = 2 };
 unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx);
 unsigned pmr_chain_design(pmr_chain q, int what, unsigned idx, float *out, unsigned cap);

@@ -125,6 +125,10 @@ struct pmr_chain_s {
     float *d_fe_G1;                  /* [..] fe1_K * mu^e: level 1's carry gain per tile-local index (level 2's load-time fix) */
     cfl *d_fe_ring1; uint64_t ring1_mask;
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
+    /* dc carry applied where the channelizer loads the resampled stream (pmr_carry_fix): supported by this plan's kernels;
+     * used by THIS call; table mu^q' as one float product; LDS table length; decimated samples per frame; index bias (tiles) */
+    int cal_ok, cal_now; float *d_fe_G12; unsigned cal_nv, cal_adv_q, cal_nbias;
+    unsigned cal_fix_limit, cal_ntiles, cal_slot; uint32_t cal_phi0;   /* ... of this call's block (frontend_fused) */
     int tf_on_backend, pend_tf; unsigned pend_tf_Q;    /* one-level form: k_fe_tilefix deferred to the back-end stream (uses pend_t2 / pend_f2) */
     int tf_last_be;                  /* the previous pipelined call's carry pass ran on the back-end stream */
     /* two-step synchronous form (pmr_chain_channelize_block / _demodulate_block): the audio part of the block channelized last */
@@ -448,6 +452,17 @@ static int fe_init(pmr_chain q)
                 free(g1);
             }
         }
+        if (!rc && !q->fe_two) {
+            /* one-level form, carry applied at the channelizer's loads: mu^q' as ONE table holding the float products
+             * T1[q' >> 5] * T2[q' & 31] that k_fe_tilefix forms, so both correct a sample identically */
+            float *g12 = (float *)calloc((size_t)n1 * 32, sizeof(float));
+            if (!g12) rc = fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+            else {
+                for (unsigned e = 0; e < n1 * 32; e++) g12[e] = t1[e >> 5] * t2[e & 31];
+                rc = dev_upload(q, &q->d_fe_G12, g12, (size_t)n1 * 32);
+                free(g12);
+            }
+        }
         free(t1);
         if (rc) return rc;
         if ((rc = dev_upload(q, &q->d_fe_T2, t2, 32))) return rc;
@@ -603,6 +618,14 @@ static int chain_init(pmr_chain q)
     if (q->chan_wide && (rc = dev_alloc(q, (void **)&q->d_chan_x, ((size_t)q->chan_size + 2) * M * sizeof(cfl)))) return rc;
     q->l2_on_backend = !q->sw.l2_on_fe;
     q->tf_on_backend = 0;
+    q->cal_ok = 0;
+    if (q->fe_on && !q->fe_two && q->d_fe_G12 && !q->sw.carry_inplace) {
+        q->cal_adv_q = (unsigned)(((uint64_t)M * d->arb_step) >> 24) + 1u;
+        q->cal_ok = pmr_channelize_carry_at_load(M, p, d->nco_period, q->chan_small, q->chan_wide, q->sw.chan_pair, q->sw.chan_unfused,
+                                                 q->cal_adv_q, (unsigned)q->fe_TQ);
+        q->cal_nv = pmr_channelize_carry_nv(M, q->cal_adv_q, (unsigned)q->fe_TQ);
+        q->cal_nbias = (unsigned)(((uint64_t)(p + 4) * q->cal_adv_q) / (unsigned)q->fe_TQ) + 2u;
+    }
 
     q->n_raw = 0; q->arb_phase = 0; q->xr_abs = 0; q->frames_done = 0; q->n_calls = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "init sync");
@@ -632,6 +655,7 @@ static void read_switches(pmr_switches *w)
     w->host_gate = !env_is("PMR_HOST_GATE", "0");
     w->fe_marker = env_is("PMR_FE_EVENT", "marker");
     w->tf_on_be = env_is("PMR_TILEFIX_STREAM", "be") ? 1 : env_is("PMR_TILEFIX_STREAM", "fe") ? 2 : 0;
+    w->carry_inplace = env_is("PMR_CARRY", "inplace");
     w->no_zerocopy = env_is("PMR_ZEROCOPY", "0");
     { const char *e = getenv("PMR_ZEROCOPY_MAX"); w->zc_max_in = e && atol(e) > 0 ? (unsigned)atol(e) : ZC_MAX_IN; }
 }
@@ -719,7 +743,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_dbg_ct, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_G12, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events,
                      q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1 };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
@@ -966,6 +990,13 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[slot]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
     f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
     f.Kgain = q->fe_Kgain;
+    if (q->cal_now) {
+        /* carry applied at the channelizer's loads: here only the tail later calls re-read as history is corrected in place
+         * (every sample from (frames_done' - p) M on, frames_done' M >= end - (M - 1)) */
+        const unsigned keep = (q->d.pfb_p + 3u) * q->M;
+        f.j0 = ny > keep ? ny - keep : 0;
+        q->cal_fix_limit = f.j0; q->cal_ntiles = ntiles; q->cal_slot = slot; q->cal_phi0 = q->arb_phase;
+    }
     if (q->tf_on_backend) {
         /* PMR_TILEFIX_STREAM=be: the carry pass heads the back-end stream's work for this block; the front-end stream then
          * carries front-end kernels only, back to back */
@@ -1086,6 +1117,7 @@ int pmr_chain_frontend_block(pmr_chain q, const void *d_iq, unsigned n_in, unsig
     const int keep_l2 = q->l2_on_backend, keep_tf = q->tf_on_backend;
     q->l2_on_backend = 0;                         /* this entry point has no back-end stream: everything on stream_fe */
     q->tf_on_backend = 0;
+    q->cal_now = 0;                               /* ... and no channelizer: the carry is applied in place */
     q->sfe = q->stream_fe;
     q->fe_done_ev = NULL; q->fe_done_used = 0;
     int rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
@@ -1437,8 +1469,11 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     }
     const uint64_t xr_abs0 = q->xr_abs;
     unsigned ny = 0;
+    /* the ring must hold corrected samples when something besides the channelizer reads it (debug capture, waterfall) */
+    q->cal_now = q->cal_ok && !q->dbg_on && !q->spec_nfft;
+    q->cal_fix_limit = 0;
     if (q->fe_on && !q->fe_two) {
-        q->tf_on_backend = !single && tilefix_on_backend(q);
+        q->tf_on_backend = !single && (q->cal_now || tilefix_on_backend(q));
         if (!single && !q->tf_on_backend && q->tf_last_be)    /* this block's carry pass reads the dc state the previous one (back-end stream) wrote */
             HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[(par + PIPE_DEPTH - 1) % PIPE_DEPTH], 0), "wait previous carry pass");
         q->tf_last_be = q->tf_on_backend;
@@ -1489,6 +1524,13 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
         c.taps_t = q->d_pfb_taps_t; c.fft_tw = q->d_fft_tw; c.nco_cs = q->d_nco_cs; c.nco_period = d->nco_period;
         c.fm_ref = d->fm_ref; c.chan_out = d_chan_out; c.chan_stride = pcm_stride;
         c.rssi_part = d_rssi_db ? q->d_rssi_part : NULL;
+        if (q->cal_now && q->cal_fix_limit) {
+            c.fix.V = q->d_fe_V[q->cal_slot]; c.fix.GA = q->d_fe_GA; c.fix.G12 = q->d_fe_G12;
+            c.fix.pos0 = xr_abs0; c.fix.phi0 = q->cal_phi0; c.fix.step = d->arb_step; c.fix.fix_limit = q->cal_fix_limit;
+            c.fix.ntiles = q->cal_ntiles; c.fix.TQ = (unsigned)q->fe_TQ; c.fix.HhQ = (unsigned)q->fe_HhQ;
+            c.fix.nbias = q->cal_nbias; c.fix.qbias = q->cal_nbias * (unsigned)q->fe_TQ; c.fix.nv = q->cal_nv;
+            c.fix.Kgain = q->fe_Kgain;
+        }
         if (q->reset_pending) {                       /* freqdem_reset (:866) of the flagged channels: takes effect on this call's first frame */
             HIPCHK(hipMemcpyAsync(q->d_reset_flags, q->h_reset_flags, M, hipMemcpyHostToDevice, q->stream), "reset flags");
             c.reset_flags = q->d_reset_flags;
@@ -1893,6 +1935,7 @@ unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx)
     case PMR_INFO_ARB_NPFB:   return PMR_ARB_NPFB;
     case PMR_INFO_ARB_M:      return PMR_ARB_M;
     case PMR_INFO_PFB_P:      return q->d.pfb_p;
+    case PMR_INFO_CARRY_AT_LOAD: return (unsigned)q->cal_ok;
     default: return 0;
     }
 }

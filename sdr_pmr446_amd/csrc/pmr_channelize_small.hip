@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "pmr_kernels.h"
+#include "pmr_carry_load.hpp"
 
 // complex = ext-vector pair: real-tap MACs and butterflies map onto v_pk_fma_f32 / v_pk_add_f32 (~1.8x the FLOP rate of
 // the scalar forms on gfx950, tools/ubench/valu_rate.hip)
@@ -268,7 +269,9 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 #endif
 #define CW_F 16                          /* frames per (channel, group) work item */
 
-template <int M, int P>
+// FIX: the front end's dc carry is subtracted from the samples as they are loaded (pmr_carry_fix / pmr_carry_load.hpp): a thread's
+// rows are 16 outputs apart, i.e. M * step / 2^24 ~ 24 decimated samples -- less than a tile (NOV = 1 compare-and-subtract per row).
+template <int M, int P, bool FIX>
 __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) void k_channelize_win(pmr_chan_params q)
 {
     constexpr int L2M = log2c<M>::v;
@@ -285,6 +288,13 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
     const int tid = threadIdx.x;
     const unsigned wg = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
     const long t0 = (long)wg * (NFT - 1);                 // first NEW frame of this tile, relative to q.frame0
+    pmr_carry_lds ct;
+    if constexpr (FIX) {
+        // tables behind the X rows; the lowest sample of the tile is (frame0 + t0 - P) * M
+        ct = pmr_carry_setup<CW_NT>(q.fix, reinterpret_cast<float *>(Xs + NFT * FS),
+                                    ((long long)q.frame0 + t0 - (long long)P) * M - (long long)q.fix.pos0, tid);
+        __syncthreads();
+    }
 
     // ---- pass 1: polyphase bank, X[f][brev(c)] ----
     {
@@ -298,12 +308,16 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
 #pragma unroll
         for (int f = 0; f < CW_F; f++) acc[f] = cfm(0.f, 0.f);
         const unsigned a0 = (unsigned)((unsigned long long)fbase * (unsigned long long)M) + c, xr_mask32 = (unsigned)q.xr_mask;
+        pmr_carry_state cst;
+        const unsigned long long dph = (unsigned long long)M * q.fix.step;
+        if constexpr (FIX) cst = pmr_carry_init(q.fix, ct, fbase * (long long)M + (long long)c - (long long)q.fix.pos0);
         // rows in chunks of CW_RB: the chunk's loads are issued together, then its MACs; the scheduling barrier keeps the
         // compiler from hoisting all 41 row loads (and their NCO factors) to the top, which costs > 128 registers
         constexpr int CW_RB = 8;
 #pragma unroll
         for (int r0 = 0; r0 < CW_F + P - 1; r0 += CW_RB) {
             cf xm[CW_RB];
+            float2 csv[CW_RB];
 #pragma unroll
             for (int u = 0; u < CW_RB; u++) {
                 const int r = r0 + u;
@@ -312,15 +326,17 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
                     // before the stream start wrap into the zero-initialised top of the ring, as in k_channelize
                     const unsigned a = a0 + (unsigned)r * M;
                     const float2 v = reinterpret_cast<const float2 *>(xr)[a & xr_mask32];
-                    const cf x = cfm(v.x, v.y);
-                    const float2 csv = reinterpret_cast<const float2 *>(nco_cs)[a & nco_mask];
-                    xm[u] = cfm(fmaf(x.x, csv.x, x.y * csv.y), fmaf(x.y, csv.x, -(x.x * csv.y)));   // x * conj(e^{j theta})
+                    xm[u] = cfm(v.x, v.y);
+                    csv[u] = reinterpret_cast<const float2 *>(nco_cs)[a & nco_mask];
                 }
             }
 #pragma unroll
             for (int u = 0; u < CW_RB; u++) {
                 const int r = r0 + u;
                 if (r < CW_F + P - 1) {
+                    cf x = xm[u];
+                    if constexpr (FIX) x = pmr_carry_apply<1>(q.fix, ct, cst, x, M, (unsigned)dph, (int)(dph >> 32));
+                    xm[u] = cfm(fmaf(x.x, csv[u].x, x.y * csv[u].y), fmaf(x.y, csv[u].x, -(x.x * csv[u].y)));   // x * conj(e^{j theta})
 #pragma unroll
                     for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < CW_F - 1 ? r : CW_F - 1); f++)
                         acc[f] = cfma(h[r - f], xm[u], acc[f]);
@@ -413,14 +429,20 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
     if (!p->ns) return 0;
     if (p->M != 16) return (int)hipErrorInvalidValue;
     if (win) {
-        const size_t lds_w = (size_t)CW_NT * (16 + 2) * sizeof(cf);
+        const bool fix = p->fix.V != nullptr;
+        const size_t lds_w = (size_t)CW_NT * (16 + 2) * sizeof(cf) + (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
         static pmr_attr_flags attr_w{0};
-        if (lds_w > 64 * 1024 && pmr_attr_needed(attr_w))
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26>),
+        if (lds_w > 64 * 1024 && pmr_attr_needed(attr_w)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((k_channelize_win<16, 26>), dim3(ntiles), dim3(CW_NT), lds_w, (hipStream_t)s, *p);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        if (fix) hipLaunchKernelGGL((k_channelize_win<16, 26, true>), dim3(ntiles), dim3(CW_NT), lds_w, (hipStream_t)s, *p);
+        else hipLaunchKernelGGL((k_channelize_win<16, 26, false>), dim3(ntiles), dim3(CW_NT), lds_w, (hipStream_t)s, *p);
         return (int)hipGetLastError();
     }
+    if (p->fix.V) return (int)hipErrorInvalidValue;            /* the two-frames-per-thread kernel expects corrected samples */
     const size_t lds = (size_t)(CS_NT * CS_FPT + p->p - 1) * (p->M + 2) * sizeof(cf);
     static pmr_attr_flags attr_set{0};
     if (pmr_attr_needed(attr_set)) {

@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "pmr_kernels.h"
+#include "pmr_carry_load.hpp"
 
 typedef float cf __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ cf cfm(float r, float i) { return cf{r, i}; }
@@ -167,7 +168,11 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
 // scratch array, the nine 256-point FFTs run there (same radix-4 passes as k_fft_disc), then the discriminator.  Saves the
 // scratch array's round trip (8 * rate B per input sample written and read: 54 MB per 2^26-sample block at cfg3) and a kernel
 // boundary; the arithmetic is that of k_pfb_wide + k_fft_disc, operation for operation.
+// FIX: the front end's dc carry is subtracted from the samples as they are loaded (pmr_carry_fix / pmr_carry_load.hpp).  A
+// thread's rows are 256 outputs apart = M * step / 2^24 ~ 307 decimated samples at cfg3, more than one front-end tile (217) and
+// less than two: NOV = 2 compare-and-subtract steps per row.
 #define PF_G 8
+template <bool FIX>
 __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params q)
 {
     constexpr int M = 256, NF = PF_G + 1, NROW = NF + PW_P - 1;             // frames per workgroup (first = previous); input rows
@@ -178,6 +183,12 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
     const unsigned wg = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
     const unsigned R0 = wg * PF_G;                                          // row R0 <-> frame frame0 - 1 + R0 (the previous frame)
     if (tid < M / 2) tw[tid] = ((const cf *)q.fft_tw)[tid];
+    pmr_carry_lds ct;
+    if constexpr (FIX) {
+        ct = pmr_carry_setup<256>(q.fix, reinterpret_cast<float *>(tw + M / 2),
+                                  ((long long)q.frame0 - 1 + R0 - (PW_P - 1)) * M - (long long)q.fix.pos0, tid);
+        __syncthreads();
+    }
     // ---- filter bank (k_pfb_wide's arithmetic), thread = channel ----
     {
         const unsigned c = (unsigned)tid;
@@ -193,6 +204,9 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
         const long long fbase = (long long)q.frame0 - 1 + R0 - (PW_P - 1);
         const unsigned a0 = (unsigned)((unsigned long long)fbase * (unsigned long long)M) + c;
         const cf cs_e = nco_cs[a0 & nco_mask], cs_o = nco_cs[(a0 + M) & nco_mask];
+        pmr_carry_state cst;
+        const unsigned long long dph = (unsigned long long)M * q.fix.step;
+        if constexpr (FIX) cst = pmr_carry_init(q.fix, ct, fbase * (long long)M + (long long)c - (long long)q.fix.pos0);
         constexpr int RB = 9;
 #pragma unroll
         for (int rr0 = 0; rr0 < NROW; rr0 += RB) {
@@ -202,15 +216,17 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
                 const int r = rr0 + u;
                 if (r < NROW) {
                     const unsigned a = a0 + (unsigned)r * M;
-                    const cf x = xr[a & xr_mask32];
-                    const cf cs = (r & 1) ? cs_o : cs_e;
-                    xm[u] = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));
+                    xm[u] = xr[a & xr_mask32];
                 }
             }
 #pragma unroll
             for (int u = 0; u < RB; u++) {
                 const int r = rr0 + u;
                 if (r < NROW) {
+                    cf x = xm[u];
+                    if constexpr (FIX) x = pmr_carry_apply<2>(q.fix, ct, cst, x, M, (unsigned)dph, (int)(dph >> 32));
+                    const cf cs = (r & 1) ? cs_o : cs_e;
+                    xm[u] = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));
 #pragma unroll
                     for (int f = (r - PW_P + 1 > 0 ? r - PW_P + 1 : 0); f <= (r < NF - 1 ? r : NF - 1); f++)
                         acc[f] = __builtin_elementwise_fma(cf{h[r - f], h[r - f]}, xm[u], acc[f]);
@@ -304,10 +320,13 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
     if (p->M == 256 && !unfused) {
         const unsigned ntiles = (p->ns + PF_G - 1) / PF_G;
         if (ntiles_out) *ntiles_out = ntiles;
-        const size_t lds = ((size_t)(PF_G + 1) * 256 + 128) * sizeof(cf);
-        hipLaunchKernelGGL(k_channelize_fused256, dim3(ntiles), dim3(256), lds, st, *p);
+        const bool fix = p->fix.V != nullptr;
+        const size_t lds = ((size_t)(PF_G + 1) * 256 + 128) * sizeof(cf) + (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
+        if (fix) hipLaunchKernelGGL(k_channelize_fused256<true>, dim3(ntiles), dim3(256), lds, st, *p);
+        else hipLaunchKernelGGL(k_channelize_fused256<false>, dim3(ntiles), dim3(256), lds, st, *p);
         return (int)hipGetLastError();
     }
+    if (p->fix.V) return (int)hipErrorInvalidValue;            /* the two-kernel form expects corrected samples */
     unsigned log2M = 0;
     while ((1u << log2M) < p->M) log2M++;
     const unsigned groups = (p->ns + 1 + PW_F - 1) / PW_F;
@@ -322,4 +341,21 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
     case 4096: return launch_fft_disc<4096, 2>(st, p, (const cf *)x_scratch, ntiles_out);
     }
     return (int)hipErrorInvalidValue;
+}
+
+/* ---- which channelizers subtract the front end's dc carry at load (pmr_carry_fix) ---- */
+extern "C" int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco_period, int chan_small, int chan_wide, int pair,
+                                            int unfused, unsigned adv_q, unsigned TQ)
+{
+    (void)nco_period;
+    if (chan_small) return M == 16 && p == 26 && !pair && adv_q < TQ;                  /* k_channelize_win<16, 26, true>: NOV = 1 */
+    if (chan_wide) return M == 256 && p == PW_P && !unfused && adv_q < 2 * TQ;         /* k_channelize_fused256<true>: NOV = 2 */
+    return 0;
+}
+
+extern "C" unsigned pmr_channelize_carry_nv(unsigned M, unsigned adv_q, unsigned TQ)
+{
+    /* frames a workgroup stages: M = 16: 256 + 25 rows (k_channelize_win); M = 256: 9 + 25 rows */
+    const unsigned rows = M == 16 ? 256u + 26u : (unsigned)(PF_G + 1 + PW_P);
+    return (rows * adv_q) / TQ + 3u;
 }

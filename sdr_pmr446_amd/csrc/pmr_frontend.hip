@@ -489,8 +489,9 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
         const unsigned ql = (unsigned)((ph >> 24) - qa) + f.HhQ;
         return f.GA[(unsigned)(ph & 0xffffffu) >> 16] * (f.T1[ql >> 5] * f.T2[ql & 31]);
     };
-    unsigned long long js = ja;
-    if (js < jb && ((f.pos0 + js) & 1ull)) {                    // odd ring position: one single sample first
+    unsigned long long js = ja > f.j0 ? ja : f.j0;             // carry applied at load (pmr_carry_fix): only the block's tail is fixed here
+    if (js >= jb) return;
+    if ((f.pos0 + js) & 1ull) {                    // odd ring position: one single sample first
         if (lane == 0) {
             cf *o = xr + ((f.pos0 + js) & f.mask);
             const float gg = f.Kgain * gain(js);

@@ -36,6 +36,8 @@ typedef struct {
     unsigned zc_max_in;     /* PMR_ZEROCOPY_MAX=n: largest block (samples) a synchronous call reads in place from pinned host memory */
     int no_zerocopy;        /* PMR_ZEROCOPY=0: synchronous host calls always go through the copy engines (H2D / D2H) */
     int tf_on_be;           /* PMR_TILEFIX_STREAM: unset = by load (pmr_chain.c tilefix_on_backend), "be" = 1 back-end stream, "fe" = 2 front-end stream */
+    int carry_inplace;      /* PMR_CARRY=inplace: one-level front end's dc carry by the read-modify-write pass over the whole block
+                               (k_fe_tilefix) instead of at the channelizer's loads                                     */
     int fe_marker;          /* PMR_FE_EVENT=marker: "front end done" as a separate event-record packet (default: the last
                                front-end launch's own completion signal) */
 } pmr_switches;
@@ -81,6 +83,24 @@ int pmr_launch_iq_convert(pmr_stream_t s, const void *raw, void *out_cf32, unsig
  * sample index (sample a at xr[a & xr_mask]); the discriminator output in a ring of time-major rows addressed by the
  * absolute frame index (frame t at fm[(t & fm_mask) * M + k]).  Frame f covers samples [f*M, (f+1)*M); the NCO phase
  * of sample a is table entry a mod period.  Negative indices (before the stream start) wrap onto still-zero memory. */
+/* DC carry applied WHERE THE CHANNELIZER LOADS the resampled stream (one-level front ends: cfg2, cfg3).  The front end's tiles run
+ * their dc blocker from zero state; the missing carry adds V_c * K * GA[branch] * mu^q' to the outputs of tile c (pmr_frontend.hip).
+ * Instead of a read-modify-write pass over the whole resampled block (k_fe_tilefix: 2 x 8 x rate bytes per input sample), the
+ * carry pass only computes the V_c and corrects IN PLACE the block's last few outputs [fix_limit, ny) -- the part later calls
+ * re-read as filter history -- and the channelizer subtracts the same term, in the same arithmetic (bit for bit), from every
+ * sample j < fix_limit as it loads it.  V == NULL: nothing to do at load (the ring holds corrected samples). */
+typedef struct {
+    const void *V;              /* [ntiles] cf32 carries of this block's front-end tiles                          */
+    const float *GA, *G12;      /* [256] gain per polyphase branch; [TQ + HhQ + 32] mu^q' (= T1[q' >> 5] * T2[q' & 31], float) */
+    uint64_t pos0;              /* absolute ring index of the block's first output                                */
+    uint32_t phi0, step;        /* resampler phase before the block's first decimated sample, step (2^24 per decimated sample) */
+    uint32_t fix_limit;         /* outputs j < fix_limit are corrected at load                                    */
+    uint32_t ntiles, TQ, HhQ;   /* tiles of the block; decimated samples a tile owns; its halo in decimated samples */
+    uint32_t qbias, nbias;      /* nbias * TQ: added to decimated indices so history before the block stays non-negative */
+    uint32_t nv;                /* carries one workgroup can meet (LDS table length)                              */
+    float Kgain;
+} pmr_carry_fix;
+
 typedef struct {
     const void *xr; uint64_t xr_mask;   /* resampled ring                                                   */
     int64_t frame0;                     /* absolute index of the first NEW frame of this call               */
@@ -93,7 +113,16 @@ typedef struct {
     float *rssi_part;                       /* nullable, [ntiles][M] partial sums of |y|                      */
     const uint8_t *reset_flags;             /* nullable, [M]: non-zero = freqdem_reset (:866) before this call's first frame,
                                                i.e. the channel's first discriminator output is arg(0) = 0   */
+    pmr_carry_fix fix;                      /* dc carry applied at load (fix.V == NULL: off); honoured by the kernels
+                                               pmr_channelize_carry_at_load() names                                       */
 } pmr_chan_params;
+
+/* does the channelizer this (M, p, nco_period, switches) selects apply pmr_carry_fix at load?  `adv_q` = decimated samples one
+ * frame advances (upper bound), TQ as above */
+int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco_period, int chan_small, int chan_wide, int pair, int unfused,
+                                 unsigned adv_q, unsigned TQ);
+/* LDS table length (pmr_carry_fix.nv) for that kernel */
+unsigned pmr_channelize_carry_nv(unsigned M, unsigned adv_q, unsigned TQ);
 
 /* NCO shift + polyphase analysis bank + M-point FFT + discriminator (:808-821, :881), any power-of-two M */
 int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int ft_forced /*0 = automatic*/);
@@ -204,7 +233,7 @@ typedef struct {
 typedef struct {
     void *xr; uint64_t pos0, mask; const void *V;
     const float *GA, *T1, *T2;
-    unsigned ny, TQ, HhQ;       /* ny: outputs of the block; only j in [j0, ny) are corrected */
+    unsigned ny, TQ, HhQ;       /* ny: outputs of the block; only j in [j0, ny) are corrected (k_fe_carry, k_fe_tilefix) */
     unsigned j0;
     uint32_t phi0, step;
     float Kgain;
