@@ -2,7 +2,7 @@
 // pmr_kernels.h; reference stages src/sdr_pmr446.c:795-796 feeding :804-814).
 //
 // Output j of the block belongs to front-end tile c = q / TQ, q = (phi0 + j * step) >> 24 (the decimated sample the resampler
-// stood at), and misses  V_c * Kgain * (GA[branch] * mu^q'),  q' = q - c * TQ + HhQ,  branch = bits 16..23 of the phase: exactly
+// stood at), and misses  V_c * ((Kgain * GA[branch]) * mu^q'),  q' = q - c * TQ + HhQ,  branch = bits 16..23 of the phase: exactly
 // k_fe_tilefix's expression, evaluated in the same order, so a sample corrected here equals the sample corrected in place.
 //
 // A thread walks samples at a constant stride (one per frame row), so everything is INCREMENTAL: the 64-bit phase advances by
@@ -60,9 +60,9 @@ static __device__ __forceinline__ pmr_carry_lds pmr_carry_setup(const pmr_carry_
 }
 
 struct pmr_carry_state {            // per thread
-    unsigned ph_lo; int ph_hi;      // phi0 + j * step of the sample the next call corrects
+    unsigned long long ph;          // phi0 + j * step of the sample the next call corrects (two's complement for j < 0)
     int j;                          // its block-relative index
-    int qb;                         // (biased tile) * TQ - HhQ - qbias: q' = ((ph >> 24) & 0xffffffff) - qb
+    int qb;                         // (biased tile) * TQ - HhQ - qbias: q' = low32(ph >> 24) - qb
     int vi;                         // tile - c_lo
 };
 
@@ -71,39 +71,34 @@ static __device__ __forceinline__ pmr_carry_state pmr_carry_init(const pmr_carry
     pmr_carry_state s;
     int qp;
     const int c = pmr_carry_tile(f, j, &qp);
-    const long long ph = (long long)f.phi0 + j * (long long)f.step;
-    s.ph_lo = (unsigned)ph; s.ph_hi = (int)(ph >> 32);
+    s.ph = (unsigned long long)((long long)f.phi0 + j * (long long)f.step);
     s.j = (int)j;
     s.qb = c * (int)f.TQ - (int)f.HhQ - (int)f.qbias;
     s.vi = c - t.c_lo;
     return s;
 }
 
-// correct sample x (output s.j) and advance the state by one row: dj outputs, (dph_hi, dph_lo) = dj * step
+// correct sample x (output s.j) and advance the state by one row: dj outputs, dph = dj * step.
+// Out-of-range samples (history in front of the block, the tail corrected in place) get a zero gain: x - V * 0 = x.
 template <int NOV>
 static __device__ __forceinline__ pmr_cfv pmr_carry_apply(const pmr_carry_fix &f, const pmr_carry_lds &t, pmr_carry_state &s,
-                                                          pmr_cfv x, int dj, unsigned dph_lo, int dph_hi)
+                                                          pmr_cfv x, int dj, unsigned long long dph)
 {
-    const int q = (int)__builtin_amdgcn_alignbit((unsigned)s.ph_hi, s.ph_lo, 24);      // low 32 bits of ph >> 24
+    const unsigned lo = (unsigned)s.ph;
+    const int q = (int)__builtin_amdgcn_alignbit((unsigned)(s.ph >> 32), lo, 24);       // low 32 bits of ph >> 24
     int ql = q - s.qb;
     const int TQ = (int)f.TQ, TQH = (int)(f.TQ + f.HhQ);
 #pragma unroll
     for (int o = 0; o < NOV; o++) {
-        const bool ov = ql >= TQH;
-        ql = ov ? ql - TQ : ql;
-        s.qb = ov ? s.qb + TQ : s.qb;
-        s.vi += ov ? 1 : 0;
+        const int d = ql >= TQH ? TQ : 0;
+        ql -= d; s.qb += d;
+        s.vi += d ? 1 : 0;
     }
-    const unsigned idx = (s.ph_lo >> 16) & 0xffu;
-    const float gg = f.Kgain * (t.GA[idx] * t.G12[ql]);
+    float gg = t.GA[(lo >> 16) & 0xffu] * t.G12[ql];
+    gg = (unsigned)s.j < f.fix_limit ? gg : 0.f;
     const pmr_cfv V = t.V[s.vi];
-    const bool in = (unsigned)s.j < f.fix_limit;
-    const float yr = fmaf(-V.x, gg, x.x), yi = fmaf(-V.y, gg, x.y);
-    x = pmr_cfv{in ? yr : x.x, in ? yi : x.y};
-    // advance
-    const unsigned nlo = s.ph_lo + dph_lo;
-    s.ph_hi += dph_hi + (nlo < s.ph_lo ? 1 : 0);
-    s.ph_lo = nlo;
+    x = pmr_cfv{fmaf(-V.x, gg, x.x), fmaf(-V.y, gg, x.y)};
+    s.ph += dph;
     s.j += dj;
     return x;
 }

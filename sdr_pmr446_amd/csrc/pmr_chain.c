@@ -127,7 +127,7 @@ struct pmr_chain_s {
     uint64_t *d_fe_tile_j; float *d_fe_rho_pow; unsigned fe_K;   /* k_fe_tilefix inputs */
     /* dc carry applied where the channelizer loads the resampled stream (pmr_carry_fix): supported by this plan's kernels;
      * used by THIS call; table mu^q' as one float product; LDS table length; decimated samples per frame; index bias (tiles) */
-    int cal_ok, cal_now; float *d_fe_G12; unsigned cal_nv, cal_adv_q, cal_nbias;
+    int cal_ok, cal_now; float *d_fe_G12, *d_fe_GAK; unsigned cal_nv, cal_adv_q, cal_nbias;
     unsigned cal_fix_limit, cal_ntiles, cal_slot; uint32_t cal_phi0;   /* ... of this call's block (frontend_fused) */
     int tf_on_backend, pend_tf; unsigned pend_tf_Q;    /* one-level form: k_fe_tilefix deferred to the back-end stream (uses pend_t2 / pend_f2) */
     int tf_last_be;                  /* the previous pipelined call's carry pass ran on the back-end stream */
@@ -435,6 +435,13 @@ static int fe_init(pmr_chain q)
             ga[idx] = (float)acc;
         }
         if ((rc = dev_upload(q, &q->d_fe_GA, ga, PMR_ARB_NPFB))) return rc;
+        {
+            /* one-level form: the carry's gain per polyphase branch with the cascade's gain folded in, Kgain * GA[idx] as ONE float
+             * product: what k_fe_tilefix, k_fe_carry_tail and the channelizers' loads all multiply by mu^q' */
+            float gak[PMR_ARB_NPFB];
+            for (unsigned idx = 0; idx < PMR_ARB_NPFB; idx++) gak[idx] = q->fe_Kgain * ga[idx];
+            if ((rc = dev_upload(q, &q->d_fe_GAK, gak, PMR_ARB_NPFB))) return rc;
+        }
         const unsigned nq = (unsigned)(N0 / (q->fe_two ? D1 : D)), n1 = nq / 32 + 2;
         float *t1 = (float *)calloc(n1, sizeof(float)), t2[32];
         if (!t1) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
@@ -648,6 +655,7 @@ static void read_switches(pmr_switches *w)
     w->fir_mode = env_is("PMR_FIR", "pair") ? PMR_FIR_PAIR : env_is("PMR_FIR", "lds") ? PMR_FIR_LDS
                 : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
     w->fir_mfma_global = env_is("PMR_FIR_MFMA", "global");
+    w->fir_mfma32 = env_is("PMR_FIR_MFMA", "32");
     { const char *e = getenv("PMR_FIR_TPW"); w->fir_tpw = e ? atoi(e) : 2; }
     w->fir_nodual = env_is("PMR_FIR_DUAL", "0");
     w->no_overlap = env_is("PMR_OVERLAP", "0");
@@ -743,7 +751,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_dbg_ct, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_G12, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_G12, q->d_fe_GAK, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events,
                      q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1 };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
@@ -987,7 +995,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
 
     pmr_fe_fix_params f;
     memset(&f, 0, sizeof(f));
-    f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[slot]; f.GA = q->d_fe_GA; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
+    f.xr = q->d_xr; f.pos0 = q->xr_abs; f.mask = q->xr_mask; f.V = q->d_fe_V[slot]; f.GA = q->d_fe_GAK; f.T1 = q->d_fe_T1; f.T2 = q->d_fe_T2;
     f.ny = ny; f.TQ = (unsigned)q->fe_TQ; f.HhQ = (unsigned)q->fe_HhQ; f.phi0 = q->arb_phase; f.step = d->arb_step;
     f.Kgain = q->fe_Kgain;
     if (q->cal_now) {
@@ -1004,7 +1012,8 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     } else {
         pmr_launch_events ev; prof_pending pe;
         fe_launch_events(q, K_FE_TILEFIX, t.ntiles != 0, &ev, &pe);
-        LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, &ev));
+        if (q->cal_now) LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_carry_tail(q->sfe, &t, &f, &ev));
+        else LAUNCH_FE(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->sfe, &t, &f, Q, &ev));
     }
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
@@ -1494,7 +1503,8 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     if (!single) HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
     if (q->pend_tf) {
         q->pend_tf = 0;
-        LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t2, &q->pend_f2, q->pend_tf_Q, NULL));
+        if (q->cal_now) LAUNCH(K_FE_TILEFIX, pmr_launch_fe_carry_tail(q->stream, &q->pend_t2, &q->pend_f2, NULL));
+        else LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t2, &q->pend_f2, q->pend_tf_Q, NULL));
     }
     if (q->pend_l2) {
         q->pend_l2 = 0;
@@ -1525,11 +1535,10 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
         c.fm_ref = d->fm_ref; c.chan_out = d_chan_out; c.chan_stride = pcm_stride;
         c.rssi_part = d_rssi_db ? q->d_rssi_part : NULL;
         if (q->cal_now && q->cal_fix_limit) {
-            c.fix.V = q->d_fe_V[q->cal_slot]; c.fix.GA = q->d_fe_GA; c.fix.G12 = q->d_fe_G12;
+            c.fix.V = q->d_fe_V[q->cal_slot]; c.fix.GA = q->d_fe_GAK; c.fix.G12 = q->d_fe_G12;
             c.fix.pos0 = xr_abs0; c.fix.phi0 = q->cal_phi0; c.fix.step = d->arb_step; c.fix.fix_limit = q->cal_fix_limit;
             c.fix.ntiles = q->cal_ntiles; c.fix.TQ = (unsigned)q->fe_TQ; c.fix.HhQ = (unsigned)q->fe_HhQ;
             c.fix.nbias = q->cal_nbias; c.fix.qbias = q->cal_nbias * (unsigned)q->fe_TQ; c.fix.nv = q->cal_nv;
-            c.fix.Kgain = q->fe_Kgain;
         }
         if (q->reset_pending) {                       /* freqdem_reset (:866) of the flagged channels: takes effect on this call's first frame */
             HIPCHK(hipMemcpyAsync(q->d_reset_flags, q->h_reset_flags, M, hipMemcpyHostToDevice, q->stream), "reset flags");

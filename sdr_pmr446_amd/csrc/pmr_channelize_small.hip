@@ -308,6 +308,8 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
 #pragma unroll
         for (int f = 0; f < CW_F; f++) acc[f] = cfm(0.f, 0.f);
         const unsigned a0 = (unsigned)((unsigned long long)fbase * (unsigned long long)M) + c, xr_mask32 = (unsigned)q.xr_mask;
+        // the NCO table's period divides 2 M (launcher), so a thread meets two factors: one on even rows of its window, one on odd rows
+        const cf cs_e = nco_cs[a0 & nco_mask], cs_o = nco_cs[(a0 + M) & nco_mask];
         pmr_carry_state cst;
         const unsigned long long dph = (unsigned long long)M * q.fix.step;
         if constexpr (FIX) cst = pmr_carry_init(q.fix, ct, fbase * (long long)M + (long long)c - (long long)q.fix.pos0);
@@ -317,7 +319,6 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
 #pragma unroll
         for (int r0 = 0; r0 < CW_F + P - 1; r0 += CW_RB) {
             cf xm[CW_RB];
-            float2 csv[CW_RB];
 #pragma unroll
             for (int u = 0; u < CW_RB; u++) {
                 const int r = r0 + u;
@@ -327,16 +328,17 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
                     const unsigned a = a0 + (unsigned)r * M;
                     const float2 v = reinterpret_cast<const float2 *>(xr)[a & xr_mask32];
                     xm[u] = cfm(v.x, v.y);
-                    csv[u] = reinterpret_cast<const float2 *>(nco_cs)[a & nco_mask];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);            // the chunk's loads stay together, ahead of everything that consumes them
 #pragma unroll
             for (int u = 0; u < CW_RB; u++) {
                 const int r = r0 + u;
                 if (r < CW_F + P - 1) {
                     cf x = xm[u];
-                    if constexpr (FIX) x = pmr_carry_apply<1>(q.fix, ct, cst, x, M, (unsigned)dph, (int)(dph >> 32));
-                    xm[u] = cfm(fmaf(x.x, csv[u].x, x.y * csv[u].y), fmaf(x.y, csv[u].x, -(x.x * csv[u].y)));   // x * conj(e^{j theta})
+                    if constexpr (FIX) x = pmr_carry_apply<1>(q.fix, ct, cst, x, M, dph);
+                    const cf cs = (r & 1) ? cs_o : cs_e;
+                    xm[u] = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));   // x * conj(e^{j theta})
 #pragma unroll
                     for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < CW_F - 1 ? r : CW_F - 1); f++)
                         acc[f] = cfma(h[r - f], xm[u], acc[f]);
@@ -423,7 +425,8 @@ extern "C" int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned n
 
 extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int pair)
 {
-    const bool win = !pair && p->p == 26;                       /* pair = two frames per thread (PMR_CHANNELIZER_SMALL=pair) */
+    /* pair = two frames per thread (PMR_CHANNELIZER_SMALL=pair); the sliding-window kernel keeps two NCO factors per thread */
+    const bool win = !pair && p->p == 26 && (2u * p->M) % p->nco_period == 0;
     const unsigned ntiles = win ? (p->ns + CW_NT - 2) / (CW_NT - 1) : pmr_channelize_small_tiles(p->ns);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;

@@ -219,12 +219,13 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
                     xm[u] = xr[a & xr_mask32];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);            // the batch's loads stay together, ahead of everything that consumes them
 #pragma unroll
             for (int u = 0; u < RB; u++) {
                 const int r = rr0 + u;
                 if (r < NROW) {
                     cf x = xm[u];
-                    if constexpr (FIX) x = pmr_carry_apply<2>(q.fix, ct, cst, x, M, (unsigned)dph, (int)(dph >> 32));
+                    if constexpr (FIX) x = pmr_carry_apply<2>(q.fix, ct, cst, x, M, dph);
                     const cf cs = (r & 1) ? cs_o : cs_e;
                     xm[u] = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));
 #pragma unroll
@@ -347,8 +348,7 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
 extern "C" int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco_period, int chan_small, int chan_wide, int pair,
                                             int unfused, unsigned adv_q, unsigned TQ)
 {
-    (void)nco_period;
-    if (chan_small) return M == 16 && p == 26 && !pair && adv_q < TQ;                  /* k_channelize_win<16, 26, true>: NOV = 1 */
+    if (chan_small) return M == 16 && p == 26 && !pair && nco_period && 32u % nco_period == 0 && adv_q < TQ;   /* k_channelize_win<16, 26, true>: NOV = 1 */
     if (chan_wide) return M == 256 && p == PW_P && !unfused && adv_q < 2 * TQ;         /* k_channelize_fused256<true>: NOV = 2 */
     return 0;
 }

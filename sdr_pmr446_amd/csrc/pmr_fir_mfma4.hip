@@ -1,0 +1,276 @@
+// pmr_fir_mfma4.hip -- the audio FIR (reference src/sdr_pmr446.c:882-904: 377-tap CTCSS high-pass, gain, 50 us de-emphasis, PCM
+// hand-off; the complementary CTCSS low-pass branch :884-889; the optional FIR de-emphasis / low-pass passes :896,:901) on the
+// gfx950 matrix pipe with v_mfma_f32_16x16x4_f32, 16 channels x 128 frames per workgroup.
+//
+// Same formulation as pmr_fir_mfma.hip (banded Toeplitz x data, taps with gain and the truncated de-emphasis response folded in,
+// exact k-ordered f32 accumulation oldest sample first = liquid's order) -- the results are bit-identical to that kernel's.
+// What differs is the GRAIN.  With 32x32x2 tiles a wave's unit of work is 64 frames x 16 channels = 13.3k matrix-pipe cycles,
+// a cfg2 block has 5462 of them for 1024 SIMDs (5.3 each: some SIMDs run 6, the launch lasts as long as those), and a workgroup
+// needs 45 KB of LDS (three per CU).  Here:
+//   * D = A B with the 16x16x4 shape: A[i][kappa] = g[i + (n-1) - kappa] (lane l: row l & 15, kappa = 4 s + (l >> 4)),
+//     B[kappa][j] = X[T - (n-1) + kappa][channel j] (lane l: 64 CONSECUTIVE floats of the time-major window per step: no bank
+//     conflicts, no padding).  The band needs n - 1 + 16 kappa per 16 frames: 398 -> 100 steps (the 32-row tiles need 414 -> 416);
+//   * a wave owns 32 frames: two accumulators (16 frames each) that share every A operand and alternate on the pipe (32-cycle
+//     issue, 40-cycle dependent latency);
+//   * a workgroup = 4 waves = 128 frames: 33 KB of LDS, four per CU, 2731 workgroups per cfg2 block: the dispatcher evens the
+//     load out (10.7 wave-units of 6.4k cycles per SIMD), and one workgroup's window staging hides under three others' MFMAs;
+//   * the epilogue goes through LDS so that PCM / audio leave as whole 16-byte pieces of a channel row (256 B per channel).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmr_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define F4_NT 256
+#define F4_TILE 128                              /* frames per workgroup: 4 waves x 2 accumulators x 16 */
+#define F4_GS 8                                  /* k-steps per software-pipeline group */
+#define F4_LDY (F4_TILE + 4)                     /* epilogue staging: floats per channel row */
+
+static __device__ __forceinline__ int16_t pcm16_4(float y)
+{
+    const float s = y * 32767.0f;
+    if (!(s == s)) return 0;
+    if (s >= 32767.0f) return 32767;
+    if (s <= -32768.0f) return -32768;
+    return (int16_t)s;                            // truncation toward zero (src/dsd_in.c:174), saturated
+}
+
+// GATHER (open-channel mask, reference :876-877): the 16 columns of a tile are 16 arbitrary (channel, 128-frame segment) units.
+// DUAL: a second tap set over the same samples -> time-major out2_tm (the CTCSS low-pass branch, :884-889), same pass.
+// TMOUT: the product itself also goes out time-major (intermediate of the FIR de-emphasis / low-pass chains).
+template <bool GATHER, bool DUAL, bool TMOUT>
+__global__ __launch_bounds__(F4_NT, 4) void k_fir_mfma4(const float *__restrict__ in, unsigned long long row_mask, long long row0,
+                                                      unsigned ns, const float *__restrict__ taps_c, unsigned ntaps,
+                                                      float *__restrict__ out_tm, int16_t *__restrict__ pcm,
+                                                      float *__restrict__ audio, unsigned stride, unsigned M,
+                                                      const unsigned *__restrict__ chan_list, unsigned n_units, unsigned nseg,
+                                                      const float *__restrict__ taps2_c, float *__restrict__ out2_tm)
+{
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (!GATHER) {
+        const unsigned L = pmr_xcd_contiguous(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        bx = L % gridDim.x; by = L / gridDim.x;
+    }
+    __shared__ unsigned s_ch[16];                                    // channel of column slot s
+    __shared__ long s_t0[16];                                        // first frame of slot s
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (GATHER) {
+        if (tid < 16) {
+            const unsigned u = blockIdx.x * 16u + tid;
+            s_ch[tid] = chan_list[u < n_units ? u / nseg : 0];
+            s_t0[tid] = u < n_units ? (long)(u % nseg) * F4_TILE : (long)ns;          // beyond the block: nothing stored
+        }
+    } else {
+        const unsigned cg0 = by * 16u;                               // a group of 16 adjacent channels per workgroup row
+        in += cg0;
+        if (out_tm) out_tm += cg0;
+        if (DUAL) out2_tm += cg0;
+        if (pcm) pcm += (size_t)cg0 * stride;
+        if (audio) audio += (size_t)cg0 * stride;
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem_4[];
+    const unsigned qlen = ntaps + 2 * PMR_TAP_PAD, qpad = (qlen + 31) & ~31u;
+    float *Qs = reinterpret_cast<float *>(smem_4);                   // padded taps
+    float *Q2 = Qs + qpad;                                           // DUAL: second padded tap table
+    float *Xs = Q2 + (DUAL ? qpad : 0u);                             // window: row r at 16 r (r <-> frame T0 - (ntaps-1) + r)
+    const unsigned nsteps = (ntaps - 1 + 16 + 3) / 4, ngroups = (nsteps + F4_GS - 1) / F4_GS;
+    const unsigned nrows = (F4_TILE - 16) + 4 * F4_GS * ngroups;
+    const long T0 = GATHER ? 0 : (long)bx * F4_TILE;                 // first frame of the tile (relative to row0)
+
+    for (unsigned i = tid; i < qlen; i += F4_NT) Qs[i] = taps_c[i];
+    if constexpr (DUAL) for (unsigned i = tid; i < qlen; i += F4_NT) Q2[i] = taps2_c[i];
+
+    // ---- window: HBM ring -> LDS.  All loads of a thread are issued before the first is stored ----
+    if constexpr (GATHER) {
+        __syncthreads();                                             // slot tables
+        for (unsigned e0 = tid; e0 < nrows * 16; e0 += F4_NT * 11) {
+            float v[11];
+#pragma unroll
+            for (int i = 0; i < 11; i++) {
+                const unsigned e = e0 + F4_NT * i, r = e >> 4, sl = e & 15;
+                const long t = s_t0[sl] - (long)(ntaps - 1) + r;
+                v[i] = 0.f;
+                if (e < nrows * 16 && t < (long)ns) v[i] = in[((unsigned long long)(row0 + t) & row_mask) * M + s_ch[sl]];
+            }
+#pragma unroll
+            for (int i = 0; i < 11; i++) {
+                const unsigned e = e0 + F4_NT * i;
+                if (e < nrows * 16) Xs[e] = v[i];
+            }
+        }
+    } else {
+        for (unsigned u0 = tid; u0 < nrows * 4; u0 += F4_NT * 9) {
+            float4 v[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const unsigned u = u0 + F4_NT * i, r = u >> 2, q4 = (u & 3) * 4;
+                const long t = T0 - (long)(ntaps - 1) + r;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u < nrows * 4 && t < (long)ns)
+                    v[i] = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + q4);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const unsigned u = u0 + F4_NT * i;
+                if (u < nrows * 4) reinterpret_cast<float4 *>(Xs)[u] = v[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- banded Toeplitz x window.  step s of accumulator a: A = Q[PAD + (ntaps-1) + (lane & 15) - (lane >> 4) - 4 s],
+    //      B = Xs[(32 wave + 16 a + 4 s) * 16 + lane].  Two register sets: group g+1's operands are in flight from LDS while
+    //      group g's MFMAs issue ----
+    const bool active = GATHER || T0 + 32 * wave < (long)ns;         // else: the whole wave lies beyond the block
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acd0 = acc0, acd1 = acc0;
+    if (active) {
+        const float *qa = Qs + PMR_TAP_PAD + (ntaps - 1) + (lane & 15) - (lane >> 4) - 4 * (F4_GS - 1);   // group 0: step u at qa[4 (GS-1-u)]
+        const float *q2 = Q2 + (qa - Qs);
+        const float *xb = Xs + (32 * wave) * 16 + lane;                                                    // group 0: step u at xb[64 u] (+256: acc 1)
+        float a0[F4_GS], b00[F4_GS], b01[F4_GS], a1[F4_GS], b10[F4_GS], b11[F4_GS];
+        float c0[DUAL ? F4_GS : 1], c1[DUAL ? F4_GS : 1];
+#define F4_LOAD(A, B0, B1, C, G) do { const unsigned gi_ = (G) < ngroups ? (G) : ngroups - 1;    /* clamped: never past the tables */ \
+        const float *q_ = qa - 4 * F4_GS * (int)gi_, *x_ = xb + 64 * F4_GS * (int)gi_;                                                 \
+        _Pragma("unroll") for (int u = 0; u < F4_GS; u++) {                                                                             \
+            A[u] = q_[4 * (F4_GS - 1 - u)]; B0[u] = x_[64 * u]; B1[u] = x_[256 + 64 * u];                                               \
+            if constexpr (DUAL) C[u] = (q2 - 4 * F4_GS * (int)gi_)[4 * (F4_GS - 1 - u)]; }                                              \
+        __builtin_amdgcn_sched_barrier(0); } while (0)   /* keep the loads ahead of the MFMA block that hides them */
+#define F4_MMA(A, B0, B1, C) do { _Pragma("unroll") for (int u = 0; u < F4_GS; u++) {                                                  \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B0[u], acc0, 0, 0, 0);                                                    \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B1[u], acc1, 0, 0, 0);                                                    \
+            if constexpr (DUAL) {                                                                                                       \
+                acd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(C[u], B0[u], acd0, 0, 0, 0);                                                \
+                acd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(C[u], B1[u], acd1, 0, 0, 0); } }                                            \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+        F4_LOAD(a0, b00, b01, c0, 0u);
+        unsigned g = 0;
+        for (; g + 2 <= ngroups; g += 2) {
+            F4_LOAD(a1, b10, b11, c1, g + 1);
+            F4_MMA(a0, b00, b01, c0);
+            F4_LOAD(a0, b00, b01, c0, g + 2);
+            F4_MMA(a1, b10, b11, c1);
+        }
+        if (ngroups & 1) F4_MMA(a0, b00, b01, c0);                   // set 0 holds group ngroups-1 here
+#undef F4_LOAD
+#undef F4_MMA
+    }
+
+    // D layout: lane holds column (lane & 15) = channel slot; register q = row 4 (lane >> 4) + q = frame
+    const int sl = lane & 15, fr = 32 * wave + 4 * (lane >> 4);      // + 16 a + q
+    if (active) {
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const f32x4 d = a ? acd1 : acd0;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const long t = (GATHER ? s_t0[sl] : T0) + fr + 16 * a + qq;
+                    const unsigned chs = GATHER ? s_ch[sl] : (unsigned)sl;
+                    if (t < (long)ns) out2_tm[((unsigned long long)(row0 + t) & row_mask) * M + chs] = d[qq];
+                }
+            }
+        }
+        if constexpr (TMOUT) {
+#pragma unroll
+            for (int a = 0; a < 2; a++) {
+                const f32x4 d = a ? acc1 : acc0;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const long t = (GATHER ? s_t0[sl] : T0) + fr + 16 * a + qq;
+                    const unsigned chs = GATHER ? s_ch[sl] : (unsigned)sl;
+                    if (t < (long)ns) out_tm[((unsigned long long)(row0 + t) & row_mask) * M + chs] = d[qq];
+                }
+            }
+        }
+    }
+    if (!pcm && !audio) return;                                      // uniform
+
+    // ---- channel-major outputs through LDS: Ys[slot][frame], then 8 consecutive frames of one channel per thread ----
+    __syncthreads();                                                 // every wave is done with the window
+    float *Ys = Xs;                                                  // 16 x F4_LDY floats (8.4 KB) over the window
+    if (active) {
+        *reinterpret_cast<f32x4 *>(Ys + sl * F4_LDY + fr) = acc0;
+        *reinterpret_cast<f32x4 *>(Ys + sl * F4_LDY + fr + 16) = acc1;
+    }
+    __syncthreads();
+    {
+        const int os = tid >> 4, f0 = 8 * (tid & 15);                // slot, first frame inside the tile
+        const long tb = (GATHER ? s_t0[os] : T0) + f0;
+        const unsigned chs = GATHER ? s_ch[os] : (unsigned)os;
+        if (tb < (long)ns) {
+            const f32x4 y0 = *reinterpret_cast<const f32x4 *>(Ys + os * F4_LDY + f0);
+            const f32x4 y1 = *reinterpret_cast<const f32x4 *>(Ys + os * F4_LDY + f0 + 4);
+            const float yy[8] = {y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+            const bool full = tb + 8 <= (long)ns;
+            if (pcm) {
+                int16_t *o = pcm + (size_t)chs * stride + tb;
+                if (full && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+                    uint4 w;
+                    w.x = (unsigned)(uint16_t)pcm16_4(yy[0]) | ((unsigned)(uint16_t)pcm16_4(yy[1]) << 16);
+                    w.y = (unsigned)(uint16_t)pcm16_4(yy[2]) | ((unsigned)(uint16_t)pcm16_4(yy[3]) << 16);
+                    w.z = (unsigned)(uint16_t)pcm16_4(yy[4]) | ((unsigned)(uint16_t)pcm16_4(yy[5]) << 16);
+                    w.w = (unsigned)(uint16_t)pcm16_4(yy[6]) | ((unsigned)(uint16_t)pcm16_4(yy[7]) << 16);
+                    *reinterpret_cast<uint4 *>(o) = w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) if (tb + i < (long)ns) o[i] = pcm16_4(yy[i]);
+                }
+            }
+            if (audio) {
+                float *o = audio + (size_t)chs * stride + tb;
+                if (full && (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+                    *reinterpret_cast<f32x4 *>(o) = y0;
+                    *reinterpret_cast<f32x4 *>(o + 4) = y1;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) if (tb + i < (long)ns) o[i] = yy[i];
+                }
+            }
+        }
+    }
+}
+
+extern "C" int pmr_fir_mfma4_supported(unsigned M, unsigned ntaps)
+{
+    /* the window (112 + 32 ceil((ntaps + 18) / 32) rows of 64 B) + the tap table(s) must fit four workgroups' LDS budget */
+    return M >= 16 && M % 16 == 0 && M <= 16 * 65535u && ntaps >= 2 && ntaps <= 480;
+}
+
+extern "C" int pmr_launch_fir_mfma4(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+                                    const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
+                                    const unsigned *chan_list, unsigned n_chan, const float *taps2_pad, float *out2_tm)
+{
+    if (!ns) return 0;
+    if (!pmr_fir_mfma4_supported(M, ntaps)) return (int)hipErrorInvalidValue;
+    const int dual = taps2_pad && out2_tm;
+    if ((taps2_pad || out2_tm) && !dual) return (int)hipErrorInvalidValue;
+    const unsigned qlen = ntaps + 2 * PMR_TAP_PAD, qpad = (qlen + 31) & ~31u;
+    const unsigned nsteps = (ntaps - 1 + 16 + 3) / 4, ngroups = (nsteps + F4_GS - 1) / F4_GS;
+    const unsigned nrows = (F4_TILE - 16) + 4 * F4_GS * ngroups;
+    size_t win = (size_t)nrows * 16;
+    if (win < 16 * F4_LDY) win = 16 * F4_LDY;                       /* the epilogue's staging lives in the window's space */
+    const size_t lds = ((dual ? 2 : 1) * (size_t)qpad + win) * sizeof(float);
+    hipStream_t st = (hipStream_t)s;
+    const unsigned long long rm = (unsigned long long)row_mask;
+    const long long r0 = (long long)row0;
+    const unsigned tiles = (ns + F4_TILE - 1) / F4_TILE;
+    dim3 grid(tiles, M / 16);
+    unsigned n_units = 0;
+    if (chan_list) {
+        if (!n_chan) return 0;
+        n_units = n_chan * tiles;
+        grid = dim3((n_units + 15) / 16);
+    }
+#define F4_GO(G_, D_, T_) hipLaunchKernelGGL((k_fir_mfma4<G_, D_, T_>), grid, dim3(F4_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps, out_tm, \
+                                             pcm, audio, stride, M, chan_list, n_units, tiles, taps2_pad, out2_tm)
+    if (chan_list) {
+        if (dual) { if (out_tm) F4_GO(true, true, true); else F4_GO(true, true, false); }
+        else      { if (out_tm) F4_GO(true, false, true); else F4_GO(true, false, false); }
+    } else {
+        if (dual) { if (out_tm) F4_GO(false, true, true); else F4_GO(false, true, false); }
+        else      { if (out_tm) F4_GO(false, false, true); else F4_GO(false, false, false); }
+    }
+#undef F4_GO
+    return (int)hipGetLastError();
+}

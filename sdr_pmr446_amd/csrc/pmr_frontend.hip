@@ -437,6 +437,34 @@ __global__ __launch_bounds__(256) void k_fe_carry(pmr_fe_tiles_params t, pmr_fe_
     *o = v;
 }
 
+// One-level front end, carry applied where the channelizer loads the resampled stream (pmr_carry_fix): this launch computes the
+// tile carries V_c (one thread each) + the dc state for the next call, and corrects IN PLACE only the block's last outputs
+// [j0, ny) -- what later calls re-read as filter history -- one thread per output, in k_fe_tilefix's arithmetic.
+__global__ __launch_bounds__(256) void k_fe_carry_tail(pmr_fe_tiles_params t, pmr_fe_fix_params f, unsigned nb_tiles)
+{
+    if (blockIdx.x < nb_tiles) {
+        const unsigned c = blockIdx.x * 256u + threadIdx.x;
+        if (c >= t.ntiles) return;
+        const cf V = fe_carry_V(t, c);
+        ((cf *)t.V)[c] = V;
+        if (c == t.c_end) {
+            const cf pe = *(const cf *)t.probeE;
+            *(cf *)t.v_out = cfm(fmaf(t.lamEnd, V.x, pe.x), fmaf(t.lamEnd, V.y, pe.y));
+        }
+        return;
+    }
+    const unsigned j = f.j0 + (blockIdx.x - nb_tiles) * 256u + threadIdx.x;
+    if (j >= f.ny) return;
+    const unsigned long long ph = (unsigned long long)f.phi0 + (unsigned long long)j * f.step;
+    const unsigned qd = (unsigned)(ph >> 24), c = qd / f.TQ, ql = qd - c * f.TQ + f.HhQ;
+    const float gg = f.GA[(unsigned)(ph & 0xffffffu) >> 16] * (f.T1[ql >> 5] * f.T2[ql & 31]);    // GA carries the cascade gain
+    const cf V = fe_carry_V(t, c);
+    cf *o = (cf *)f.xr + ((f.pos0 + j) & f.mask);
+    cf w = *o;
+    w.x = fmaf(-V.x, gg, w.x); w.y = fmaf(-V.y, gg, w.y);
+    *o = w;
+}
+
 // ---------------------------------------------------------------------------------------------
 // One-level front end: carries + correction of the resampled stream in one launch, one WAVE per front-end tile.  The lanes sum
 // the K predecessor terms of the tile's carry (wave reduction), then the same wave corrects the ~T_own * rate resampler outputs
@@ -448,27 +476,10 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
     const unsigned lane = threadIdx.x & 63u;
     const unsigned c = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (c >= t.ntiles) return;
-    const cf *pa = (const cf *)t.probeA, *pb = (const cf *)t.probeB;
-    // ---- V_c: the K-term sum spread over the lanes (record of tile 0 = P_0 + rho W_0, lane k-1 holds term k, xor-butterfly
-    // reduction) ----
-    const unsigned kmax = c < t.K ? c : t.K;
-    float ar = 0.f, ai = 0.f;
-    float V0r = 0.f, V0i = 0.f;
-    if (c <= t.K) {
-        const cf vs = *(const cf *)t.v_in, pl = *(const cf *)t.probeL;
-        V0r = (vs.x - pl.x) * t.inv_lamL; V0i = (vs.y - pl.y) * t.inv_lamL;
-    }
-    for (unsigned k = 1 + lane; k <= kmax; k += 64u) {
-        const cf A = pa[c - k], B = pb[c - k];
-        float Pr = fmaf(-t.rho, A.x, B.x), Pi = fmaf(-t.rho, A.y, B.y);
-        if (k == c) { Pr = fmaf(t.rho, fmaf(t.lamHh, V0r, A.x), Pr); Pi = fmaf(t.rho, fmaf(t.lamHh, V0i, A.y), Pi); }
-        const float pw = t.rho_pow[k - 1];                           // rho^(k-1), tabulated in double on the host
-        ar += pw * Pr; ai += pw * Pi;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { ar += __shfl_xor(ar, d); ai += __shfl_xor(ai, d); }
-    const cf Ac = pa[c];
-    const float Vr = c == 0 ? V0r : (ar - Ac.x) * t.inv_lamHh, Vi = c == 0 ? V0i : (ai - Ac.y) * t.inv_lamHh;
+    // ---- V_c: fe_carry_V's arithmetic (every lane evaluates the same sum), so that this pass and k_fe_carry_tail -- the form
+    // that leaves most of the block to the channelizer's loads -- correct a sample with the same carry, bit for bit ----
+    const cf Vc = fe_carry_V(t, c);
+    const float Vr = Vc.x, Vi = Vc.y;
     if (lane == 0) {
         ((cf *)t.V)[c] = cfm(Vr, Vi);
         if (c == t.c_end) {
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
     if ((f.pos0 + js) & 1ull) {                    // odd ring position: one single sample first
         if (lane == 0) {
             cf *o = xr + ((f.pos0 + js) & f.mask);
-            const float gg = f.Kgain * gain(js);
+            const float gg = gain(js);
             cf w = *o;
             w.x = fmaf(-Vr, gg, w.x); w.y = fmaf(-Vi, gg, w.y);
             *o = w;
@@ -515,7 +526,7 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
 #pragma unroll
         for (int u = 0; u < 3; u++) {
             if (pb2 + 64u * u < npair) {
-                const float ga = f.Kgain * g0[u], gb = f.Kgain * g1[u];
+                const float ga = g0[u], gb = g1[u];
                 float4 w = v[u];
                 w.x = fmaf(-Vr, ga, w.x); w.y = fmaf(-Vi, ga, w.y);
                 w.z = fmaf(-Vr, gb, w.z); w.w = fmaf(-Vi, gb, w.w);
@@ -526,7 +537,7 @@ __global__ __launch_bounds__(256) void k_fe_tilefix(pmr_fe_tiles_params t, pmr_f
     if (((jb - js) & 1ull) && lane == 0) {                      // odd count: the last sample alone
         const unsigned long long j = jb - 1;
         cf *o = xr + ((f.pos0 + j) & f.mask);
-        const float gg = f.Kgain * gain(j);
+        const float gg = gain(j);
         cf w = *o;
         w.x = fmaf(-Vr, gg, w.x); w.y = fmaf(-Vi, gg, w.y);
         *o = w;
@@ -583,6 +594,15 @@ extern "C" int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t,
     if (!t->ntiles) return 0;
     const unsigned nb_tiles = (t->ntiles + 255) / 256, nb_fix = f->ny > f->j0 ? (f->ny - f->j0 + 255) / 256 : 0;
     hipLaunchKernelGGL(k_fe_carry, dim3(nb_tiles + nb_fix), dim3(256), 0, (hipStream_t)s, *t, *f, nb_tiles);
+    return (int)hipGetLastError();
+}
+
+extern "C" int pmr_launch_fe_carry_tail(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f,
+                                        const pmr_launch_events *ev)
+{
+    if (!t->ntiles) return 0;
+    const unsigned nb_tiles = (t->ntiles + 255) / 256, nb_fix = f->ny > f->j0 ? (f->ny - f->j0 + 255) / 256 : 0;
+    PMR_LAUNCH_EV(k_fe_carry_tail, dim3(nb_tiles + nb_fix), dim3(256), 0, (hipStream_t)s, ev, *t, *f, nb_tiles);
     return (int)hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ typedef struct {
     int chan_ft;            /* PMR_CHAN_FT=n: tile height of the generic channelizer (0 = automatic)        */
     int fir_mode;           /* PMR_FIR=pair|lds|global: VALU versions of the audio FIR (PMR_FIR_*)          */
     int fir_mfma_global;    /* PMR_FIR_MFMA=global: MFMA FIR without the LDS sample window                  */
+    int fir_mfma32;         /* PMR_FIR_MFMA=32: the 32x32x2 / 256-frame-tile form of the MFMA FIR (A/B reference) */
     int fir_tpw;            /* PMR_FIR_TPW=1: one tile per workgroup in the MFMA FIR (default 2)            */
     int fir_nodual;         /* PMR_FIR_DUAL=0: CTCSS low-pass branch in a FIR pass of its own                */
     int no_overlap;         /* PMR_OVERLAP=0                                                                */
@@ -91,14 +92,13 @@ int pmr_launch_iq_convert(pmr_stream_t s, const void *raw, void *out_cf32, unsig
  * sample j < fix_limit as it loads it.  V == NULL: nothing to do at load (the ring holds corrected samples). */
 typedef struct {
     const void *V;              /* [ntiles] cf32 carries of this block's front-end tiles                          */
-    const float *GA, *G12;      /* [256] gain per polyphase branch; [TQ + HhQ + 32] mu^q' (= T1[q' >> 5] * T2[q' & 31], float) */
+    const float *GA, *G12;      /* [256] Kgain * gain per polyphase branch (one float product); [TQ + HhQ + 32] mu^q' (= T1[q' >> 5] * T2[q' & 31]) */
     uint64_t pos0;              /* absolute ring index of the block's first output                                */
     uint32_t phi0, step;        /* resampler phase before the block's first decimated sample, step (2^24 per decimated sample) */
     uint32_t fix_limit;         /* outputs j < fix_limit are corrected at load                                    */
     uint32_t ntiles, TQ, HhQ;   /* tiles of the block; decimated samples a tile owns; its halo in decimated samples */
     uint32_t qbias, nbias;      /* nbias * TQ: added to decimated indices so history before the block stays non-negative */
     uint32_t nv;                /* carries one workgroup can meet (LDS table length)                              */
-    float Kgain;
 } pmr_carry_fix;
 
 typedef struct {
@@ -161,7 +161,13 @@ int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in,
                         const float *taps_pad, const float *taps2_pad, unsigned ntaps, int16_t *pcm, float *audio, unsigned stride,
                         float *out2_tm, const unsigned *chan_list, unsigned n_chan);
 
-/* M = 16 audio FIR on the matrix pipe (pmr_fir_mfma.hip): banded-Toeplitz x data with v_mfma_f32_32x32x2_f32 */
+/* audio FIR on the matrix pipe, the product (pmr_fir_mfma4.hip): banded-Toeplitz x data with v_mfma_f32_16x16x4_f32, 128-frame
+ * tiles; chan_list as below; taps2_pad / out2_tm: optional second tap set -> time-major, same pass */
+int pmr_fir_mfma4_supported(unsigned M, unsigned ntaps);
+int pmr_launch_fir_mfma4(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+                         const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
+                         const unsigned *chan_list, unsigned n_chan, const float *taps2_pad, float *out2_tm);
+/* the 32x32x2 form it replaced (PMR_FIR_MFMA=32: A/B reference) */
 int pmr_fir_mfma_supported(unsigned M, unsigned ntaps);
 int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
                         unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio,
@@ -232,7 +238,7 @@ typedef struct {
 
 typedef struct {
     void *xr; uint64_t pos0, mask; const void *V;
-    const float *GA, *T1, *T2;
+    const float *GA, *T1, *T2;  /* one-level form (k_fe_tilefix, k_fe_carry_tail): GA = Kgain * gain per branch; level 1 (k_fe_carry): unused */
     unsigned ny, TQ, HhQ;       /* ny: outputs of the block; only j in [j0, ny) are corrected (k_fe_carry, k_fe_tilefix) */
     unsigned j0;
     uint32_t phi0, step;
@@ -252,6 +258,8 @@ int pmr_launch_frontend_l2(pmr_stream_t s, const pmr_fe_params *p, unsigned ntil
 int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev);
 /* tile carries of a level-1 launch (V[c], next call's dc state) + in-place dc fix of the ring samples [f->j0, f->ny) */
 int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f);
+/* one-level front end, carry applied at the channelizer's loads: tile carries + in-place correction of the block's tail [f->j0, f->ny) */
+int pmr_launch_fe_carry_tail(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, const pmr_launch_events *ev);
 /* one-level front end, carries + correction of the resampled stream in place, one wave per tile */
 int pmr_launch_fe_tilefix(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f, unsigned n_q,
                           const pmr_launch_events *ev);

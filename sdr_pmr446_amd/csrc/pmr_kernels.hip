@@ -764,7 +764,10 @@ extern "C" int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const
                                    unsigned M, const float *taps_pad, const float *taps2_pad, unsigned ntaps, int16_t *pcm, float *audio,
                                    unsigned stride, float *out2_tm, const unsigned *chan_list, unsigned n_chan)
 {
-    if (sw->fir_mode != PMR_FIR_MFMA || sw->fir_mfma_global || !pmr_fir_mfma_supported(M, ntaps)) return -1;
+    if (sw->fir_mode != PMR_FIR_MFMA || sw->fir_mfma_global) return -1;
+    if (!sw->fir_mfma32 && pmr_fir_mfma4_supported(M, ntaps))
+        return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan, taps2_pad, out2_tm);
+    if (!pmr_fir_mfma_supported(M, ntaps)) return -1;
     if (!ns) return 0;
     return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan,
                                taps2_pad, out2_tm);
@@ -777,6 +780,8 @@ extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const f
 {
     if (!ns) return 0;
     const int mode = sw->fir_mode;           /* PMR_FIR_MFMA (default where supported), _PAIR, _LDS, _TM */
+    if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && !sw->fir_mfma32 && !sw->fir_mfma_global && pmr_fir_mfma4_supported(M, ntaps))
+        return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr);
     if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
         return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr);
     if ((mode == PMR_FIR_PAIR || mode == PMR_FIR_MFMA) && M >= 2) {
