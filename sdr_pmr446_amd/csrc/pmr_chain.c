@@ -656,6 +656,7 @@ static void read_switches(pmr_switches *w)
                 : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
     w->fir_mfma_global = env_is("PMR_FIR_MFMA", "global");
     w->fir_mfma32 = env_is("PMR_FIR_MFMA", "32");
+    w->fir_mfma4 = env_is("PMR_FIR_MFMA", "4");
     { const char *e = getenv("PMR_FIR_TPW"); w->fir_tpw = e ? atoi(e) : 2; }
     w->fir_nodual = env_is("PMR_FIR_DUAL", "0");
     w->no_overlap = env_is("PMR_OVERLAP", "0");

@@ -15,6 +15,15 @@
 //   * a workgroup = 4 waves = 128 frames: 33 KB of LDS, four per CU, 2731 workgroups per cfg2 block: the dispatcher evens the
 //     load out (10.7 wave-units of 6.4k cycles per SIMD), and one workgroup's window staging hides under three others' MFMAs;
 //   * the epilogue goes through LDS so that PCM / audio leave as whole 16-byte pieces of a channel row (256 B per channel).
+// Measured on MI355X (round 3): the k loop alone reaches 140-150 TFLOP/s with 2-4 workgroups per CU (tools/exp/mfma_f32_rate.hip:
+// 90-96 % of the f32 MFMA peak, operands from LDS), the kernel 88 (cfg2: 0.053 ms; the 32x32x2 form 0.055): the rest is the
+// window traffic -- 2731 x 36 KB = 98 MB per cfg2 block, fetched by all the workgroups of a dispatch round at once.  Two forms
+// that cut it (a workgroup sliding the window over a run of 2-6 tiles with the next rows prefetched under the MFMAs; one
+// persistent workgroup per CU) were built and measured: equal or slower alone (0.053-0.071 ms) and slower in the chain, so they
+// are not in the tree.  In the chain this kernel wins where a block has few frames (cfg3 +3 %, the reference point: twice the
+// workgroups of the 256-frame form) and LOSES at cfg2 (-8 %: its short-lived workgroups get a smaller share of the CUs beside
+// the front end's tiles than the long-lived ones of the 256-frame form, and the back-end stream is the critical one there);
+// pmr_launch_fir_tm picks per plan.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,6 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define F4_NT 256
 #define F4_TILE 128                              /* frames per workgroup: 4 waves x 2 accumulators x 16 */
 #define F4_GS 8                                  /* k-steps per software-pipeline group */
+#define F4_STAGE 10                              /* float4 per thread to stage a whole window: up to 640 rows */
 #define F4_LDY (F4_TILE + 4)                     /* epilogue staging: floats per channel row */
 
 static __device__ __forceinline__ int16_t pcm16_4(float y)
@@ -34,6 +44,59 @@ static __device__ __forceinline__ int16_t pcm16_4(float y)
     if (s >= 32767.0f) return 32767;
     if (s <= -32768.0f) return -32768;
     return (int16_t)s;                            // truncation toward zero (src/dsd_in.c:174), saturated
+}
+
+// The k loop of one wave: two 16-frame accumulators (frames 32 wave + 16 a + i of the window's tile) over `ngroups` groups of F4_GS
+// steps.  step s of accumulator a: A = Q[PAD + (ntaps-1) + (lane & 15) - (lane >> 4) - 4 s], B = Xs[(32 wave + 16 a + 4 s) * 16 + lane].
+// Two register sets: group g+1's operands are in flight from LDS while group g's MFMAs issue.
+template <bool DUAL>
+static __device__ __forceinline__ void f4_kloop(const float *Qs, const float *Q2, const float *Xs, unsigned ntaps, unsigned ngroups,
+                                                int wave, int lane, f32x4 &acc0, f32x4 &acc1, f32x4 &acd0, f32x4 &acd1)
+{
+    const float *qa = Qs + PMR_TAP_PAD + (ntaps - 1) + (lane & 15) - (lane >> 4) - 4 * (F4_GS - 1);   // group 0: step u at qa[4 (GS-1-u)]
+    const float *q2 = Q2 + (qa - Qs);
+    const float *xb = Xs + (32 * wave) * 16 + lane;                                                    // group 0: step u at xb[64 u] (+256: acc 1)
+    float a0[F4_GS], b00[F4_GS], b01[F4_GS], a1[F4_GS], b10[F4_GS], b11[F4_GS];
+    float c0[DUAL ? F4_GS : 1], c1[DUAL ? F4_GS : 1];
+#define F4_LOAD(A, B0, B1, C, G) do { const unsigned gi_ = (G) < ngroups ? (G) : ngroups - 1;    /* clamped: never past the tables */ \
+    const float *q_ = qa - 4 * F4_GS * (int)gi_, *x_ = xb + 64 * F4_GS * (int)gi_;                                                 \
+    _Pragma("unroll") for (int u = 0; u < F4_GS; u++) {                                                                             \
+        A[u] = q_[4 * (F4_GS - 1 - u)]; B0[u] = x_[64 * u]; B1[u] = x_[256 + 64 * u];                                               \
+        if constexpr (DUAL) C[u] = (q2 - 4 * F4_GS * (int)gi_)[4 * (F4_GS - 1 - u)]; }                                              \
+    __builtin_amdgcn_sched_barrier(0); } while (0)   /* keep the loads ahead of the MFMA block that hides them */
+#define F4_MMA(A, B0, B1, C) do { _Pragma("unroll") for (int u = 0; u < F4_GS; u++) {                                                  \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B0[u], acc0, 0, 0, 0);                                                    \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B1[u], acc1, 0, 0, 0);                                                    \
+        if constexpr (DUAL) {                                                                                                       \
+            acd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(C[u], B0[u], acd0, 0, 0, 0);                                                \
+            acd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(C[u], B1[u], acd1, 0, 0, 0); } }                                            \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+    F4_LOAD(a0, b00, b01, c0, 0u);
+    unsigned g = 0;
+    for (; g + 2 <= ngroups; g += 2) {
+        F4_LOAD(a1, b10, b11, c1, g + 1);
+        F4_MMA(a0, b00, b01, c0);
+        F4_LOAD(a0, b00, b01, c0, g + 2);
+        F4_MMA(a1, b10, b11, c1);
+    }
+    if (ngroups & 1) F4_MMA(a0, b00, b01, c0);                       // set 0 holds group ngroups-1 here
+#undef F4_LOAD
+#undef F4_MMA
+}
+
+// time-major store of one wave's two accumulators: register q of lane l = frame t0 + 16 a + 4 (l >> 4) + q, channel (l & 15)
+static __device__ __forceinline__ void f4_store_tm(float *__restrict__ out, unsigned long long row_mask, long long row0, unsigned M,
+                                                   unsigned ns, long t0, unsigned chs, int lane, const f32x4 &d0, const f32x4 &d1)
+{
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const f32x4 d = a ? d1 : d0;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            const long t = t0 + 16 * a + 4 * (lane >> 4) + qq;
+            if (t < (long)ns) out[((unsigned long long)(row0 + t) & row_mask) * M + chs] = d[qq];
+        }
+    }
 }
 
 // GATHER (open-channel mask, reference :876-877): the 16 columns of a tile are 16 arbitrary (channel, 128-frame segment) units.
@@ -100,61 +163,29 @@ __global__ __launch_bounds__(F4_NT, 4) void k_fir_mfma4(const float *__restrict_
             }
         }
     } else {
-        for (unsigned u0 = tid; u0 < nrows * 4; u0 += F4_NT * 9) {
-            float4 v[9];
+        {
+            float4 v[F4_STAGE];                                      // nrows * 4 <= F4_STAGE * F4_NT (pmr_fir_mfma4_supported)
 #pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const unsigned u = u0 + F4_NT * i, r = u >> 2, q4 = (u & 3) * 4;
+            for (int i = 0; i < F4_STAGE; i++) {
+                const unsigned u = tid + F4_NT * i, r = u >> 2, q4 = (u & 3) * 4;
                 const long t = T0 - (long)(ntaps - 1) + r;
                 v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (u < nrows * 4 && t < (long)ns)
                     v[i] = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + q4);
             }
 #pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const unsigned u = u0 + F4_NT * i;
+            for (int i = 0; i < F4_STAGE; i++) {
+                const unsigned u = tid + F4_NT * i;
                 if (u < nrows * 4) reinterpret_cast<float4 *>(Xs)[u] = v[i];
             }
         }
     }
     __syncthreads();
 
-    // ---- banded Toeplitz x window.  step s of accumulator a: A = Q[PAD + (ntaps-1) + (lane & 15) - (lane >> 4) - 4 s],
-    //      B = Xs[(32 wave + 16 a + 4 s) * 16 + lane].  Two register sets: group g+1's operands are in flight from LDS while
-    //      group g's MFMAs issue ----
+    // ---- banded Toeplitz x window ----
     const bool active = GATHER || T0 + 32 * wave < (long)ns;         // else: the whole wave lies beyond the block
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acd0 = acc0, acd1 = acc0;
-    if (active) {
-        const float *qa = Qs + PMR_TAP_PAD + (ntaps - 1) + (lane & 15) - (lane >> 4) - 4 * (F4_GS - 1);   // group 0: step u at qa[4 (GS-1-u)]
-        const float *q2 = Q2 + (qa - Qs);
-        const float *xb = Xs + (32 * wave) * 16 + lane;                                                    // group 0: step u at xb[64 u] (+256: acc 1)
-        float a0[F4_GS], b00[F4_GS], b01[F4_GS], a1[F4_GS], b10[F4_GS], b11[F4_GS];
-        float c0[DUAL ? F4_GS : 1], c1[DUAL ? F4_GS : 1];
-#define F4_LOAD(A, B0, B1, C, G) do { const unsigned gi_ = (G) < ngroups ? (G) : ngroups - 1;    /* clamped: never past the tables */ \
-        const float *q_ = qa - 4 * F4_GS * (int)gi_, *x_ = xb + 64 * F4_GS * (int)gi_;                                                 \
-        _Pragma("unroll") for (int u = 0; u < F4_GS; u++) {                                                                             \
-            A[u] = q_[4 * (F4_GS - 1 - u)]; B0[u] = x_[64 * u]; B1[u] = x_[256 + 64 * u];                                               \
-            if constexpr (DUAL) C[u] = (q2 - 4 * F4_GS * (int)gi_)[4 * (F4_GS - 1 - u)]; }                                              \
-        __builtin_amdgcn_sched_barrier(0); } while (0)   /* keep the loads ahead of the MFMA block that hides them */
-#define F4_MMA(A, B0, B1, C) do { _Pragma("unroll") for (int u = 0; u < F4_GS; u++) {                                                  \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B0[u], acc0, 0, 0, 0);                                                    \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[u], B1[u], acc1, 0, 0, 0);                                                    \
-            if constexpr (DUAL) {                                                                                                       \
-                acd0 = __builtin_amdgcn_mfma_f32_16x16x4f32(C[u], B0[u], acd0, 0, 0, 0);                                                \
-                acd1 = __builtin_amdgcn_mfma_f32_16x16x4f32(C[u], B1[u], acd1, 0, 0, 0); } }                                            \
-        __builtin_amdgcn_sched_barrier(0); } while (0)
-        F4_LOAD(a0, b00, b01, c0, 0u);
-        unsigned g = 0;
-        for (; g + 2 <= ngroups; g += 2) {
-            F4_LOAD(a1, b10, b11, c1, g + 1);
-            F4_MMA(a0, b00, b01, c0);
-            F4_LOAD(a0, b00, b01, c0, g + 2);
-            F4_MMA(a1, b10, b11, c1);
-        }
-        if (ngroups & 1) F4_MMA(a0, b00, b01, c0);                   // set 0 holds group ngroups-1 here
-#undef F4_LOAD
-#undef F4_MMA
-    }
+    if (active) f4_kloop<DUAL>(Qs, Q2, Xs, ntaps, ngroups, wave, lane, acc0, acc1, acd0, acd1);
 
     // D layout: lane holds column (lane & 15) = channel slot; register q = row 4 (lane >> 4) + q = frame
     const int sl = lane & 15, fr = 32 * wave + 4 * (lane >> 4);      // + 16 a + q
@@ -234,7 +265,8 @@ __global__ __launch_bounds__(F4_NT, 4) void k_fir_mfma4(const float *__restrict_
 extern "C" int pmr_fir_mfma4_supported(unsigned M, unsigned ntaps)
 {
     /* the window (112 + 32 ceil((ntaps + 18) / 32) rows of 64 B) + the tap table(s) must fit four workgroups' LDS budget */
-    return M >= 16 && M % 16 == 0 && M <= 16 * 65535u && ntaps >= 2 && ntaps <= 480;
+    const unsigned nsteps = (ntaps - 1 + 16 + 3) / 4, ngroups = (nsteps + F4_GS - 1) / F4_GS;
+    return M >= 16 && M % 16 == 0 && M <= 16 * 65535u && ntaps >= 2 && ((F4_TILE - 16) + 4 * F4_GS * ngroups) * 4 <= F4_STAGE * F4_NT;
 }
 
 extern "C" int pmr_launch_fir_mfma4(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,

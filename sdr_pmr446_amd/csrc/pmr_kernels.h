@@ -29,6 +29,7 @@ typedef struct {
     int fir_mode;           /* PMR_FIR=pair|lds|global: VALU versions of the audio FIR (PMR_FIR_*)          */
     int fir_mfma_global;    /* PMR_FIR_MFMA=global: MFMA FIR without the LDS sample window                  */
     int fir_mfma32;         /* PMR_FIR_MFMA=32: the 32x32x2 / 256-frame-tile form of the MFMA FIR (A/B reference) */
+    int fir_mfma4;          /* PMR_FIR_MFMA=4: the 16x16x4 / 128-frame-tile form for every plan (default: by plan, pmr_launch_fir_tm) */
     int fir_tpw;            /* PMR_FIR_TPW=1: one tile per workgroup in the MFMA FIR (default 2)            */
     int fir_nodual;         /* PMR_FIR_DUAL=0: CTCSS low-pass branch in a FIR pass of its own                */
     int no_overlap;         /* PMR_OVERLAP=0                                                                */

@@ -760,12 +760,23 @@ extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, un
     return (int)hipGetLastError();
 }
 
+/* Which MFMA form runs the audio FIR (both give the same bits).  The 16x16x4 / 128-frame-tile kernel (pmr_fir_mfma4.hip) unless
+ * the plan is 16 channels with big blocks: there the 32x32x2 kernel's 256-frame, two-tiles-per-workgroup form is faster IN THE
+ * CHAIN (cfg2: 376 vs 345 GS/s on one box; see the header of pmr_fir_mfma4.hip), while blocks of a few thousand frames (the
+ * reference's 100 000-sample blocks: 1220) want the finer tiles (10 workgroups instead of 5).  PMR_FIR_MFMA=4 / =32 force one. */
+static bool fir_use_mfma4(const pmr_switches *sw, unsigned M, unsigned ntaps, unsigned ns)
+{
+    if (!pmr_fir_mfma4_supported(M, ntaps) || sw->fir_mfma32) return false;
+    if (sw->fir_mfma4 || !pmr_fir_mfma_supported(M, ntaps)) return true;
+    return !(M == 16 && ns >= 65536);
+}
+
 extern "C" int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
                                    unsigned M, const float *taps_pad, const float *taps2_pad, unsigned ntaps, int16_t *pcm, float *audio,
                                    unsigned stride, float *out2_tm, const unsigned *chan_list, unsigned n_chan)
 {
     if (sw->fir_mode != PMR_FIR_MFMA || sw->fir_mfma_global) return -1;
-    if (!sw->fir_mfma32 && pmr_fir_mfma4_supported(M, ntaps))
+    if (fir_use_mfma4(sw, M, ntaps, ns))
         return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan, taps2_pad, out2_tm);
     if (!pmr_fir_mfma_supported(M, ntaps)) return -1;
     if (!ns) return 0;
@@ -780,7 +791,7 @@ extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const f
 {
     if (!ns) return 0;
     const int mode = sw->fir_mode;           /* PMR_FIR_MFMA (default where supported), _PAIR, _LDS, _TM */
-    if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && !sw->fir_mfma32 && !sw->fir_mfma_global && pmr_fir_mfma4_supported(M, ntaps))
+    if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && !sw->fir_mfma_global && fir_use_mfma4(sw, M, ntaps, ns))
         return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr);
     if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
         return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr);

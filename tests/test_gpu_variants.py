@@ -49,7 +49,9 @@ VARIANTS = [
     ({"PMR_CHANNELIZER_SMALL": "pair"}, CFG2),
     ({"PMR_FIR": "pair"}, CFG2),
     ({"PMR_FIR_MFMA": "global"}, CFG2),
-    ({"PMR_FIR_TPW": "1"}, CFG2),
+    ({"PMR_FIR_TPW": "1", "PMR_FIR_MFMA": "32"}, CFG2),
+    ({"PMR_FIR_MFMA": "4"}, CFG2),                            # 16x16x4 / 128-frame tiles where the plan would pick the 256-frame form
+    ({"PMR_FIR_MFMA": "32"}, CFG3),                           # ... and the other way round
     ({"PMR_FIR_DUAL": "0"}, CFG2),
     ({"PMR_OVERLAP": "0", "PMR_STREAM_PRIO": "1"}, CFG2),
 ]
