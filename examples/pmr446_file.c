@@ -111,7 +111,7 @@ static int run_scan(const char *in, const char *out, double fs, unsigned M)
     int rc = pmr_chain_set_channel_mask(q, mask, W);                                    /* scanning: nothing is demodulated */
     pmr_squelch sq;
     pmr_squelch_init(&sq);
-    int n;
+    int n = 0;
     unsigned long blocks = 0, frames = 0;
     while (!rc && (n = pmr_iq_reader_read(r, iq, cfg.max_block)) > 0) {                 /* :789 */
         unsigned ns = 0;
@@ -137,7 +137,7 @@ static int run_scan(const char *in, const char *out, double fs, unsigned M)
     fprintf(stderr, "pmr446_file: %lu blocks, %lu audio frames written\n", blocks, frames);
     pmr_wav_writer_close(w); pmr_iq_reader_close(r); pmr_chain_destroy(q);
     free(iq); free(audio); free(rssi); free(pcm);
-    return rc ? 1 : 0;
+    return rc || n < 0 ? 1 : 0;                                                          /* n < 0: the reader failed */
 }
 
 static int run_dsd(const char *in, const char *out, double fs)

@@ -142,7 +142,8 @@ int   pmr_chain_synchronize_input(pmr_chain q);
  * the squelch state machine hands over the active channel, :834-839).  mask_words: bit (k & 63) of word k >> 6 enables
  * channel k, n_words * 64 >= M; NULL = every channel (the default).  Channelizer, RSSI and the discriminator keep running for
  * every channel, so a channel that is opened later starts with current filter history; the audio FIR / PCM / CTCSS branch
- * run for the enabled channels only and the pcm / audio rows of disabled channels are left untouched.
+ * run for the enabled channels only and the pcm / audio rows of disabled channels are left untouched (host and device entry
+ * points alike).  Needs num_channels to be a multiple of 16 (the audio kernels' tile width); PMR_EINVAL otherwise.
  * pmr_chain_reset_channel = freqdem_reset + ctcss_detector_reset of one channel (what the reference does when the squelch
  * detunes, :866-867): the channel's first discriminator output of the next block is arg(0) = 0. ---- */
 int   pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned n_words);

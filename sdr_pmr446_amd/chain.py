@@ -490,9 +490,9 @@ class PmrChain:
         else:
             iq = np.ascontiguousarray(iq, dtype=np.int16 if fmt == IQ_CS16 else np.uint8).reshape(-1); n = len(iq) // 2
         self._pending = getattr(self, "_pending", [])
-        self._pending.append((iq, set(want)))
         w = sum(self.WANT[k] for k in want)
         self._check(self._L.pmr_chain_submit_block_fmt(self.h, iq.ctypes.data if n else None, fmt, n, w))
+        self._pending.append((iq, set(want)))        # only a block the library accepted is waiting to be collected
 
     def collect_block(self):
         """Outputs of the oldest submitted block: dict like process_block."""

@@ -53,6 +53,8 @@ typedef struct {
     char *hd_out; cfl *hd_chan;                  /* the same pinned buffers as the DEVICE sees them (zero-copy outputs of small blocks) */
     size_t out_bytes, off_pcm, off_audio;
     hipEvent_t done; unsigned ns, stride, want;
+    uint8_t *open_rows; int masked;              /* the channel mask the block's audio part ran under (rows of closed channels are
+                                                    never handed to the caller: include/pmr_chain.h, pmr_chain_set_channel_mask) */
 } pmr_slot;
 
 struct pmr_chain_s {
@@ -94,7 +96,7 @@ struct pmr_chain_s {
     pmr_slot slot[PIPE_DEPTH]; unsigned slot_head, n_inflight;
 
     /* open-channel mask (reference :876-877) and per-channel discriminator reset (:866) */
-    unsigned *d_chan_list; unsigned n_enabled; int mask_on;
+    unsigned *d_chan_list; unsigned n_enabled; int mask_on; uint8_t *h_open;   /* h_open[k]: channel k enabled (host copy of the mask) */
     uint8_t *d_reset_flags, *h_reset_flags; int reset_pending;
 
     /* CTCSS branch (pmr_ctcss.hip), allocated by pmr_chain_ctcss_enable */
@@ -617,6 +619,8 @@ static int chain_init(pmr_chain q)
     if ((rc = dev_alloc(q, (void **)&q->d_chan_list, (size_t)M * sizeof(unsigned)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_reset_flags, M))) return rc;
     if (!(q->h_reset_flags = (uint8_t *)calloc(M, 1))) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
+    if (!(q->h_open = (uint8_t *)malloc(M))) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
+    memset(q->h_open, 1, M);
     q->n_enabled = M; q->mask_on = 0; q->reset_pending = 0;
 
     if ((rc = fe_init(q))) return rc;
@@ -769,6 +773,8 @@ int pmr_chain_destroy(pmr_chain q)
     if (q->stream) hipStreamDestroy(q->stream);
     pmr_design_free(&q->d);
     free(q->h_reset_flags);
+    free(q->h_open);
+    for (unsigned i = 0; i < PIPE_DEPTH; i++) free(q->slot[i].open_rows);
     free(q);
     return PMR_OK;
 }
@@ -1614,6 +1620,17 @@ static int slot_prepare(pmr_chain q, unsigned i, int want_chan)
 
 static const void *host_zero_copy(const void *p, size_t bytes);
 
+/* remember which channels the audio part of the slot's block runs for: the FIR leaves the rows of closed channels alone, and the
+ * compact staging rows they would come from hold another block's data */
+static int slot_snapshot_mask(pmr_chain q, pmr_slot *sl)
+{
+    sl->masked = q->mask_on;
+    if (!q->mask_on) return PMR_OK;
+    if (!sl->open_rows && !(sl->open_rows = (uint8_t *)malloc(q->M))) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
+    memcpy(sl->open_rows, q->h_open, q->M);
+    return PMR_OK;
+}
+
 /* queue one block: H2D -> chain -> D2H into the slot's pinned buffers; nothing is waited for.
  * Synchronous calls on SMALL blocks skip both copy engines (each copy is a submission of its own with ~10 us of hand-over on
  * either side, 100 us -> 70 us per 100 000-sample call): the front end reads the caller's pinned buffer in place and the last
@@ -1663,6 +1680,7 @@ static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigne
                                    (want & PMR_WANT_RSSI) ? o_out : NULL, single, phase);
     if (rc) return rc;
     sl->ns = ns; sl->stride = stride; sl->want = want;
+    if ((rc = slot_snapshot_mask(q, sl))) return rc;
     if (ns && !zc_out) {
         const size_t lo = (want & PMR_WANT_RSSI) ? 0 : (want & PMR_WANT_PCM) ? sl->off_pcm : sl->off_audio;
         const size_t hi = (want & PMR_WANT_AUDIO) ? sl->off_audio + n * sizeof(float)
@@ -1688,8 +1706,9 @@ static int slot_collect(pmr_chain q, unsigned i, int16_t *pcm, float *audio, uns
         const int16_t *hp = (const int16_t *)(sl->h_out + sl->off_pcm);
         const float *ha = (const float *)(sl->h_out + sl->off_audio);
         for (unsigned k = 0; k < M; k++) {
-            if (pcm && (sl->want & PMR_WANT_PCM)) memcpy(pcm + (size_t)k * pcm_stride, hp + (size_t)k * sl->stride, (size_t)ns * sizeof(int16_t));
-            if (audio && (sl->want & PMR_WANT_AUDIO)) memcpy(audio + (size_t)k * pcm_stride, ha + (size_t)k * sl->stride, (size_t)ns * sizeof(float));
+            const int open = !sl->masked || sl->open_rows[k];   /* closed channel: its pcm / audio rows stay as the caller left them */
+            if (open && pcm && (sl->want & PMR_WANT_PCM)) memcpy(pcm + (size_t)k * pcm_stride, hp + (size_t)k * sl->stride, (size_t)ns * sizeof(int16_t));
+            if (open && audio && (sl->want & PMR_WANT_AUDIO)) memcpy(audio + (size_t)k * pcm_stride, ha + (size_t)k * sl->stride, (size_t)ns * sizeof(float));
             if (chan_out && (sl->want & PMR_WANT_CHAN)) memcpy((cfl *)chan_out + (size_t)k * pcm_stride, sl->h_chan + (size_t)k * sl->stride, (size_t)ns * sizeof(cfl));
         }
         if (rssi_db && (sl->want & PMR_WANT_RSSI)) memcpy(rssi_db, sl->h_out, (size_t)M * sizeof(float));
@@ -1761,6 +1780,7 @@ int pmr_chain_demodulate_block(pmr_chain q, int16_t *pcm, float *audio, unsigned
     if (ns && (rc = audio_part(q, q->pend_audio_frame0, ns, (want & PMR_WANT_PCM) ? o_out + sl->off_pcm : NULL,
                                (want & PMR_WANT_AUDIO) ? o_out + sl->off_audio : NULL, stride))) return rc;
     sl->ns = ns; sl->stride = stride; sl->want = want;
+    if ((rc = slot_snapshot_mask(q, sl))) return rc;
     if (ns && !zc_out && want)
         HIPCHK(hipMemcpyAsync(sl->h_out + sl->off_pcm, sl->d_out + sl->off_pcm, out_hi - sl->off_pcm, hipMemcpyDeviceToHost, q->stream), "D2H");
     HIPCHK(hipEventRecord(sl->done, q->stream), "record");
@@ -1866,8 +1886,12 @@ int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned
     if (!q) return PMR_EINVAL;
     const unsigned M = q->M;
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
-    if (!mask_words) { q->mask_on = 0; q->n_enabled = M; return PMR_OK; }
+    if (!mask_words) { q->mask_on = 0; q->n_enabled = M; memset(q->h_open, 1, M); return PMR_OK; }
     if ((uint64_t)n_words * 64 < M) return fail(q, PMR_EINVAL, "channel mask shorter than num_channels", hipSuccess);
+    /* the mask is applied by the MFMA audio kernels (16 channels per tile); the VALU versions (num_channels not a multiple of 16,
+     * PMR_FIR=pair|lds|global) would write every row: refuse instead of breaking the "closed rows stay untouched" promise */
+    if (q->sw.fir_mode != PMR_FIR_MFMA || q->sw.fir_mfma_global || !pmr_fir_mfma4_supported(M, q->hp_len))
+        return fail(q, PMR_EINVAL, "channel mask needs the MFMA audio kernels (num_channels a multiple of 16)", hipSuccess);
     unsigned *list = (unsigned *)malloc((size_t)M * sizeof(unsigned));
     if (!list) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
     unsigned n = 0;
@@ -1875,6 +1899,10 @@ int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned
     /* the list is read by kernels of calls already queued: let them finish before it changes */
     hipError_t e = hipStreamSynchronize(q->stream);
     if (e == hipSuccess && n) e = hipMemcpy(q->d_chan_list, list, (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        memset(q->h_open, 0, M);
+        for (unsigned i = 0; i < n; i++) q->h_open[list[i]] = 1;
+    }
     free(list);
     if (e != hipSuccess) return fail(q, PMR_EHIP, "channel mask upload", e);
     q->n_enabled = n;
@@ -1897,6 +1925,7 @@ int pmr_chain_reset_channel(pmr_chain q, unsigned channel)
         for (int i = 0; i < 2; i++)
             HIPCHK(hipMemset((char *)q->d_ct_carry[i] + (size_t)channel * PMR_CT_TONES * 2 * sizeof(float), 0,
                              (size_t)PMR_CT_TONES * 2 * sizeof(float)), "reset channel");
+        HIPCHK(hipMemset(q->d_ct_dcstate + channel, 0, sizeof(float)), "reset channel");    /* iirfilt_rrrf_reset of :606's blocker */
     }
     return PMR_OK;
 }

@@ -13,23 +13,23 @@ SENTINEL = 12345
 
 
 def _gpu_masked(fs, M, x, splits, enabled, **kw):
-    """PCM rows of a chain with the channel mask set, output buffers pre-filled with a sentinel."""
-    import torch
+    """PCM rows of a chain with the channel mask set, output buffers pre-filled with a sentinel.  Device buffers come from the
+    library's own runtime (include/pmr_mem.h), not from torch."""
     from sdr_pmr446_amd import chain
     g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(splits), **kw)
     g.set_channel_mask(enabled)
     S = g.max_frames
-    dev = torch.device("cuda", 0)
-    xd = torch.from_numpy(x.view(np.float32)).to(dev)
+    xd = chain.DeviceBuffer(x.nbytes); xd.upload(x)
+    out = chain.DeviceBuffer(M * S * 2)
+    fill = np.full(M * S, SENTINEL, dtype=np.int16)
     parts, pos = [], 0
     for n in splits:
-        pcm = torch.full((M, S), SENTINEL, dtype=torch.int16, device=dev)
-        torch.cuda.synchronize()
-        ns = g.process_block_device(xd.data_ptr() + pos * 8, n, d_pcm=pcm.data_ptr(), stride=S)
+        out.upload(fill)
+        ns = g.process_block_device(xd.ptr + pos * 8, n, d_pcm=out.ptr, stride=S)
         g.synchronize()
-        parts.append(pcm[:, :ns].cpu().numpy())
+        parts.append(out.download(np.int16, M * S).reshape(M, S)[:, :ns].copy())
         pos += n
-    g.close()
+    g.close(); xd.free(); out.free()
     return np.concatenate(parts, axis=1)
 
 
@@ -73,7 +73,6 @@ def test_open_channels_equal_the_all_channel_run(cfg, enabled):
 def test_mask_change_between_blocks_and_lowpass_chain():
     """The mask may change between calls; a channel opened later has current history (the discriminator ran all along), so
     from its first open block on it equals the all-channel run.  Also covers the multi-pass audio chain (deemph FIR + low-pass)."""
-    import torch
     from sdr_pmr446_amd import chain
     fs, M = CFG2
     n = 100000
@@ -82,16 +81,16 @@ def test_mask_change_between_blocks_and_lowpass_chain():
     full = _gpu_masked(fs, M, x, [n, n, n], None, **kw)
     g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n, **kw)
     S = g.max_frames
-    dev = torch.device("cuda", 0)
-    xd = torch.from_numpy(x.view(np.float32)).to(dev)
+    xd = chain.DeviceBuffer(x.nbytes); xd.upload(x)
+    pcm = chain.DeviceBuffer(M * S * 2)
+    fill = np.full(M * S, SENTINEL, dtype=np.int16)
     out = []
     for b, en in enumerate(([2], [2, 6], [6])):
         g.set_channel_mask(en)
-        pcm = torch.full((M, S), SENTINEL, dtype=torch.int16, device=dev)
-        torch.cuda.synchronize()
-        ns = g.process_block_device(xd.data_ptr() + b * n * 8, n, d_pcm=pcm.data_ptr(), stride=S)
+        pcm.upload(fill)
+        ns = g.process_block_device(xd.ptr + b * n * 8, n, d_pcm=pcm.ptr, stride=S)
         g.synchronize()
-        out.append(pcm[:, :ns].cpu().numpy())
+        out.append(pcm.download(np.int16, M * S).reshape(M, S)[:, :ns].copy())
     f0 = out[0].shape[1]; f1 = f0 + out[1].shape[1]
     assert np.array_equal(out[0][2], full[2, :f0]) and np.array_equal(out[1][2], full[2, f0:f1])
     assert np.array_equal(out[1][6], full[6, f0:f1]) and np.array_equal(out[2][6], full[6, f1:])
@@ -120,3 +119,67 @@ def test_reset_channel_is_freqdem_reset(cfg, k):
     assert np.abs(rg["fm"][act] - ro["fm"][act]).max() < 5e-6
     assert pcm_diff(rg["pcm"][act], ro["pcm"][act]).max() <= 1
     o.close(); g.close()
+
+
+def test_host_entry_points_leave_closed_channels_rows_untouched():
+    """include/pmr_chain.h: 'the pcm / audio rows of disabled channels are left untouched' -- also for the HOST-buffer entry points
+    (pmr_chain_process_block_f32, submit / collect, channelize + demodulate), whose outputs pass through compact staging rows that
+    hold another block's data for a closed channel.  Rows of open channels equal the all-channel run bit for bit."""
+    import ctypes as C
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    n, nb = 100000, 4
+    x = synth.synth_iq(nb * n, fs, M, dev_hz=1500.0)
+    ref = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n)
+    full = [ref.process_block(x[b * n:(b + 1) * n], want=("pcm", "audio")) for b in range(nb)]
+    ref.close()
+    masks = ([3], [3, 9], [9], [0, 15])
+    ip = lambda a: a.ctypes.data
+
+    def buffers(S):
+        return np.full((M, S), SENTINEL, dtype=np.int16), np.full((M, S), float(SENTINEL), dtype=np.float32)
+
+    def check(b, pcm, audio, ns, en):
+        assert ns == full[b]["n_frames"] and ns > 100
+        closed = [c for c in range(M) if c not in en]
+        assert np.all(pcm[closed] == SENTINEL) and np.all(audio[closed] == float(SENTINEL)), "block %d: closed rows written" % b
+        assert np.array_equal(pcm[en, :ns], full[b]["pcm"][en]) and np.array_equal(audio[en, :ns], full[b]["audio"][en])
+        assert np.all(pcm[en, ns:] == SENTINEL)
+
+    # synchronous call
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n)
+    S = g.max_frames
+    for b, en in enumerate(masks):
+        g.set_channel_mask(en)
+        pcm, audio = buffers(S)
+        ns = C.c_uint(0)
+        xb = np.ascontiguousarray(x[b * n:(b + 1) * n])
+        g._check(g._L.pmr_chain_process_block_f32(g.h, ip(xb), n, ip(pcm), ip(audio), S, C.byref(ns), None, None))
+        check(b, pcm, audio, ns.value, en)
+    g.close()
+    # asynchronous pair: two blocks in flight, the mask changes between the submits
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n)
+    keep = []
+    for b0 in (0, 2):
+        for b in (b0, b0 + 1):
+            g.set_channel_mask(masks[b])
+            xb = np.ascontiguousarray(x[b * n:(b + 1) * n]); keep.append(xb)
+            g._check(g._L.pmr_chain_submit_block(g.h, ip(xb), n, 3))
+        for b in (b0, b0 + 1):
+            pcm, audio = buffers(S)
+            ns = C.c_uint(0)
+            g._check(g._L.pmr_chain_collect_block(g.h, ip(pcm), ip(audio), S, C.byref(ns), None, None))
+            check(b, pcm, audio, ns.value, masks[b])
+    g.close()
+    # two-step form: the mask set AFTER the block was channelized is the one that counts
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n)
+    for b, en in enumerate(masks):
+        xb = np.ascontiguousarray(x[b * n:(b + 1) * n])
+        ns = C.c_uint(0)
+        rssi = np.zeros(M, dtype=np.float32)
+        g._check(g._L.pmr_chain_channelize_block(g.h, ip(xb), n, C.byref(ns), None, 0, ip(rssi)))
+        g.set_channel_mask(en)
+        pcm, audio = buffers(S)
+        g._check(g._L.pmr_chain_demodulate_block(g.h, ip(pcm), ip(audio), S, C.byref(ns)))
+        check(b, pcm, audio, ns.value, en)
+    g.close()
