@@ -190,30 +190,10 @@ __global__ __launch_bounds__(F4_NT, 4) void k_fir_mfma4(const float *__restrict_
     // D layout: lane holds column (lane & 15) = channel slot; register q = row 4 (lane >> 4) + q = frame
     const int sl = lane & 15, fr = 32 * wave + 4 * (lane >> 4);      // + 16 a + q
     if (active) {
-        if constexpr (DUAL) {
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const f32x4 d = a ? acd1 : acd0;
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    const long t = (GATHER ? s_t0[sl] : T0) + fr + 16 * a + qq;
-                    const unsigned chs = GATHER ? s_ch[sl] : (unsigned)sl;
-                    if (t < (long)ns) out2_tm[((unsigned long long)(row0 + t) & row_mask) * M + chs] = d[qq];
-                }
-            }
-        }
-        if constexpr (TMOUT) {
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const f32x4 d = a ? acc1 : acc0;
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    const long t = (GATHER ? s_t0[sl] : T0) + fr + 16 * a + qq;
-                    const unsigned chs = GATHER ? s_ch[sl] : (unsigned)sl;
-                    if (t < (long)ns) out_tm[((unsigned long long)(row0 + t) & row_mask) * M + chs] = d[qq];
-                }
-            }
-        }
+        const long tw = (GATHER ? s_t0[sl] : T0) + 32 * wave;
+        const unsigned chs = GATHER ? s_ch[sl] : (unsigned)sl;
+        if constexpr (DUAL) f4_store_tm(out2_tm, row_mask, row0, M, ns, tw, chs, lane, acd0, acd1);
+        if constexpr (TMOUT) f4_store_tm(out_tm, row_mask, row0, M, ns, tw, chs, lane, acc0, acc1);
     }
     if (!pcm && !audio) return;                                      // uniform
 
