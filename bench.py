@@ -90,7 +90,7 @@ def _native_oracle():
     return None, "gcc -O3 -ffp-contract=off (portable build; -march=native build failed on this box)"
 
 
-def cpu_baseline(fs, M, seconds_target=8.0):
+def cpu_baseline(fs, M, seconds_target=8.0, multi=True):
     """Time the CPU oracle (kind 'port': the reference itself needs liquid-dsp and cannot be built here) on a
     bounded sample of the same workload (1 Msample blocks of the same synthetic channel plan, one process per stream):
     (i) single thread like the reference's DSP thread (src/sdr_pmr446.c:788) -- the headline `value`; (ii) N independent
@@ -119,7 +119,7 @@ def cpu_baseline(fs, M, seconds_target=8.0):
     out["one_channel"] = {"value": tot1 / dt1 / 1e6, "cores": 1,
                           "sample": "reference semantics: only the selected channel demodulated, %.1f s" % dt1}
     try:
-        ncores = len(os.sched_getaffinity(0))                           # every core this process may use
+        ncores = len(os.sched_getaffinity(0)) if multi else 1           # every core this process may use
         if ncores > 1:
             rates = [t / d for t, d in workers(ncores, seconds_target / 2, -1)]
             out["multi"] = {"value": sum(rates) / 1e6, "cores": ncores,
@@ -238,7 +238,7 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
         ch.synchronize()
         return n
 
-    sync_dev = dev if args.dist_backend == "nccl" else None
+    sync_dev = None                                   # (the Dist object knows where its MAX-reduce tensor lives)
     dts, frames = [], 0
     for _ in range(max(1, args.regions if headline or world == 1 else 1)):
         dt, frames = multigpu.timed_region(run, dist, device_sync, sync_dev)
@@ -316,8 +316,9 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
             rec["parity_checked"] = parity_check(ch, fs, M, iq, block, pcm_bufs, S, nchk)
         if headline and args.host_io and world == 1:
             rec["host_io"] = host_io(ch, iq, block, M, S)
-        if headline and world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(fs, M)
+        if world == 1 and not args.no_cpu_baseline:
+            # headline: ~16 s incl. one stream per core; sub-records: the single-core and one-channel figures only (~6 s each)
+            rec["cpu_baseline"] = cpu_baseline(fs, M, 8.0 if headline else 4.0, multi=headline)
     ch.close()
     iq.free()
     for b in pcm_bufs:
@@ -392,7 +393,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="blocks per timed region (three blocks are in flight: a region "
-                    "pays one pipeline fill/drain of ~0.17 ms, 6 % of a 20-step region)")
+                    "pays one pipeline fill/drain of ~0.17 ms, 6 %% of a 20-step region)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--also", default=None, help="comma list of further workloads reported as sub-records "
@@ -401,8 +402,9 @@ def main():
     ap.add_argument("--parity-blocks", type=int, default=4, help="blocks of the un-synchronised oracle check (0 = skip)")
     ap.add_argument("--log2-block", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets two ranks share one "
-                                                          "GPU to exercise the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs (falls back to gloo, and says so, if the "
+                                                          "RCCL group does not come up); gloo lets two ranks share one GPU to "
+                                                          "exercise the N > 1 code path on a 1-GPU box")
     ap.add_argument("--host-io", action="store_true",
                     help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
@@ -410,19 +412,27 @@ def main():
                                                          "not the headline workload")
     args = ap.parse_args()
 
-    import torch
     from sdr_pmr446_amd import multigpu
 
     rank, local_rank, world = multigpu.env_world()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process (which has made NO GPU call) starts
+        # `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child, relays rank 0's JSON line
+        # (the child's stdout is ours) and its exit code
+        sys.exit(multigpu.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("WORLD_SIZE = %d but --gpus %d" % (world, args.gpus))
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    if args.dist_backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()          # self-test only: ranks may share a device
+    ndev = torch.cuda.device_count()
+    if args.dist_backend != "nccl" or ndev < world:
+        local_rank = local_rank % ndev                               # ranks may share a device (self-test on a 1-GPU box)
+        if args.dist_backend == "nccl" and ndev < world:
+            args.dist_backend = "gloo"                               # RCCL needs one device per rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    affinity = multigpu.bind_to_gpu_numa(local_rank, min(world, ndev)) if world > 1 else None
     dist = multigpu.init_dist(args.dist_backend, dev)
 
     if args.also is None:
@@ -446,8 +456,10 @@ def main():
                "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic"}
         if world > 1:
-            out["dist"] = {"backend": args.dist_backend, "use": "start/stop barrier and MAX of the elapsed time only: one "
-                           "independent IQ stream per rank, no data-path collective"}
+            out["dist"] = {"backend": args.dist_backend, "backend_used": dist.backend_used, "fallback_reason": dist.note,
+                           "devices_visible": ndev, "rank0_affinity": affinity,
+                           "use": "start/stop barrier and MAX of the elapsed time only: one independent IQ stream per rank, no "
+                                  "data-path collective"}
         for k in ("timed_regions", "config", "roofline", "one_open_channel", "parity_checked", "host_io", "cpu_baseline"):
             if k in head:
                 out[k] = head[k]
@@ -455,7 +467,7 @@ def main():
             out["also"] = subs
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.destroy()
 
 
 if __name__ == "__main__":

@@ -14,19 +14,121 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_dist(backend, device=None):
-    """Join the process group if WORLD_SIZE > 1.  Returns the torch.distributed module or None."""
+class Dist:
+    """What bench.py needs from torch.distributed: a barrier and the MAX of one number -- on the backend that actually came up."""
+
+    def __init__(self, dist, group, backend_used, device, note=None):
+        self.dist, self.group, self.backend_used, self.device, self.note = dist, group, backend_used, device, note
+
+    def barrier(self):
+        if self.backend_used == "nccl":                      # an all-reduce on this rank's device + a device sync: no device guessing
+            import torch
+            t = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self.dist.all_reduce(t, group=self.group)
+            torch.cuda.synchronize(self.device)
+        else:
+            self.dist.barrier(group=self.group)
+
+    def max_float(self, x):
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device=self.device if self.backend_used == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def destroy(self):
+        self.dist.destroy_process_group()
+
+
+def init_dist(backend, device=None, nccl_timeout_s=120):
+    """Join the process group if WORLD_SIZE > 1.  Returns a Dist or None.
+
+    The world group is always gloo (it only carries a barrier and one float64): that cannot fail for GPU reasons.  With
+    backend "nccl" (= RCCL on ROCm) an RCCL group is created on top and proven with one all-reduce; the ranks then AGREE (MIN over
+    gloo) whether it works everywhere -- if it does the timed region's barrier / MAX run on it, if not they stay on gloo and the
+    record says so (`backend_used`), instead of the first multi-GPU run dying in communicator set-up."""
     rank, _, world = env_world()
     if world <= 1:
         return None
+    import datetime
+    import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    kw = {}
-    if device is not None and backend == "nccl":
-        kw["device_id"] = device
-    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-    return dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend != "nccl":
+        return Dist(dist, None, "gloo", None)
+    ok, note, grp = 1, None, None
+    try:
+        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=nccl_timeout_s))
+        t = torch.ones(1, dtype=torch.float64, device=device)
+        dist.all_reduce(t, group=grp)
+        torch.cuda.synchronize(device)
+        if int(t.item()) != world:
+            raise RuntimeError("all_reduce returned %r" % t.item())
+    except Exception as e:                                   # reported in the record, never swallowed
+        ok, note = 0, "%s: %s" % (type(e).__name__, str(e)[:200])
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)             # gloo: every rank learns whether RCCL came up EVERYWHERE
+    if int(flag.item()) == 1:
+        return Dist(dist, grp, "nccl", device)
+    return Dist(dist, None, "gloo", None, note or "RCCL group failed on another rank")
+
+
+def bind_to_gpu_numa(local_rank, world_local):
+    """Best effort: pin this rank's host threads to the cores next to its GPU (the host-fed legs: H2D staging, the oracle check).
+    Uses the GPU's PCI function in sysfs (local_cpulist); falls back to an even split of the visible cores.  Returns a note."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except Exception:
+        return "affinity unsupported"
+    want = None
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as f:
+            spec = f.read().strip()
+        want = set()
+        for part in spec.split(","):
+            if "-" in part:
+                lo, hi = part.split("-"); want.update(range(int(lo), int(hi) + 1))
+            elif part:
+                want.add(int(part))
+        want = sorted(want & set(cores))
+        how = "cores local to GPU %s" % bdf
+    except Exception:
+        want = None
+    if not want:
+        n = max(1, len(cores) // max(1, world_local))
+        want = cores[(local_rank % max(1, world_local)) * n:(local_rank % max(1, world_local) + 1) * n] or cores
+        how = "even split of the visible cores"
+    try:
+        os.sched_setaffinity(0, want)
+    except Exception as e:
+        return "sched_setaffinity failed: %s" % e
+    return "%d %s" % (len(want), how)
+
+
+def self_launch(script, argv, nproc, port=None, python=None, extra_env=None):
+    """`python script --gpus N` without an external launcher: start `python -m torch.distributed.run --nproc-per-node N script argv`
+    as a CHILD process (this process has made no GPU call and makes none), relay its stdout / stderr and return its exit code.
+    Never an exec: a process image that initialised the GPU must not be replaced, and the parent stays alive to report."""
+    import socket
+    import subprocess
+    import sys
+    if port is None:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this pool's driver
+    env.update(extra_env or {})
+    p = subprocess.Popen(cmd, env=env)
+    try:
+        return p.wait()
+    except KeyboardInterrupt:
+        p.terminate()
+        return p.wait()
 
 
 def stream_id_for_rank(rank):
@@ -35,8 +137,7 @@ def stream_id_for_rank(rank):
 
 
 def timed_region(run, dist=None, device_sync=None, reduce_device=None):
-    """barrier + sync | run() | sync + barrier; returns the MAX over ranks of the elapsed seconds."""
-    import torch
+    """barrier + sync | run() | sync + barrier; returns the MAX over ranks of the elapsed seconds.  `dist`: a Dist or None."""
     if dist is not None:
         dist.barrier()
     if device_sync:
@@ -49,9 +150,7 @@ def timed_region(run, dist=None, device_sync=None, reduce_device=None):
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=reduce_device or "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = dist.max_float(dt)
     return dt, out
 
 

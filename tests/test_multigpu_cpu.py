@@ -42,7 +42,8 @@ def _worker(rank, world, port, q):
     local = time.perf_counter() - t0
     q.put((rank, sid, float(np.abs(x[:64]).sum()), dt, local, frames,
            multigpu.aggregate_throughput(world, steps, n, dt)))
-    dist.destroy_process_group()
+    assert dist.backend_used == "gloo"
+    dist.destroy()
 
 
 def test_two_ranks_two_streams_max_time():
@@ -72,3 +73,54 @@ def test_single_process_defaults():
     dt, out = multigpu.timed_region(lambda: 7)
     assert out == 7 and dt >= 0
     assert multigpu.aggregate_throughput(8, 10, 1 << 20, 2.0) == 8 * 10 * (1 << 20) / 2.0
+
+
+_RANK_SCRIPT = """
+import json, os, sys
+sys.path.insert(0, %r)
+from sdr_pmr446_amd import multigpu
+rank, local_rank, world = multigpu.env_world()
+dist = multigpu.init_dist("gloo")
+dt, out = multigpu.timed_region(lambda: rank + 1, dist)
+if rank == 0:
+    print(json.dumps({"world": world, "backend_used": dist.backend_used, "args": sys.argv[1:], "out": out}), flush=True)
+dist.destroy()
+sys.exit(int(os.environ.get("FAIL_RANK", "-1")) == rank and 3 or 0)
+"""
+
+
+def test_self_launch_starts_the_ranks_relays_output_and_exit_code(tmp_path):
+    """`python bench.py --gpus N` without an external launcher: the parent spawns torch.distributed.run as a CHILD,
+    rank 0's JSON line arrives on the parent's stdout, a failing rank's exit code is not lost."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % root)
+    parent = ("import sys; sys.path.insert(0, %r)\nfrom sdr_pmr446_amd import multigpu\n"
+              "sys.exit(multigpu.self_launch(%r, ['--x', '1'], 2))" % (root, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", parent], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    rec = json.loads(line[0])
+    assert rec == {"world": 2, "backend_used": "gloo", "args": ["--x", "1"], "out": 1}
+    r = subprocess.run([sys.executable, "-c", parent], env=dict(env, FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
+def test_bench_gpus_2_launches_itself():
+    """bench.py --gpus 2 with no WORLD_SIZE set must not ask for a launcher: it starts one.  Here (no GPU) the ranks stop at
+    'needs a GPU' -- which proves the children ran bench.py with the same arguments -- and the parent relays the failure."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by profiles/r03_bench_2rank_1gpu.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs a GPU" in r.stderr and "launch with torch.distributed.run" not in r.stderr
