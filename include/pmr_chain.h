@@ -168,7 +168,8 @@ enum { PMR_INFO_NUM_STAGES = 0, PMR_INFO_M_STAGE = 1, PMR_INFO_ARB_STEP = 2, PMR
        PMR_INFO_ARB_NPFB = 4, PMR_INFO_ARB_M = 5, PMR_INFO_PFB_P = 6,
        PMR_INFO_CARRY_AT_LOAD = 7 /* 1: the front end's dc carry is applied where the channelizer loads the resampled stream
                                      (one-level front ends with the 16- / 256-channel kernels); handle only */ };
-enum { PMR_DESIGN_HALFBAND = 0, PMR_DESIGN_ARB = 1, PMR_DESIGN_PFB = 2 };
+enum { PMR_DESIGN_HALFBAND = 0, PMR_DESIGN_ARB = 1, PMR_DESIGN_PFB = 2,
+       PMR_DESIGN_DEEMPH = 3 /* {b0, b1, a1} of the de-emphasis IIR, normalised by a0 (src/sdr_pmr446.c:462-463) */ };
 unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx);
 unsigned pmr_chain_design(pmr_chain q, int what, unsigned idx, float *out, unsigned cap);
 enum { PMR_DEBUG_RESAMPLED = 0,   /* cf32 [ny]  resampler output of the last block (:796)              */

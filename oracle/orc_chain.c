@@ -88,6 +88,43 @@ static unsigned ctcss_detector_analyze(orc_ctcss_detector *c, const float *xs, u
     return nev;
 }
 
+/* The detector and the dc blocker in front of it (ctcss_execute, :605-610) on a bare float stream, from zero state: what
+ * tests/test_ctcss_ref_fixture.py runs against vectors produced by the REFERENCE's own ctcss_detector_* code
+ * (tools/make_ref_fixtures.py compiles src/sdr_pmr446.c:338-409 in the build container).  powers: nullable [cap][38]. */
+unsigned orc_ctcss_detector_run(const float *xs, unsigned nx, double audio_rate, unsigned block, orc_ctcss_event *ev, unsigned cap,
+                                float *powers)
+{
+    orc_ctcss_detector c;
+    ctcss_detector_init(&c, audio_rate);
+    unsigned nev = 0;
+    for (unsigned i = 0; i < nx; i++) {
+        orc_ctcss_event e;
+        if (ctcss_detector_analyze(&c, xs + i, 1, block, &e, 1)) {
+            if (nev < cap) {
+                if (ev) ev[nev] = e;
+                if (powers) memcpy(powers + (size_t)nev * ORC_CTCSS_NUM_FREQS, c.power, sizeof(c.power));
+            }
+            nev++;
+        }
+    }
+    return nev;
+}
+
+/* the literals handed to iirfilt_rrrf_create at src/sdr_pmr446.c:462-463 (tests/golden/deemph_ref.npz: what the reference's
+ * scripts/filter_des.py standard_deemph() returns) */
+void orc_deemph_iir_coefs(float b[2], float a[2])
+{
+    b[0] = 0.507301437230636; b[1] = 0.507301437230636;
+    a[0] = 1.0; a[1] = 0.014602874461272194;
+}
+
+void orc_dcblock_rrrf_run(const float *x, unsigned n, float alpha, float *y)
+{
+    orc_iirfilt_rrrf *f = orc_iirfilt_rrrf_create_dc_blocker(alpha);               /* :450 */
+    orc_iirfilt_rrrf_execute_block(f, (float *)x, n, y);                              /* :606 */
+    orc_iirfilt_rrrf_destroy(f);
+}
+
 /* reference src/sdr_pmr446.c:330-336 */
 static float average_power(const cf32 *data, size_t len)
 {
@@ -136,8 +173,8 @@ orc_chain *orc_chain_create(const orc_chain_cfg *cfg)
         if (cfg->deemph_fir) {
             c->deemph_fir = orc_firfilt_rrrf_create(q->cfg.deemph_taps, q->cfg.deemph_len);       /* :458 */
         } else {
-            float b[2] = {0.507301437230636, 0.507301437230636};                                  /* :462 */
-            float a[2] = {1.0, 0.014602874461272194};                                             /* :463 */
+            float b[2], a[2];
+            orc_deemph_iir_coefs(b, a);                                                           /* :462-463 */
             c->deemph_iir = orc_iirfilt_rrrf_create(b, 2, a, 2);
         }
     }

@@ -77,6 +77,10 @@ typedef struct {
 void       orc_chain_default_cfg(orc_chain_cfg *cfg);
 orc_chain *orc_chain_create(const orc_chain_cfg *cfg);
 int        orc_chain_reset(orc_chain *q);
+unsigned   orc_ctcss_detector_run(const float *xs, unsigned nx, double audio_rate, unsigned block, orc_ctcss_event *ev, unsigned cap,
+                                  float *powers /*nullable [cap][38]*/);
+void       orc_deemph_iir_coefs(float b[2], float a[2]);
+void       orc_dcblock_rrrf_run(const float *x, unsigned n, float alpha, float *y);
 int        orc_chain_reset_channel(orc_chain *q, unsigned channel);   /* freqdem_reset + ctcss_detector_reset, :866-867 */
 int        orc_chain_destroy(orc_chain *q);
 unsigned   orc_chain_max_frames(const orc_chain *q);

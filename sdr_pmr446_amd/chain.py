@@ -13,7 +13,7 @@ from . import build as _build
 PMR_OK, PMR_EINVAL, PMR_ERANGE, PMR_EHIP, PMR_ENOMEM = 0, 1, 2, 3, 4
 
 INFO_NUM_STAGES, INFO_M_STAGE, INFO_ARB_STEP, INFO_NCO_DTHETA, INFO_ARB_NPFB, INFO_ARB_M, INFO_PFB_P, INFO_CARRY_AT_LOAD = range(8)
-DESIGN_HALFBAND, DESIGN_ARB, DESIGN_PFB = range(3)
+DESIGN_HALFBAND, DESIGN_ARB, DESIGN_PFB, DESIGN_DEEMPH = range(4)
 DEBUG_RESAMPLED, DEBUG_FM, DEBUG_CTCSS_LP = range(3)
 
 #: every symbol include/pmr_chain.h declares

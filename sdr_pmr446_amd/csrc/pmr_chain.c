@@ -1989,6 +1989,11 @@ unsigned pmr_chain_design(pmr_chain q, int what, unsigned idx, float *out, unsig
         src = q->d.hb_proto[idx]; n = 4 * q->d.m_stage[idx] + 1; break;
     case PMR_DESIGN_ARB: src = q->d.arb_proto; n = 2 * PMR_ARB_M * PMR_ARB_NPFB + 1; break;
     case PMR_DESIGN_PFB: src = q->d.pfb_proto; n = 2 * q->M * q->d.pfb_m + 1; break;
+    case PMR_DESIGN_DEEMPH: {
+        const float de[3] = { q->d.de_b0, q->d.de_b1, q->d.de_a1 };
+        if (out) memcpy(out, de, (size_t)(cap < 3 ? cap : 3) * sizeof(float));
+        return 3;
+    }
     default: return 0;
     }
     if (out) memcpy(out, src, (size_t)(n < cap ? n : cap) * sizeof(float));

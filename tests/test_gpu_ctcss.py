@@ -106,3 +106,31 @@ def test_ctcss_decisions_around_the_thresholds():
             else:
                 near += 1
     assert seen[0] >= 4 and seen[1] >= 4, (seen, near)        # the sweep really straddles the avg > 120 threshold (252 Hz ~ 120)
+
+
+def test_ctcss_decisions_equal_the_references_own_detector_code():
+    """The HIP detector against decisions taken by the REFERENCE's ctcss_detector_analyze (src/sdr_pmr446.c:366-409, compiled from
+    the reference in the build container: tests/golden/ctcss_ref.npz, tools/make_ref_fixtures.py) on the same synthetic tone-level
+    sweep: tone index and decision identical wherever the reference's own margin to a threshold (:403-404) exceeds the 0.5 %
+    power tolerance, strongest-tone power within that tolerance."""
+    import os
+    from sdr_pmr446_amd import chain
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ctcss_ref.npz"))
+    fs, M, n = float(g["synth_fs"]), int(g["synth_M"]), int(g["synth_n"])
+    devs = list(g["synth_ctcss_devs"])
+    x = synth.synth_iq(n, fs, M, dev_hz=float(g["synth_dev_hz"]), ctcss_dev_of=lambda k: devs[k])
+    splits = [900000, 600001, 899999]
+    eg = _run(chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(splits)), x, splits)
+    B = g["index"].shape[1]
+    assert eg.shape == (M, B)
+    tol, seen = 5e-3, {0: 0, 1: 0}
+    for k in [k for k in active_channels(M) if synth.channel_kind(k) == "fm"]:
+        for b in range(1, B):                                 # (block 0 holds the start-up transient)
+            mx = float(g["max_power"][k, b])
+            avg = float(np.float32(g["power"][k, b].astype(np.float32).sum(dtype=np.float32) / np.float32(38)))
+            assert eg["max_power"][k, b] == pytest.approx(mx, rel=tol)
+            margin = min(abs(avg - 120.0) / 120.0, abs(mx / avg - 10.0) / 10.0)
+            if margin > 2 * tol:
+                assert eg["index"][k, b] == g["index"][k, b] and eg["detected"][k, b] == g["detected"][k, b], (k, b, avg, mx / avg)
+                seen[int(g["detected"][k, b])] += 1
+    assert seen[0] >= 4 and seen[1] >= 4, seen

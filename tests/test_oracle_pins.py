@@ -50,16 +50,7 @@ def test_tap_tables_are_the_documented_filters():
     assert abs(db[0]) < 0.2 and abs(db[1]) < 0.3 and db[2] < -60
 
 
-def test_deemphasis_coefficients_rederived():
-    # bilinear transform of 1/(1 + s tau) with pre-warping, tau = 50 us, fs = 12.5 kHz -- the formula of
-    # reference scripts/filter_des.py:31-44; the literals are at src/sdr_pmr446.c:462-463
-    tau, fs = 50e-6, 12500.0
-    wca = 2.0 * fs * math.tan((1.0 / tau) / (2.0 * fs))
-    k = -wca / (2.0 * fs)
-    p1 = (1.0 + k) / (1.0 - k)
-    b0 = -k / (1.0 - k)
-    assert b0 == pytest.approx(0.507301437230636, abs=1e-15)
-    assert -p1 == pytest.approx(0.014602874461272194, abs=1e-15)
+# (the de-emphasis coefficients: tests/test_ref_fixtures.py, against what the reference's scripts/filter_des.py returns)
 
 
 def test_buffer_sizing_asserts_of_the_reference():
