@@ -409,7 +409,8 @@ def main():
                     help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--ctcss", action="store_true", help="run with the CTCSS detector enabled (SURVEY s8 row f2) -- an A/B aid, "
-                                                         "not the headline workload")
+                                                         "not the headline workload (the one_open_channel sub-record then is "
+                                                         "the reference's mode: detector on the open channel only, :893)")
     args = ap.parse_args()
 
     from sdr_pmr446_amd import multigpu

@@ -180,7 +180,9 @@ int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes
 
 /* ---- CTCSS tone detection for every channel (complementary low-pass branch src/sdr_pmr446.c:884-889,
  * ctcss_execute :605-628, 38-tone Goertzel bank over 2441-sample blocks :366-409).  When enabled, every
- * process_block call also runs the detector; each Goertzel block completed by the call yields one event per channel. ---- */
+ * process_block call also runs the detector; each Goertzel block completed by the call yields one event per channel.  With a
+ * channel mask set the detector runs for the OPEN channels only (the reference calls ctcss_execute for the active channel, :893):
+ * events of closed channels read {index -1, detected 0}, and a channel's partial Goertzel sums restart when it is opened. ---- */
 typedef struct { int index;        /* strongest of the 38 tones (ctcss_freqs[index], :138-141)          */
                  int detected;     /* avg power > 120 && max/avg > 10 (:403-404)                         */
                  float max_power, avg_power; } pmr_ctcss_event;

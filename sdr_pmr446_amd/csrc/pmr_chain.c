@@ -37,7 +37,7 @@ static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcbloc
                                         "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
                                         "k_fir_tm<lp>", "k_frontend", "k_fe_carry",
                                         "k_channelize_small", "k_frontend<level2>", "k_fir_tm<ctcss_lp>",
-                                        "k_ct_dc_*", "k_ct_goertzel+final", "k_fe_tilefix", "k_spgram+finish" };
+                                        "k_ct_dc_* (unused)", "k_ct_seg_agg+scan, k_ct_goertzel+final", "k_fe_tilefix", "k_spgram+finish" };
 
 #define ZC_MAX_IN  (1u << 18)            /* zero-copy synchronous calls: samples (above this a copy engine + HBM-speed kernels win) */
 #define ZC_MAX_OUT (1u << 20)            /* ... and bytes of [rssi | pcm | audio] */
@@ -102,7 +102,7 @@ struct pmr_chain_s {
     /* CTCSS branch (pmr_ctcss.hip), allocated by pmr_chain_ctcss_enable */
     int ct_on; unsigned ct_max_ev, ct_nev_last; int ct_sel;
     float *d_ct_taps_ext;            /* the low-pass-branch taps zero-extended to the folded audio filter's length (dual pass) */
-    float *d_ctlp, *d_ct_taps, *d_ct_agg, *d_ct_W, *d_ct_dcstate, *d_ct_U, *d_ct_coef, *d_ct_part, *d_ct_carry[2];
+    float *d_ctlp, *d_ct_taps, *d_ct_lampow, *d_ct_agg, *d_ct_W, *d_ct_dcstate, *d_ct_U, *d_ct_coef, *d_ct_part, *d_ct_carry[2];
     pmr_ctcss_event *d_ct_events;
     unsigned hp_len_raw;             /* length of the un-folded high-pass table (377)                 */
 
@@ -756,7 +756,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_chan_x, q->d_chan_list, q->d_reset_flags, q->d_rssi_part, q->d_dbg_xr, q->d_dbg_fm, q->d_dbg_ct, q->d_fe_taps, q->d_fe_GA,
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
-                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_G12, q->d_fe_GAK, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
+                     q->d_fe_V[1], q->d_fe_V[2], q->d_fe_G12, q->d_fe_GAK, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_lampow, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events,
                      q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1 };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
@@ -1180,18 +1180,17 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
         if ((rc_ = ring_to_linear(q, q->d_dbg_ct, q->d_ctlp, q->fm_mask, (uint64_t)frame0, ns, (size_t)M * sizeof(float)))) return rc_;
     }
     const float a1 = -1.0f + 0.0005f;                              /* iirfilt_rrrf_create_dc_blocker(0.0005f), :450 */
-    const double lam = -(double)a1;
-    const unsigned nchunks = (ns + PMR_CT_CHUNK - 1) / PMR_CT_CHUNK, len_last = ns - (nchunks - 1) * PMR_CT_CHUNK;
-    LAUNCH(K_CT_DC, pmr_launch_ct_dc(q->stream, q->d_ctlp, q->fm_mask, frame0, ns, M, a1, (float)pow(lam, (double)PMR_CT_CHUNK),
-                                     (float)pow(lam, (double)len_last), q->d_ct_dcstate, q->d_ct_agg, q->d_ct_W));
+    /* the detector runs for the open channels only (the reference calls ctcss_execute for active_chan, :893): a closed channel's
+     * dc-blocker state stays as it was, its partial Goertzel sums restart from zero when it is opened again (:867) */
+    const unsigned *sel = q->mask_on ? q->d_chan_list : NULL;
     const uint64_t f0 = (uint64_t)frame0, f1 = f0 + ns;
     const unsigned nblk = (unsigned)((f1 - 1) / N - f0 / N + 1), ncomplete = (unsigned)(f1 / N - f0 / N);
     if (ncomplete > q->ct_max_ev) return fail(q, PMR_ERANGE, "ctcss events", hipSuccess);
     const int cur = q->ct_sel, nxt = cur ^ 1;
-    HIPCHK(hipMemsetAsync(q->d_ct_carry[nxt], 0, (size_t)M * PMR_CT_TONES * 2 * sizeof(float), q->stream), "ctcss");
-    LAUNCH(K_CT_GOERTZEL, pmr_launch_ct_goertzel(q->stream, q->d_ctlp, q->fm_mask, frame0, ns, M, N, q->d_ct_U, q->d_ct_coef,
-                                                 q->d_ct_part, q->d_ct_carry[cur], q->d_ct_carry[nxt], q->d_ct_events,
-                                                 nblk, ncomplete));
+    /* (k_ct_final writes every open channel's carry for the next call, zeros when the call ends on a block boundary) */
+    LAUNCH(K_CT_GOERTZEL, pmr_launch_ct_detector(q->stream, q->d_ctlp, q->fm_mask, frame0, ns, M, N, a1, q->d_ct_lampow, q->d_ct_dcstate,
+                                                 q->d_ct_agg, q->d_ct_W, q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[cur],
+                                                 q->d_ct_carry[nxt], q->d_ct_events, nblk, ncomplete, sel, q->n_enabled));
     q->ct_sel = nxt;
     q->ct_nev_last = ncomplete;
     return PMR_OK;
@@ -1314,8 +1313,14 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on)
         free(U);
         if (rc) return rc;
         if ((rc = dev_upload(q, &q->d_ct_coef, coef, PMR_CT_TONES))) return rc;
-        const size_t rows = (size_t)(q->fm_mask + 1), nch = q->chan_size / PMR_CT_CHUNK + 2;
         q->ct_max_ev = q->chan_size / N + 2;
+        const size_t rows = (size_t)(q->fm_mask + 1), nch = (size_t)(q->ct_max_ev + 1) * PMR_CT_SEG;     /* segments a call can touch */
+        {
+            float lp_[161];
+            const float a1_ = -1.0f + 0.0005f;                         /* iirfilt_rrrf_create_dc_blocker(0.0005f), :450 */
+            for (unsigned i = 0; i <= 160; i++) lp_[i] = (float)pow(-(double)a1_, (double)i);
+            if ((rc = dev_upload(q, &q->d_ct_lampow, lp_, 161))) return rc;
+        }
         if ((rc = dev_alloc(q, (void **)&q->d_ctlp, rows * M * sizeof(float)))) return rc;
         if ((rc = dev_alloc(q, (void **)&q->d_ct_agg, nch * M * sizeof(float)))) return rc;
         if ((rc = dev_alloc(q, (void **)&q->d_ct_W, nch * M * sizeof(float)))) return rc;
@@ -1345,7 +1350,12 @@ int pmr_chain_ctcss_read(pmr_chain q, pmr_ctcss_event *events, unsigned cap, uns
     if (!tmp) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
     hipError_t e = hipMemcpy(tmp, q->d_ct_events, (size_t)n * M * sizeof(*tmp), hipMemcpyDeviceToHost);
     if (e == hipSuccess)
-        for (unsigned b = 0; b < n; b++) for (unsigned k = 0; k < M; k++) events[(size_t)k * cap + b] = tmp[(size_t)b * M + k];
+        for (unsigned b = 0; b < n; b++) for (unsigned k = 0; k < M; k++) {
+            if (q->mask_on && !q->h_open[k]) {            /* closed channel: the detector did not run (index -1, nothing detected) */
+                const pmr_ctcss_event none = { -1, 0, 0.0f, 0.0f };
+                events[(size_t)k * cap + b] = none;
+            } else events[(size_t)k * cap + b] = tmp[(size_t)b * M + k];
+        }
     free(tmp);
     return e == hipSuccess ? PMR_OK : fail(q, PMR_EHIP, "ctcss D2H", e);
 }
@@ -1899,6 +1909,16 @@ int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned
     /* the list is read by kernels of calls already queued: let them finish before it changes */
     hipError_t e = hipStreamSynchronize(q->stream);
     if (e == hipSuccess && n) e = hipMemcpy(q->d_chan_list, list, (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (e == hipSuccess && q->d_ct_carry[0]) {
+        /* ctcss_detector_reset of the channels that open now (:867): their partial Goertzel sums were frozen while closed */
+        for (unsigned i = 0; i < n && e == hipSuccess; i++) {
+            if (q->h_open[list[i]] && q->mask_on) continue;                /* was open already */
+            if (!q->mask_on) break;                                        /* every channel was running */
+            for (int b = 0; b < 2 && e == hipSuccess; b++)
+                e = hipMemset((char *)q->d_ct_carry[b] + (size_t)list[i] * PMR_CT_TONES * 2 * sizeof(float), 0,
+                              (size_t)PMR_CT_TONES * 2 * sizeof(float));
+        }
+    }
     if (e == hipSuccess) {
         memset(q->h_open, 0, M);
         for (unsigned i = 0; i < n; i++) q->h_open[list[i]] = 1;

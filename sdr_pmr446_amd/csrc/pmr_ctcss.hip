@@ -7,61 +7,103 @@
 // GPU formulation (everything per channel is linear, so time can be cut into pieces):
 //  * the low-pass branch is ONE FIR with taps delta[d-188] - h[d]: the audio FIR kernel (pmr_fir_mfma.hip /
 //    k_fir_pair) run a second time on the discriminator ring, writing a time-major ring (done by the host);
-//  * the dc-blocker v0 = x - a1 v1, y = v0 - v1 is a first-order linear scan: 64-frame chunks run from zero state
-//    (k_ct_dc_agg), a workgroup per channel strings the chunk aggregates together with a parallel scan of affine maps
-//    (k_ct_dc_scan), k_ct_dc_apply redoes each chunk from its true carry, in place;
+//  * the dc-blocker v0 = x - a1 v1, y = v0 - v1 is a first-order linear scan, cut on the SAME segment grid as the Goertzel bank:
+//    zero-state aggregates of every (segment, channel) (k_ct_seg_agg), a workgroup per channel strings them together with a
+//    parallel scan of affine maps (k_ct_seg_scan), and the Goertzel kernel applies the exact recurrence to the segment it has
+//    staged in LDS, from the segment's true carry -- no pass that rewrites the low-pass branch in memory, no latency-bound
+//    serial loops (round 2's chunk scan walked 22 dependent loads per thread: 0.05 ms whatever the channel count);
 //  * the Goertzel recurrence u0' = x + coef u0 - u1 has the impulse response U_n = sin((n+1)w)/sin(w), so after the N
 //    samples of a block  u0 = sum_i x_i U_{N-1-i},  u1 = sum_i x_i U_{N-2-i}: a weighted sum that is split over 16 time
 //    segments x 38 tones x M channels (k_ct_goertzel: LDS-tiled [16 channels] x [frames] . [frames] x [38 tones]) and reduced in a fixed order (k_ct_final), which also carries
 //    the partial sums of a block that straddles two calls.  U is tabulated in double on the host.
+//  * open-channel mask (the reference runs ctcss_execute for the squelch-selected channel only, :893): every kernel takes the
+//    list of enabled channels (chan_list / n_chan; NULL = all M) and touches those channels only -- work, launch sizes and the
+//    state that advances (dc-blocker state, Goertzel carry) are per OPEN channel; a closed channel's state stays as it was.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "pmr_kernels.h"
 
-#define CT_CHUNK PMR_CT_CHUNK            /* frames per dc-scan chunk */
-
-// chunk aggregates of the dc blocker from zero state: agg[c][k] = sum_i lam^(len-1-i) x[t0 + i][k].  The loads of a batch are all
-// issued before the dependent fma chain consumes them (a run-time-bounded loop pays the L2 latency once per sample).
-__global__ __launch_bounds__(256) void k_ct_dc_agg(const float *__restrict__ lp, unsigned long long row_mask,
-                                                   long long row0, unsigned ns, unsigned M, unsigned log2M, float lam,
-                                                   float *__restrict__ agg, unsigned nchunks)
+// Segment grid shared by the dc-blocker scan and the Goertzel bank: block b = frames [b N, (b+1) N), cut into PMR_CT_SEG segments
+// of SL = ceil(N / SEG) frames (the last one shorter); a call covers the segments that overlap [row0, row0 + ns), clipped.
+struct ct_seg { long long lo; int len; unsigned n0; };             // first frame, frames inside the call, position inside the block
+static __device__ __forceinline__ ct_seg ct_segment(long long b, unsigned seg, unsigned N, unsigned SL, long long row0, unsigned ns)
 {
-    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
-    const unsigned k = gid & (M - 1), c = gid >> log2M;
-    if (c >= nchunks) return;
-    const unsigned t0 = c * CT_CHUNK, len = min((unsigned)CT_CHUNK, ns - t0);
-    float v = 0.f;
-    for (unsigned i0 = 0; i0 < len; i0 += 16) {
-        float x[16];
-#pragma unroll
-        for (unsigned u = 0; u < 16; u++)
-            x[u] = i0 + u < len ? lp[((unsigned long long)(row0 + t0 + i0 + u) & row_mask) * M + k] : 0.f;
-#pragma unroll
-        for (unsigned u = 0; u < 16; u++) if (i0 + u < len) v = fmaf(lam, v, x[u]);
-    }
-    agg[(size_t)c * M + k] = v;
+    long long lo = b * (long long)N + (long long)seg * SL, hi = lo + SL;
+    const long long bend = (b + 1) * (long long)N;
+    if (hi > bend) hi = bend;
+    if (lo < row0) lo = row0;                                      // frames of earlier calls are in the carried state
+    if (hi > row0 + (long long)ns) hi = row0 + (long long)ns;
+    ct_seg r;
+    r.len = hi > lo ? (int)(hi - lo) : 0;
+    r.lo = lo;
+    r.n0 = r.len ? (unsigned)(lo - b * (long long)N) : 0;
+    return r;
 }
 
-// dc-blocker state just before every chunk: a first-order linear scan over the chunk aggregates, one WORKGROUP per channel
-// (a thread walks a contiguous run of chunks; the runs are strung together by a Hillis-Steele scan of (multiplier, value) pairs)
-__global__ __launch_bounds__(256) void k_ct_dc_scan(const float *__restrict__ agg, unsigned nchunks, unsigned M,
-                                                    float lam_chunk, float lam_last, float *__restrict__ state,
-                                                    float *__restrict__ W)
+// dc blocker of ctcss_execute (:606), pass 1: the zero-state aggregate of every (segment, channel),
+//   agg = sum_i lam^(len-1-i) x[lo + i].  A workgroup = one segment x 16 channel slots x 16 time slices of CT_SUB frames: a thread's
+// loads are all in flight before its fma chain runs, the 16 slices of a channel are strung together through LDS.
+#define CT_SUB 10                                                  /* 16 x 10 >= SL = 153 */
+__global__ __launch_bounds__(256) void k_ct_seg_agg(const float *__restrict__ lp, unsigned long long row_mask, long long row0,
+                                                    unsigned ns, unsigned M, unsigned N, float lam,
+                                                    const float *__restrict__ lampow /*[SL + 1] lam^n*/, float *__restrict__ agg,
+                                                    long long b0, const unsigned *__restrict__ chan_list, unsigned n_chan)
+{
+    __shared__ float sv[16][17];
+    __shared__ int sl_len[16];
+    const unsigned SL = (N + PMR_CT_SEG - 1) / PMR_CT_SEG;
+    const unsigned g = blockIdx.x, blk = g / PMR_CT_SEG, seg = g % PMR_CT_SEG;
+    const ct_seg sg = ct_segment(b0 + blk, seg, N, SL, row0, ns);
+    const unsigned tid = threadIdx.x, sl = tid & 15u, ss = tid >> 4, ci = blockIdx.y * 16u + sl;
+    const unsigned k = ci < n_chan ? (chan_list ? chan_list[ci] : ci) : 0u;
+    const int i0 = (int)ss * CT_SUB, len = sg.len - i0 < 0 ? 0 : (sg.len - i0 > CT_SUB ? CT_SUB : sg.len - i0);
+    float x[CT_SUB];
+#pragma unroll
+    for (int u = 0; u < CT_SUB; u++)
+        x[u] = (u < len && ci < n_chan) ? lp[((unsigned long long)(sg.lo + i0 + u) & row_mask) * M + k] : 0.f;
+    float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < CT_SUB; u++) if (u < len) v = fmaf(lam, v, x[u]);
+    sv[ss][sl] = v;
+    if (sl == 0) sl_len[ss] = len;
+    __syncthreads();
+    if (ss == 0 && ci < n_chan) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) a = fmaf(lampow[sl_len[q]], a, sv[q][sl]);
+        agg[(size_t)g * M + k] = a;
+    }
+}
+
+// pass 2: the blocker's state just before every segment -- a first-order linear scan over the segment aggregates, one WORKGROUP per
+// open channel: the aggregates are fetched in one batch, a thread walks a contiguous run of segments, the runs are strung together
+// by a Hillis-Steele scan of (multiplier, value) pairs.  Leaves the state after the call's last frame in state[k].
+#define CT_PER 24                                                  /* segments per thread: 256 x 24 = 6144 segments = 384 Goertzel blocks per call */
+__global__ __launch_bounds__(256) void k_ct_seg_scan(const float *__restrict__ agg, unsigned nseg, unsigned M, unsigned N,
+                                                     long long row0, unsigned ns, long long b0,
+                                                     const float *__restrict__ lampow, float *__restrict__ state,
+                                                     float *__restrict__ W, const unsigned *__restrict__ chan_list)
 {
     __shared__ float sP[256], sA[256];
-    const unsigned k = blockIdx.x, t = threadIdx.x;
-    const unsigned per = (nchunks + 255u) / 256u, c0 = t * per, c1 = min(nchunks, c0 + per);
-    float P = 1.f, A = 0.f;                                    // run from zero state: v_out = P v_in + A
-    for (unsigned c = c0; c < c1; c++) {
-        const float l = c + 1 == nchunks ? lam_last : lam_chunk;
-        A = fmaf(l, A, agg[(size_t)c * M + k]);
-        P *= l;
+    const unsigned SL = (N + PMR_CT_SEG - 1) / PMR_CT_SEG;
+    const unsigned k = chan_list ? chan_list[blockIdx.x] : blockIdx.x, t = threadIdx.x;
+    const unsigned per = (nseg + 255u) / 256u, c0 = t * per;       // per <= CT_PER (launcher)
+    float a[CT_PER], l[CT_PER];
+#pragma unroll
+    for (unsigned u = 0; u < CT_PER; u++) {
+        const unsigned g = c0 + u;
+        const bool in = u < per && g < nseg;
+        a[u] = in ? agg[(size_t)g * M + k] : 0.f;
+        l[u] = in ? lampow[ct_segment(b0 + g / PMR_CT_SEG, g % PMR_CT_SEG, N, SL, row0, ns).len] : 1.f;
     }
+    float P = 1.f, A = 0.f;                                        // run from zero state: v_out = P v_in + A
+#pragma unroll
+    for (unsigned u = 0; u < CT_PER; u++) { A = fmaf(l[u], A, a[u]); P *= l[u]; }
     sP[t] = P; sA[t] = A;
     __syncthreads();
 #pragma unroll
-    for (unsigned d = 1; d < 256; d <<= 1) {                   // inclusive scan of the affine maps
+    for (unsigned d = 1; d < 256; d <<= 1) {                       // inclusive scan of the affine maps
         float p2 = 1.f, a2 = 0.f;
         if (t >= d) { p2 = sP[t - d]; a2 = sA[t - d]; }
         __syncthreads();
@@ -69,98 +111,179 @@ __global__ __launch_bounds__(256) void k_ct_dc_scan(const float *__restrict__ ag
         __syncthreads();
     }
     const float s0 = state[k];
-    float v = t == 0 ? s0 : fmaf(sP[t - 1], s0, sA[t - 1]);    // state before this thread's run
-    for (unsigned c = c0; c < c1; c++) {
-        W[(size_t)c * M + k] = v;
-        v = fmaf(c + 1 == nchunks ? lam_last : lam_chunk, v, agg[(size_t)c * M + k]);
+    float v = t == 0 ? s0 : fmaf(sP[t - 1], s0, sA[t - 1]);        // state before this thread's run
+#pragma unroll
+    for (unsigned u = 0; u < CT_PER; u++) {
+        const unsigned g = c0 + u;
+        if (u < per && g < nseg) { W[(size_t)g * M + k] = v; v = fmaf(l[u], v, a[u]); }
     }
     if (t == 255) state[k] = fmaf(sP[255], s0, sA[255]);
 }
 
-__global__ __launch_bounds__(256) void k_ct_dc_apply(float *__restrict__ lp, unsigned long long row_mask,
-                                                     long long row0, unsigned ns, unsigned M, unsigned log2M, float a1,
-                                                     const float *__restrict__ W, unsigned nchunks)
-{
-    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
-    const unsigned k = gid & (M - 1), c = gid >> log2M;
-    if (c >= nchunks) return;
-    const unsigned t0 = c * CT_CHUNK, len = min((unsigned)CT_CHUNK, ns - t0);
-    float v1 = W[(size_t)c * M + k];
-    for (unsigned i0 = 0; i0 < len; i0 += 16) {
-        float x[16];
-#pragma unroll
-        for (unsigned u = 0; u < 16; u++)
-            x[u] = i0 + u < len ? lp[((unsigned long long)(row0 + t0 + i0 + u) & row_mask) * M + k] : 0.f;
-#pragma unroll
-        for (unsigned u = 0; u < 16; u++) {
-            if (i0 + u < len) {
-                const float v0 = __fsub_rn(x[u], __fmul_rn(a1, v1));    // iirfilt_rrrf dc blocker, :606
-                lp[((unsigned long long)(row0 + t0 + i0 + u) & row_mask) * M + k] = __fsub_rn(v0, v1);
-                v1 = v0;
-            }
-        }
-    }
-}
-
-// partial Goertzel sums of one (block, segment, group of 16 channels): part[(blk*CT_SEG + seg)][k][j][2].
-// A block is the product  [channels] x [frames] . [frames] x [38 tones x 2]  with the weights U: the segment's samples (16
-// channels) and the matching window of U (38 tones) are staged in LDS once; a thread owns one tone and FOUR channels, so an
-// iteration is one ds_read_b128 of samples (broadcast among the threads of a quad) + one weight for eight FMAs.
-#define CG_T 192                                                   /* threads: 38 tones x 4 channel quads = 152 active */
+// partial Goertzel sums of one (block, segment, group of 16 channel slots): part[(blk*CT_SEG + seg)][k][j][2].
+// A segment is the product  [16 channels] x [frames] . [frames] x [38 tones x (u0, u1)]  with the weights U, k-ordered oldest
+// frame first like the recurrence -- a small GEMM, so it runs on the matrix pipe: v_mfma_f32_16x16x4_f32 with
+//   A[i][kappa] = x[frame 4 s + kappa][slot i]          (64 consecutive floats of the staged, dc-blocked segment per step)
+//   B[kappa][c] = U-weight of frame 4 s + kappa for column c = 2 tone + (0: u0, 1: u1), five 16-column tiles (76 columns used)
+// exact f32, sequential in kappa: the sums are those of the scalar loop this replaces.  A workgroup (3 waves: column tiles 0/3,
+// 1/4, 2) walks the same segment position of CG_NB consecutive blocks: the window of U depends on the position inside the block
+// only, so it is staged once per workgroup.
+#define CG_T 192
+#define CG_NB 1                                                    /* blocks per workgroup */
+#define CG_ROWS 156                                                /* staged rows: SL = 153 rounded up to the MFMA's k step */
+typedef float ct_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ lp, unsigned long long row_mask,
                                                      long long row0, unsigned ns, unsigned M, unsigned N,
                                                      const float *__restrict__ U /*[38][N+1], U[j][m+1] = U_m*/,
-                                                     float *__restrict__ part, long long b0)
+                                                     float *__restrict__ part, long long b0, unsigned nblk,
+                                                     const unsigned *__restrict__ chan_list, unsigned n_chan,
+                                                     const float *__restrict__ W /*[segments][M] blocker state before each segment*/,
+                                                     float dc_a1, const float *__restrict__ lampow)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
-    const unsigned SL = (N + PMR_CT_SEG - 1) / PMR_CT_SEG;         // frames per segment
-    float *xs = reinterpret_cast<float *>(smem_c);                 // [SL][16]
-    float *us = xs + (size_t)SL * 16;                              // [38][SL + 2] (odd-ish stride: conflict-free over the tones)
+    const unsigned SL = (N + PMR_CT_SEG - 1) / PMR_CT_SEG;         // frames per segment (<= 153)
+    float *xs = reinterpret_cast<float *>(smem_c);                 // [CG_ROWS][16], rows beyond the segment zero
+    float *us = xs + (size_t)CG_ROWS * 16;                         // [38][US]: us[j][m] = U[j][N - e + m], e = segment end inside the block
     const unsigned US = SL + 2 + ((SL & 1) ? 0 : 1);               // row stride of us, odd
-    const unsigned tid = threadIdx.x;
-    const unsigned bs = blockIdx.x, blk = bs / PMR_CT_SEG, seg = bs % PMR_CT_SEG, cg = blockIdx.y * 16u;
-    const long long b = b0 + blk;
-    long long lo = b * (long long)N + (long long)seg * SL, hi = lo + SL;
-    const long long bend = (b + 1) * (long long)N;
-    if (hi > bend) hi = bend;
-    if (lo < row0) lo = row0;                                      // frames of earlier calls are in the carry
-    if (hi > row0 + (long long)ns) hi = row0 + (long long)ns;
-    const int len = hi > lo ? (int)(hi - lo) : 0;
-    const unsigned n0 = len ? (unsigned)(lo - b * (long long)N) : 0;   // position of the first sample inside the block
-    for (int i = tid; i < len * 4; i += CG_T) {                    // samples: 64 bytes per frame
-        const int r = i >> 2, q4 = (i & 3) * 4;
-        const float *src = lp + ((unsigned long long)(lo + r) & row_mask) * M + cg + q4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cg + q4 + 4 <= M) v = *reinterpret_cast<const float4 *>(src);                 // M >= 4 is a power of two
-        else if (cg + q4 < M) { v.x = src[0]; if (cg + q4 + 1 < M) v.y = src[1]; }           // M = 2
-        *reinterpret_cast<float4 *>(xs + r * 16 + q4) = v;
-    }
-    // weights: sample n of the block meets U[N - n] (-> u0) and U[N - 1 - n] (-> u1); window = U[N - n0 - len .. N - n0]
-    for (int i = tid; i < (int)PMR_CT_TONES * (len + 1); i += CG_T) {
-        const int j = i / (len + 1), m = i % (len + 1);
-        us[j * US + m] = U[(size_t)j * (N + 1) + (N - n0 - len) + m];
-    }
-    __syncthreads();
-    const unsigned j = tid >> 2, kq = tid & 3u;
-    if (j >= PMR_CT_TONES) return;
-    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-    const float *uj = us + j * US;
-    if (len) {
-        float u_hi = uj[len];                                      // U[N - n0]: weight of the first sample in u0
-        for (int r = 0; r < len; r++) {
-            const float u_lo = uj[len - 1 - r];                    // U[N - 1 - n]
-            const float4 x = *reinterpret_cast<const float4 *>(xs + r * 16 + 4 * kq);
-            a0[0] = fmaf(x.x, u_hi, a0[0]); a0[1] = fmaf(x.y, u_hi, a0[1]); a0[2] = fmaf(x.z, u_hi, a0[2]); a0[3] = fmaf(x.w, u_hi, a0[3]);
-            a1[0] = fmaf(x.x, u_lo, a1[0]); a1[1] = fmaf(x.y, u_lo, a1[1]); a1[2] = fmaf(x.z, u_lo, a1[2]); a1[3] = fmaf(x.w, u_lo, a1[3]);
-            u_hi = u_lo;
+    float *sagg = us + (size_t)PMR_CT_TONES * US;                  // [12][16]
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned seg = blockIdx.x % PMR_CT_SEG, blk0 = (blockIdx.x / PMR_CT_SEG) * CG_NB, cg = blockIdx.y * 16u;   // cg: first of 16 channel SLOTS
+    const unsigned e_pos = min(N, (seg + 1) * SL), s_pos = seg * SL;     // the FULL segment inside a block: [s_pos, e_pos)
+    __shared__ float s_lam[16];                                    // lambda^n, n <= 13 (a table read inside the serial carry loop below
+    if (tid < 16) s_lam[tid] = lampow[tid];                        //  must not be a global load per step)
+    // ---- U window of the full segment, once: weight of block position p is us[j][e_pos - p] (-> u0) and us[j][e_pos - p - 1] (-> u1) ----
+    {
+        // every load of the thread is in flight before the first is stored (a run-time-bounded loop pays the L2 latency per element)
+        constexpr int NJ = (PMR_CT_TONES + CG_T / 64 - 1) / (CG_T / 64), NM = (CG_ROWS + 1 + 63) / 64;
+        float uv[NJ][NM];
+        const unsigned wlen = e_pos - s_pos;
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) {
+            const unsigned j = wave + (CG_T / 64) * jj;
+#pragma unroll
+            for (int mm = 0; mm < NM; mm++) {
+                const unsigned m = lane + 64u * mm;
+                uv[jj][mm] = (j < PMR_CT_TONES && m <= wlen) ? U[(size_t)j * (N + 1) + (N - e_pos) + m] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < NJ; jj++) {
+            const unsigned j = wave + (CG_T / 64) * jj;
+#pragma unroll
+            for (int mm = 0; mm < NM; mm++) {
+                const unsigned m = lane + 64u * mm;
+                if (j < PMR_CT_TONES && m <= wlen) us[j * US + m] = uv[jj][mm];
+            }
         }
     }
+
+    for (unsigned bi = 0; bi < CG_NB && blk0 + bi < nblk; bi++) {
+        const unsigned blk = blk0 + bi, gseg = blk * PMR_CT_SEG + seg;
+        const ct_seg sg = ct_segment(b0 + blk, seg, N, SL, row0, ns);
+        const long long lo = sg.lo;
+        const int len = sg.len;
+        __syncthreads();                                           // the previous block's readers are done (and us is complete)
+        if (chan_list) {                                           // open channels only: slot s of this workgroup = chan_list[cg + s]
+            for (int i = tid; i < CG_ROWS * 16; i += CG_T) {
+                const int r = i >> 4, sl = i & 15;
+                xs[i] = (r < len && cg + sl < n_chan) ? lp[((unsigned long long)(lo + r) & row_mask) * M + chan_list[cg + sl]] : 0.f;
+            }
+        } else {
+            constexpr int NX = (CG_ROWS * 4 + CG_T - 1) / CG_T;    // samples: 64 bytes per frame; all loads first
+            float4 xv[NX];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const unsigned k = cg + 4 * kq + q;
-        if (k >= M) break;
-        float *o = part + (((size_t)blk * PMR_CT_SEG + seg) * M + k) * PMR_CT_TONES * 2 + 2 * j;
-        o[0] = a0[q]; o[1] = a1[q];
+            for (int u = 0; u < NX; u++) {
+                const int i = tid + CG_T * u, r = i >> 2, q4 = (i & 3) * 4;
+                const float *src = lp + ((unsigned long long)(lo + r) & row_mask) * M + cg + q4;
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < len) {
+                    if (cg + q4 + 4 <= M) xv[u] = *reinterpret_cast<const float4 *>(src);         // M >= 4 is a power of two
+                    else if (cg + q4 < M) { xv[u].x = src[0]; if (cg + q4 + 1 < M) xv[u].y = src[1]; }   // M = 2
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NX; u++) {
+                const int i = tid + CG_T * u, r = i >> 2, q4 = (i & 3) * 4;
+                if (i < CG_ROWS * 4) *reinterpret_cast<float4 *>(xs + r * 16 + q4) = xv[u];
+            }
+        }
+        __syncthreads();
+        // ---- dc blocker of ctcss_execute (:606), pass 3, on the staged samples in place: thread (slot, slice of CT_SUBG frames)
+        // strings the zero-state aggregates of the slices before its own onto the segment's carried state W, then runs the exact
+        // recurrence v0 = x - a1 v1, y = v0 - v1 (liquid's iirfilt_rrrf, individually rounded) over its slice ----
+        {
+            constexpr int CT_SUBG = 13;                            // 12 slices x 13 >= SL = 153; CG_T = 12 x 16 threads
+            const unsigned sl = tid & 15u, ss = tid >> 4;
+            const int i0 = (int)ss * CT_SUBG, ln = len - i0 < 0 ? 0 : (len - i0 > CT_SUBG ? CT_SUBG : len - i0);
+            const float lam = -dc_a1;
+            float x[CT_SUBG];
+#pragma unroll
+            for (int u = 0; u < CT_SUBG; u++) x[u] = u < ln ? xs[(i0 + u) * 16 + sl] : 0.f;
+            float v = 0.f;
+#pragma unroll
+            for (int u = 0; u < CT_SUBG; u++) if (u < ln) v = fmaf(lam, v, x[u]);
+            sagg[ss * 16 + sl] = v;
+            __syncthreads();
+            const unsigned ci = cg + sl;
+            const unsigned kc = ci < n_chan ? (chan_list ? chan_list[ci] : ci) : 0u;
+            float v1 = ci < n_chan ? W[(size_t)gseg * M + kc] : 0.f;
+            for (unsigned q = 0; q < ss; q++) {
+                const int lq = len - (int)q * CT_SUBG;
+                v1 = fmaf(s_lam[lq < 0 ? 0 : (lq > CT_SUBG ? CT_SUBG : lq)], v1, sagg[q * 16 + sl]);
+            }
+#pragma unroll
+            for (int u = 0; u < CT_SUBG; u++) {
+                if (u < ln) {
+                    const float v0 = __fsub_rn(x[u], __fmul_rn(dc_a1, v1));
+                    xs[(i0 + u) * 16 + sl] = __fsub_rn(v0, v1);
+                    v1 = v0;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- the Goertzel sums on the matrix pipe.  Row r of the staged segment sits at block position p = n0 + r ----
+        {
+            const int col = lane & 15, kk = lane >> 4;
+            const int d0 = (int)e_pos - (int)sg.n0;                // us index of row r, column (tone, which): d0 - r - which
+            ct_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const int nct = wave < 2 ? 2 : 1;                      // column tiles of this wave: wave, wave + 3
+            const float *ub[2];
+            int ui[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int c = 16 * ((int)wave + 3 * t) + col, jt = c >> 1;              // column -> (tone, which); columns >= 76: tone 37 again, never stored
+                ub[t] = us + (size_t)(jt < (int)PMR_CT_TONES ? jt : (int)PMR_CT_TONES - 1) * US;
+                ui[t] = d0 - (c & 1) - kk;
+            }
+            const float *xa = xs + lane;                           // step s: xa[64 s]
+            const int nst = (len + 3) >> 2;
+            for (int st = 0; st < nst; st++) {
+                const float a = xa[64 * st];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    if (t < nct) {
+                        const int ix = ui[t] - 4 * st;
+                        const float b = ub[t][ix < 0 ? 0 : ix];    // rows beyond the segment are zero in xs: any finite weight does
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            // D: lane holds column `col` of its tile, register q = channel slot 4 kk + q
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int c = 16 * ((int)wave + 3 * t) + col;
+                if (t < nct && c < 2 * (int)PMR_CT_TONES) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const unsigned sl = cg + 4 * kk + qq;
+                        if (sl < n_chan) {
+                            const unsigned k = chan_list ? chan_list[sl] : sl;
+                            part[((size_t)gseg * M + k) * PMR_CT_TONES * 2 + c] = acc[t][qq];
+                        }
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -169,10 +292,12 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
 __global__ __launch_bounds__(64) void k_ct_final(const float *__restrict__ part, unsigned nblk, unsigned ncomplete,
                                                  unsigned M, const float *__restrict__ coef,
                                                  const float *__restrict__ carry_in, float *__restrict__ carry_out,
-                                                 pmr_ctcss_event *__restrict__ events)
+                                                 pmr_ctcss_event *__restrict__ events,
+                                                 const unsigned *__restrict__ chan_list, unsigned n_chan)
 {
     __shared__ float spw[PMR_CT_TONES];
-    const unsigned k = blockIdx.x % M, blk = blockIdx.x / M, j = threadIdx.x;
+    const unsigned ci = blockIdx.x % n_chan, blk = blockIdx.x / n_chan, j = threadIdx.x;
+    const unsigned k = chan_list ? chan_list[ci] : ci;
     const bool complete = blk < ncomplete;
     if (j < PMR_CT_TONES) {
         float u0 = 0.f, u1 = 0.f;
@@ -184,9 +309,9 @@ __global__ __launch_bounds__(64) void k_ct_final(const float *__restrict__ part,
 #pragma unroll
         for (unsigned s = 0; s < PMR_CT_SEG; s++) { u0 += pv[s].x; u1 += pv[s].y; }
         if (complete) spw[j] = (u0 * u0) + (u1 * u1) - (coef[j] * u0 * u1);
-        else {
-            carry_out[((size_t)k * PMR_CT_TONES + j) * 2] = u0;
-            carry_out[((size_t)k * PMR_CT_TONES + j) * 2 + 1] = u1;
+        if (blk + 1 == nblk) {                                     // partial sums of the block in progress (none: zeros) for the next call
+            carry_out[((size_t)k * PMR_CT_TONES + j) * 2] = complete ? 0.f : u0;
+            carry_out[((size_t)k * PMR_CT_TONES + j) * 2 + 1] = complete ? 0.f : u1;
         }
     }
     __syncthreads();
@@ -206,34 +331,28 @@ __global__ __launch_bounds__(64) void k_ct_final(const float *__restrict__ part,
     }
 }
 
-static inline unsigned ilog2u(unsigned v) { unsigned l = 0; while ((1u << l) < v) l++; return l; }
-
-extern "C" int pmr_launch_ct_dc(pmr_stream_t s, float *lp, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
-                                float a1, float lam_chunk, float lam_last, float *state, float *agg, float *W)
-{
-    if (!ns) return 0;
-    const unsigned nchunks = (ns + CT_CHUNK - 1) / CT_CHUNK;
-    const size_t threads = (size_t)nchunks * M;
-    hipLaunchKernelGGL(k_ct_dc_agg, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, lp,
-                       (unsigned long long)row_mask, (long long)row0, ns, M, ilog2u(M), -a1, agg, nchunks);
-    hipLaunchKernelGGL(k_ct_dc_scan, dim3(M), dim3(256), 0, (hipStream_t)s, agg, nchunks, M, lam_chunk, lam_last, state, W);
-    hipLaunchKernelGGL(k_ct_dc_apply, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, lp,
-                       (unsigned long long)row_mask, (long long)row0, ns, M, ilog2u(M), a1, W, nchunks);
-    return (int)hipGetLastError();
-}
-
-extern "C" int pmr_launch_ct_goertzel(pmr_stream_t s, const float *lp, uint64_t row_mask, int64_t row0, unsigned ns,
-                                      unsigned M, unsigned N, const float *U, const float *coef, float *part,
+extern "C" int pmr_launch_ct_detector(pmr_stream_t s, const float *lp, uint64_t row_mask, int64_t row0, unsigned ns,
+                                      unsigned M, unsigned N, float a1, const float *lampow, float *state, float *agg, float *W,
+                                      const float *U, const float *coef, float *part,
                                       const float *carry_in, float *carry_out, pmr_ctcss_event *events,
-                                      unsigned nblk, unsigned ncomplete)
+                                      unsigned nblk, unsigned ncomplete, const unsigned *chan_list, unsigned n_chan)
 {
-    if (!ns || !nblk) return 0;
+    const unsigned nc = chan_list ? n_chan : M;
+    if (!ns || !nblk || !nc) return 0;
     const long long b0 = row0 / (long long)N;
+    const unsigned nseg = nblk * PMR_CT_SEG;
+    if (nseg > 256u * CT_PER) return (int)hipErrorInvalidValue;
     const unsigned SL = (N + PMR_CT_SEG - 1) / PMR_CT_SEG, US = SL + 2 + ((SL & 1) ? 0 : 1);
-    const size_t lds = ((size_t)SL * 16 + (size_t)PMR_CT_TONES * US) * sizeof(float);
-    hipLaunchKernelGGL(k_ct_goertzel, dim3(nblk * PMR_CT_SEG, (M + 15) / 16), dim3(CG_T), lds, (hipStream_t)s, lp,
-                       (unsigned long long)row_mask, (long long)row0, ns, M, N, U, part, b0);
-    hipLaunchKernelGGL(k_ct_final, dim3(nblk * M), dim3(64), 0, (hipStream_t)s, part, nblk, ncomplete, M,
-                       coef, carry_in, carry_out, events);
+    if (SL > 16 * CT_SUB || SL > 12 * 13 || SL > CG_ROWS) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)s;
+    const unsigned long long rm = (unsigned long long)row_mask;
+    hipLaunchKernelGGL(k_ct_seg_agg, dim3(nseg, (nc + 15) / 16), dim3(256), 0, st, lp, rm, (long long)row0, ns, M, N, -a1, lampow, agg,
+                       b0, chan_list, nc);
+    hipLaunchKernelGGL(k_ct_seg_scan, dim3(nc), dim3(256), 0, st, agg, nseg, M, N, (long long)row0, ns, b0, lampow, state, W, chan_list);
+    const size_t lds = ((size_t)CG_ROWS * 16 + (size_t)PMR_CT_TONES * US + 12 * 16) * sizeof(float);
+    hipLaunchKernelGGL(k_ct_goertzel, dim3(((nblk + CG_NB - 1) / CG_NB) * PMR_CT_SEG, (nc + 15) / 16), dim3(CG_T), lds, st, lp, rm,
+                       (long long)row0, ns, M, N, U, part, b0, nblk, chan_list, nc, W, a1, lampow);
+    hipLaunchKernelGGL(k_ct_final, dim3(nblk * nc), dim3(64), 0, st, part, nblk, ncomplete, M, coef, carry_in, carry_out, events,
+                       chan_list, nc);
     return (int)hipGetLastError();
 }

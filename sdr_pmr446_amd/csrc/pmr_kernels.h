@@ -178,13 +178,15 @@ int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in,
 /* ---- CTCSS branch (pmr_ctcss.hip) ---- */
 #define PMR_CT_TONES 38u
 #define PMR_CT_SEG 16u          /* time segments a Goertzel block is split into */
-#define PMR_CT_CHUNK 64u        /* frames per chunk of the CTCSS branch's dc-blocker scan */
 #define PMR_CT_BLOCK 2441u      /* CTCSS_BLOCK_SIZE, src/sdr_pmr446.c:37,:46 */
-int pmr_launch_ct_dc(pmr_stream_t s, float *lp, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M, float a1,
-                     float lam_chunk, float lam_last, float *state, float *agg, float *W);
-int pmr_launch_ct_goertzel(pmr_stream_t s, const float *lp, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
-                           unsigned N, const float *U, const float *coef, float *part, const float *carry_in,
-                           float *carry_out, pmr_ctcss_event *events, unsigned nblk, unsigned ncomplete);
+/* the whole detector behind the low-pass branch `lp` (time-major ring, NOT modified): dc blocker of ctcss_execute (:606) as a
+ * scan on the Goertzel segment grid, 38-tone Goertzel bank over N-frame blocks, decision (:366-409).  chan_list / n_chan: the
+ * open channels (device array; NULL = all M): the detector runs for those only (reference :893).  lampow[n] = lambda^n, n <= 160;
+ * agg / W: [segments][M] work arrays; state: [M] blocker state carried across calls */
+int pmr_launch_ct_detector(pmr_stream_t s, const float *lp, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M, unsigned N,
+                           float a1, const float *lampow, float *state, float *agg, float *W, const float *U, const float *coef,
+                           float *part, const float *carry_in, float *carry_out, pmr_ctcss_event *events, unsigned nblk,
+                           unsigned ncomplete, const unsigned *chan_list, unsigned n_chan);
 
 /* ---- `dsd_in` back end (pmr_dsd_kernels.hip): discriminator + msresamp_rrrf interpolator on absolute-indexed rings ---- */
 int pmr_launch_dsd_fm(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t a0, unsigned ny, float *fm,

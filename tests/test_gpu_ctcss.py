@@ -134,3 +134,31 @@ def test_ctcss_decisions_equal_the_references_own_detector_code():
                 assert eg["index"][k, b] == g["index"][k, b] and eg["detected"][k, b] == g["detected"][k, b], (k, b, avg, mx / avg)
                 seen[int(g["detected"][k, b])] += 1
     assert seen[0] >= 4 and seen[1] >= 4, seen
+
+
+@pytest.mark.parametrize("cfg,k,n,splits", [(CFG2, 5, 1300000, [400000, 1, 500000, 399999]),
+                                             (CFG3, 100, 1 << 25, [1 << 24, 1 << 24])], ids=["cfg2-ch5", "cfg3-ch100"])
+def test_ctcss_with_one_open_channel_is_the_references_mode(cfg, k, n, splits):
+    """The reference runs ctcss_execute for the squelch-selected channel only (src/sdr_pmr446.c:893).  mask = {k}  <->
+    OracleChain(only_channel=k): the open channel's events as in the all-channel comparison; every closed channel reports
+    {index -1, detected 0} (the detector kernels never touched it)."""
+    from sdr_pmr446_amd import chain
+    fs, M = cfg
+    ks = sorted(set([k] + list(range(0, M, max(1, M // 16)))))
+    x = synth.synth_iq(n, fs, M, channels=ks, dev_hz=1500.0, ctcss_dev_hz=700.0)
+    mb = max(splits)
+    eo = _run(oracle.OracleChain(fs_in=fs, num_channels=M, max_block=mb, only_channel=k), x, splits)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb)
+    g.set_channel_mask([k])
+    eg = _run(g, x, splits)
+    assert eo.shape == eg.shape and eo.shape[1] >= 2
+    assert np.all(eo["detected"][k] == 1) and np.all(eo["index"][k] == k % 38)
+    assert np.array_equal(eg["index"][k], eo["index"][k]) and np.array_equal(eg["detected"][k], eo["detected"][k])
+    assert np.allclose(eg["max_power"][k], eo["max_power"][k], rtol=5e-3)
+    assert np.allclose(eg["avg_power"][k], eo["avg_power"][k], rtol=5e-3)
+    closed = [c for c in range(M) if c != k]
+    assert np.all(eg["index"][closed] == -1) and not eg["detected"][closed].any()
+    # open a second channel in mid-stream: its detector starts from zero sums at that point, the first channel is unaffected
+    g.set_channel_mask([k, ks[1] if ks[1] != k else ks[2]])
+    e2 = g.process_block(x[:splits[0]], want=("pcm", "ctcss"))["ctcss"]
+    assert e2.shape[0] == M
