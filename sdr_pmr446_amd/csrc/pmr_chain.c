@@ -632,7 +632,7 @@ static int chain_init(pmr_chain q)
     q->cal_ok = 0;
     if (q->fe_on && !q->fe_two && q->d_fe_G12 && !q->sw.carry_inplace) {
         q->cal_adv_q = (unsigned)(((uint64_t)M * d->arb_step) >> 24) + 1u;
-        q->cal_ok = pmr_channelize_carry_at_load(M, p, d->nco_period, q->chan_small, q->chan_wide, q->sw.chan_pair, q->sw.chan_unfused,
+        q->cal_ok = pmr_channelize_carry_at_load(M, p, d->nco_period, q->chan_small, q->chan_wide, q->sw.chan_pair, q->sw.chan_unfused & 1,
                                                  q->cal_adv_q, (unsigned)q->fe_TQ);
         q->cal_nv = pmr_channelize_carry_nv(M, q->cal_adv_q, (unsigned)q->fe_TQ);
         q->cal_nbias = (unsigned)(((uint64_t)(p + 4) * q->cal_adv_q) / (unsigned)q->fe_TQ) + 2u;
@@ -654,7 +654,7 @@ static void read_switches(pmr_switches *w)
     w->l2_on_fe = env_is("PMR_L2_STREAM", "fe");
     w->chan_generic = env_is("PMR_CHANNELIZER", "generic");
     w->chan_pair = env_is("PMR_CHANNELIZER_SMALL", "pair");
-    w->chan_unfused = env_is("PMR_CHAN_FUSED", "0");
+    w->chan_unfused = env_is("PMR_CHAN_FUSED", "0") | (env_is("PMR_FFT_FPW", "3") ? 2 : 0);
     { const char *e = getenv("PMR_CHAN_FT"); w->chan_ft = e ? atoi(e) : 0; }
     w->fir_mode = env_is("PMR_FIR", "pair") ? PMR_FIR_PAIR : env_is("PMR_FIR", "lds") ? PMR_FIR_LDS
                 : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
@@ -1499,7 +1499,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     q->cal_now = q->cal_ok && !q->dbg_on && !q->spec_nfft;
     q->cal_fix_limit = 0;
     if (q->fe_on && !q->fe_two) {
-        q->tf_on_backend = !single && (q->cal_now || tilefix_on_backend(q));
+        q->tf_on_backend = !single && (q->sw.tf_on_be ? q->sw.tf_on_be == 1 : (q->cal_now || tilefix_on_backend(q)));
         if (!single && !q->tf_on_backend && q->tf_last_be)    /* this block's carry pass reads the dc state the previous one (back-end stream) wrote */
             HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[(par + PIPE_DEPTH - 1) % PIPE_DEPTH], 0), "wait previous carry pass");
         q->tf_last_be = q->tf_on_backend;

@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     }
     const float lp = p.lam_lane_pow[lane], l15 = p.lam_lane_pow[(lane & 15) + 1], l31 = p.lam_lane_pow[(lane & 31) + 1];
     __syncthreads();                                       // (the compiler drains the DMA before the barrier)
+    // (a wave-local wait instead -- each wave's DMA fetches exactly the chunks its own threads read back -- was measured: neutral
+    //  in all three plans, round 3; and a build of this kernel with 101 instead of 88 VGPRs cost the cfg2 chain 10 %: the audio
+    //  FIR's and the channelizer's waves no longer fit beside four of these tiles on a SIMD, so keep an eye on the register count)
 
     cf xs[SPT];
     {
