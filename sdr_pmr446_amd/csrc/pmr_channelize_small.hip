@@ -203,7 +203,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const cf pv = PV[k + i], cu = YA[k + i];
-                rr[i] = atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
+                rr[i] = pmr_arg(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
                 if (tA == 0 && q.reset_flags && q.reset_flags[k + i]) rr[i] = 0.f;    // freqdem_reset: arg(0) = 0
             }
             *reinterpret_cast<float4 *>(o + k) = r;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const cf pv = YA[k + i], cu = YB[k + i];
-                rr[i] = atan2f(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
+                rr[i] = pmr_arg(fmaf(pv.x, cu.y, -(pv.y * cu.x)), fmaf(pv.x, cu.x, pv.y * cu.y)) * fm_ref;
                 if (tB == 0 && q.reset_flags && q.reset_flags[k + i]) rr[i] = 0.f;
             }
             *reinterpret_cast<float4 *>(o + k) = r;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const cf cu = Y[k + i];
-                rr[i] = atan2f(fmaf(pv[i].x, cu.y, -(pv[i].y * cu.x)), fmaf(pv[i].x, cu.x, pv[i].y * cu.y)) * fm_ref;
+                rr[i] = pmr_arg(fmaf(pv[i].x, cu.y, -(pv[i].y * cu.x)), fmaf(pv[i].x, cu.x, pv[i].y * cu.y)) * fm_ref;
                 if (tA == 0 && q.reset_flags && q.reset_flags[k + i]) rr[i] = 0.f;    // freqdem_reset: arg(0) = 0
             }
             *reinterpret_cast<float4 *>(o + k) = r;

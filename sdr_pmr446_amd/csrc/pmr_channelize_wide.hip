@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
         const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
         const unsigned t = row0 + f;                             // frame relative to frame0
         const bool rst = t == 0 && q.reset_flags && q.reset_flags[k];        // freqdem_reset: previous sample = 0 -> arg(0) = 0
-        q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = rst ? 0.f : atan2f(im, re) * q.fm_ref;
+        q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = rst ? 0.f : pmr_arg(im, re) * q.fm_ref;
         if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
     }
     if (q.rssi_part) {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
         const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
         const unsigned t = R0 + f;
         const bool rst = t == 0 && q.reset_flags && q.reset_flags[k];
-        q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = rst ? 0.f : atan2f(im, re) * q.fm_ref;
+        q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = rst ? 0.f : pmr_arg(im, re) * q.fm_ref;
         if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
     }
     if (q.rssi_part) {

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_dsd_fm(const cf *__restrict__ xr, unsig
     const cf cu = xr[a & xr_mask], pv = xr[(a - 1ull) & xr_mask];     // a == 0: the ring is zero there (r' = 0 after reset)
     const float re = fmaf(pv.x, cu.x, pv.y * cu.y);
     const float im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
-    fm[a & fm_mask] = atan2f(im, re) * ref;
+    fm[a & fm_mask] = pmr_arg(im, re) * ref;
 }
 
 // resamp_rrrf_execute inside msresamp_rrrf_execute (:170), outputs j0 .. j0+nu-1

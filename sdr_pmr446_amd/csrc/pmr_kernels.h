@@ -277,6 +277,32 @@ int pmr_launch_spgram(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t
 #endif
 
 #if defined(__HIPCC__)
+/* arg(re + j im) for the discriminator (freqdem, reference src/sdr_pmr446.c:881: cargf(conj(r') r)): the library atan2f spends a
+ * third of its ~38 instructions on range scaling (frexp / ldexp of both operands) and on inf / NaN classes.  Channelizer outputs
+ * are ordinary floats, so: q = min / max by one v_rcp_f32, the same odd minimax polynomial the library evaluates, octant and
+ * sign fix-ups.  Differs from atan2f in the last bit at most (|d| <= 2.4e-7 rad ~ 1e-7 of full scale after the 1 / pi);
+ * the signs of zeros are honoured like atan2f's (arg(+0 + j0) = 0, arg(-0 + j0) = pi: what liquid's freqdem yields on its first
+ * sample, whose conj(0) r product has a negative-zero real part for re(r) > 0). */
+static __device__ __forceinline__ float pmr_arg(float im, float re)
+{
+    const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    float q = mn * __builtin_amdgcn_rcpf(mx);
+    q = mx == 0.0f ? 0.0f : q;
+    const float s = q * q;
+    float p = __builtin_fmaf(s, 0x1.5a54bp-9f, -0x1.f4b218p-7f);
+    p = __builtin_fmaf(s, p, 0x1.53f67ep-5f);
+    p = __builtin_fmaf(s, p, -0x1.2fa9aep-4f);
+    p = __builtin_fmaf(s, p, 0x1.b26364p-4f);
+    p = __builtin_fmaf(s, p, -0x1.22c1ccp-3f);
+    p = __builtin_fmaf(s, p, 0x1.99717ep-3f);
+    p = __builtin_fmaf(s, p, -0x1.5554c4p-2f);
+    float r = __builtin_fmaf(q, s * p, q);
+    r = ay > ax ? 0x1.921fb6p+0f - r : r;
+    r = __builtin_bit_cast(int, re) < 0 ? 0x1.921fb6p+1f - r : r;      // the SIGN BIT: atan2(+-0, -0) = +-pi, as cargf gives for conj(0) r
+    return __builtin_copysignf(r, im);
+}
+
 #include <atomic>
 /* hipFuncSetAttribute is per device, and a process may hold handles on several GPUs driven from several threads
  * (pmr_chain_cfg.device): the "dynamic-LDS limit already raised" flag is one bit per device ordinal in an ATOMIC word.

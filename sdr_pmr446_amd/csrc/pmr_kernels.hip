@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_channelize(pmr_chan_params q, unsigned 
         const float im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
         const unsigned long long row = (unsigned long long)(q.frame0 + t0 + f) & q.fm_mask;
         const bool rst = t0 + f == 0 && q.reset_flags && q.reset_flags[k];   // freqdem_reset: previous sample = 0 -> arg(0) = 0
-        q.fm[row * M + k] = rst ? 0.f : atan2f(im, re) * q.fm_ref;
+        q.fm[row * M + k] = rst ? 0.f : pmr_arg(im, re) * q.fm_ref;
         if (chan_out) chan_out[(size_t)k * q.chan_stride + t0 + f] = cu;
     }
     if (q.rssi_part) {
