@@ -319,6 +319,19 @@ void pmr_chain_default_cfg(pmr_chain_cfg *c)
 /* ------------------------------------------------------------------------------------------- */
 /* fused front end: tile geometry and the closed-form gains of the cascade for an exponential     */
 
+/* Does the plan's cascade get the two-level front end?  (Deep cascades: with 4096-sample tiles the halo would eat the tile.) */
+static int fe_wants_two_levels(const pmr_design *d, const pmr_switches *sw)
+{
+    const unsigned h = d->num_stages, D = d->decim;
+    if (sw->fe_staged || h > PMR_FE_MAX_STAGES || h < 4) return 0;
+    unsigned long S = 0;
+    for (unsigned e = 0; e < h; e++) S += (unsigned long)(4 * d->m_stage[h - 1 - e] - 2) << e;
+    const unsigned long H = S + 13ul * D;
+    if (!(sw->fe_levels ? sw->fe_levels == 2 : (h >= 5 && (4096ul - (H < 4096ul ? H : 4096ul)) * 4 < 4096ul * 3))) return 0;
+    for (unsigned e = 0; e + 2 < h; e++) if (d->m_stage[h - 1 - e] != 3) return 0;
+    return 1;
+}
+
 static int fe_init(pmr_chain q)
 {
     const pmr_design *d = &q->d;
@@ -340,15 +353,7 @@ static int fe_init(pmr_chain q)
      * stages (6-tap filters, halo 10*(2^s1 - 1) raw samples) -> decimated ring; level 2 = the m = 5 and m = 10 stages +
      * resampler on the 2^s1-times decimated stream.  Costs 16/2^s1 B per raw sample of extra HBM traffic (1 B at s1 = 4). */
     q->fe_two = 0; q->fe_s1 = 0;
-    {
-        const int want_two = q->sw.fe_levels ? q->sw.fe_levels == 2
-                                             : (h >= 5 && (4096ul - (H < 4096ul ? H : 4096ul)) * 4 < 4096ul * 3);
-        if (want_two && h >= 4) {
-            int ok = 1;
-            for (unsigned e = 0; e + 2 < h; e++) if (q->fe_m[e] != 3) ok = 0;
-            if (ok) { q->fe_two = 1; q->fe_s1 = (int)h - 2; }
-        }
-    }
+    if (fe_wants_two_levels(d, &q->sw)) { q->fe_two = 1; q->fe_s1 = (int)h - 2; }
     const unsigned s1 = (unsigned)q->fe_s1, D1 = 1u << s1;
     if (q->fe_two) {                              /* level-1 geometry replaces the single-level one below */
         S = 0;
@@ -664,7 +669,7 @@ static void read_switches(pmr_switches *w)
     { const char *e = getenv("PMR_FIR_TPW"); w->fir_tpw = e ? atoi(e) : 2; }
     w->fir_nodual = env_is("PMR_FIR_DUAL", "0");
     w->no_overlap = env_is("PMR_OVERLAP", "0");
-    w->be_prio = env_is("PMR_STREAM_PRIO", "1") ? 1 : env_is("PMR_STREAM_PRIO", "fe") ? 2 : 0;
+    w->be_prio = env_is("PMR_STREAM_PRIO", "1") ? 1 : env_is("PMR_STREAM_PRIO", "fe") ? 2 : env_is("PMR_STREAM_PRIO", "0") ? 3 : 0;
     w->host_gate = !env_is("PMR_HOST_GATE", "0");
     w->fe_marker = env_is("PMR_FE_EVENT", "marker");
     w->tf_on_be = env_is("PMR_TILEFIX_STREAM", "be") ? 1 : env_is("PMR_TILEFIX_STREAM", "fe") ? 2 : 0;
@@ -712,7 +717,13 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
      * bimodal (regions of 0.191 and 0.21 ms; median 337 vs 343 GS/s) -- not a default. */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       /* numerically lower = higher priority */
-    int prio_be = q->sw.be_prio == 1 ? prio_hi : prio_lo, prio_fe = q->sw.be_prio == 2 ? prio_hi : prio_lo;
+    /* Round 3, per plan: the FRONT-END stream runs at the higher priority where the plan has the two-level front end (cfg5: +2.4 %,
+     * 527 -> 539 GS/s).  There the back end is light (1/16 of the data behind level 1) and its kernels -- level 2 19 KB of LDS, the
+     * filter bank none, the FFT 20 KB -- fit beside four level-1 tiles on a CU, so a front end that always gets the next free slot
+     * starves nobody.  One-level plans are the opposite (cfg3 -6.5 %, cfg2 -13 %): channelizer and audio FIR need a front-end
+     * tile's LDS to become resident at all.  PMR_STREAM_PRIO=0 / =1 / =fe force equal / back end high / front end high. */
+    const int fe_high = q->sw.be_prio == 2 || (q->sw.be_prio == 0 && !frontend_only && fe_wants_two_levels(&q->d, &q->sw));
+    int prio_be = q->sw.be_prio == 1 ? prio_hi : prio_lo, prio_fe = fe_high ? prio_hi : prio_lo;
     if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_be) != hipSuccess ||
         hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_fe) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
