@@ -12,6 +12,8 @@
  *                                                377-tap HP, delay 188, IIR de-emphasis)
  *   block loop body   :795-823 (dc-block, resample, ring, NCO mix-down, analyzer, transpose), :881-898 per channel
  *   PCM rule          src/dsd_in.c:174
+ *   waterfall line    :473-477, :911-912 (asgramcf of the resampled stream) vs orc_asgramcf
+ *   dsd_in            src/dsd_in.c:104,:170 (msresamp_rrrf 12.5 k -> 48 k) vs orc_msresamp_rrrf
  * for M = 16 channels at 1.024 MS/s (the reference's operating point) and, with arguments, any other (fs, M), demodulating
  * EVERY channel with its own set of per-channel objects (the oracle's generalisation) so all of them are compared.
  *
@@ -141,12 +143,75 @@ int main(int argc, char **argv)
             }
         }
     }
+    /* ---- the waterfall line (:473-477 asgramcf_create + set_scale(-40, 2); :911-912 write(resamp_buf, ny) + execute): the last
+     * block's resampled stream through liquid's asgramcf and the oracle's restatement; `res` still holds liquid's samples ---- */
+    int ascii_diff = 0; double d_psd_peak = 0;
+    {
+        const unsigned W = 64;
+        asgramcf ag = asgramcf_create(W);
+        asgramcf_set_scale(ag, -40.0f, 2.0f);
+        orc_asgramcf *og = orc_asgramcf_create(W);
+        orc_asgramcf_set_scale(og, -40.0f, 2.0f);
+        char a_l[W + 1], a_o[W + 1];
+        float pv_l = 0, pf_l = 0, pv_o = 0, pf_o = 0;
+        unsigned ny_last = 0;
+        {   /* one more block through liquid's front end and the oracle's, to have both resampled streams side by side */
+            make_signal(x, block, fs, M);
+            memcpy(xl, x, sizeof(*x) * block);
+            iirfilt_crcf_execute_block(dcblock, xl, block, xl);
+            msresamp_crcf_execute(resampler, xl, block, res, &ny_last);
+            orc_taps taps; memset(&taps, 0, sizeof(taps));
+            taps.resampled = (void *)res_o; taps.resampled_cap = RS; taps.stride = S;
+            unsigned ns_o = 0;
+            orc_chain_process_block(o, (const void *)x, block, pcm_o, S, &ns_o, NULL, NULL, &taps);
+        }
+        asgramcf_write(ag, res, ny_last);
+        asgramcf_execute(ag, a_l, &pv_l, &pf_l);
+        orc_asgramcf_write(og, (const cf32 *)res_o, ny_last);
+        orc_asgramcf_execute(og, a_o, &pv_o, &pf_o, NULL);
+        a_l[W] = a_o[W] = 0;
+        for (unsigned i = 0; i < W; i++) ascii_diff += a_l[i] != a_o[i];
+        d_psd_peak = fabs((double)pv_l - (double)pv_o);
+        printf("asgramcf (W = %u)  %d characters differ, peak %.2f dB vs %.2f dB at %.4f vs %.4f\n", W, ascii_diff, pv_l, pv_o, pf_l, pf_o);
+        asgramcf_destroy(ag); orc_asgramcf_destroy(og);
+    }
+
+    /* ---- `dsd_in`'s interpolator (src/dsd_in.c:104,:170): msresamp_rrrf 12.5 kS/s -> 48 kS/s, As = 60 dB, on a discriminator-like
+     * real stream, vs the oracle's orc_msresamp_rrrf; then the int16 rule of :172-175 ---- */
+    double d_up = 0; int d_up_pcm = 0, up_count_mismatch = 0;
+    {
+        const float r_up = 48000.0f / 12500.0f;
+        msresamp_rrrf up = msresamp_rrrf_create(r_up, 60.0f);
+        orc_msresamp_rrrf *oup = orc_msresamp_rrrf_create(r_up, 60.0f);
+        const unsigned n = 12500, cap = (unsigned)(n * r_up) + 64;
+        float *u = malloc(sizeof(float) * n), *y_l = malloc(sizeof(float) * cap), *y_o = malloc(sizeof(float) * cap);
+        for (unsigned b = 0; b < 3; b++) {
+            for (unsigned i = 0; i < n; i++) {
+                const double t = (double)(b * n + i) / 12500.0;
+                u[i] = (float)(0.4 * sin(2 * M_PI * 1000.0 * t) + 0.2 * sin(2 * M_PI * 2417.0 * t + 1.0) + 0.01 * (lcg_uniform() - 0.5));
+            }
+            unsigned nl = 0, no = 0;
+            msresamp_rrrf_execute(up, u, n, y_l, &nl);
+            orc_msresamp_rrrf_execute(oup, u, n, y_o, &no);
+            if (nl != no) { up_count_mismatch++; printf("interpolator block %u: liquid %u outputs, oracle %u\n", b, nl, no); continue; }
+            for (unsigned i = 0; i < nl; i++) {
+                d_up = fmax(d_up, fabsf(y_l[i] - y_o[i]));
+                const int dd = abs((int)(int16_t)(y_l[i] * INT16_MAX) - (int)(int16_t)(y_o[i] * INT16_MAX));     /* :174 */
+                if (dd > d_up_pcm) d_up_pcm = dd;
+            }
+        }
+        printf("msresamp_rrrf x3.84  max |diff| %.3g, int16 %d LSB\n", d_up, d_up_pcm);
+        msresamp_rrrf_destroy(up); orc_msresamp_rrrf_destroy(oup);
+        free(u); free(y_l); free(y_o);
+    }
+
     printf("resampler output  max |diff| %.3g  (scale %.3g)\n", d_res, s_res);
     printf("channelizer       max |diff| %.3g  (scale %.3g)\n", d_chan, s_chan);
     printf("discriminator     max |diff| %.3g\n", d_fm);
     printf("float audio       max |diff| %.3g\n", d_audio);
     printf("int16 PCM         max |diff| %d LSB\n", d_pcm);
-    const int ok = !count_mismatch && d_pcm <= 1 && d_res <= 1e-5 * s_res && d_chan <= 1e-5 * s_chan;
+    const int ok = !count_mismatch && d_pcm <= 1 && d_res <= 1e-5 * s_res && d_chan <= 1e-5 * s_chan &&
+                   !up_count_mismatch && d_up <= 1e-5 && d_up_pcm <= 1 && ascii_diff == 0 && d_psd_peak <= 0.02;
     printf("%s: the oracle restatement %s liquid-dsp on this input\n", ok ? "PASS" : "FAIL", ok ? "matches" : "does NOT match");
     return ok ? 0 : 1;
 }

@@ -637,7 +637,7 @@ static int chain_init(pmr_chain q)
     q->cal_ok = 0;
     if (q->fe_on && !q->fe_two && q->d_fe_G12 && !q->sw.carry_inplace) {
         q->cal_adv_q = (unsigned)(((uint64_t)M * d->arb_step) >> 24) + 1u;
-        q->cal_ok = pmr_channelize_carry_at_load(M, p, d->nco_period, q->chan_small, q->chan_wide, q->sw.chan_pair, q->sw.chan_unfused & 1,
+        q->cal_ok = pmr_channelize_carry_at_load(M, p, d->nco_period, q->chan_small, q->chan_wide, q->sw.chan_pair, q->sw.chan_unfused,
                                                  q->cal_adv_q, (unsigned)q->fe_TQ);
         q->cal_nv = pmr_channelize_carry_nv(M, q->cal_adv_q, (unsigned)q->fe_TQ);
         q->cal_nbias = (unsigned)(((uint64_t)(p + 4) * q->cal_adv_q) / (unsigned)q->fe_TQ) + 2u;
@@ -659,7 +659,7 @@ static void read_switches(pmr_switches *w)
     w->l2_on_fe = env_is("PMR_L2_STREAM", "fe");
     w->chan_generic = env_is("PMR_CHANNELIZER", "generic");
     w->chan_pair = env_is("PMR_CHANNELIZER_SMALL", "pair");
-    w->chan_unfused = env_is("PMR_CHAN_FUSED", "0") | (env_is("PMR_FFT_FPW", "3") ? 2 : 0);
+    w->chan_unfused = env_is("PMR_CHAN_FUSED", "0");
     { const char *e = getenv("PMR_CHAN_FT"); w->chan_ft = e ? atoi(e) : 0; }
     w->fir_mode = env_is("PMR_FIR", "pair") ? PMR_FIR_PAIR : env_is("PMR_FIR", "lds") ? PMR_FIR_LDS
                 : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
@@ -1911,7 +1911,7 @@ int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned
     if ((uint64_t)n_words * 64 < M) return fail(q, PMR_EINVAL, "channel mask shorter than num_channels", hipSuccess);
     /* the mask is applied by the MFMA audio kernels (16 channels per tile); the VALU versions (num_channels not a multiple of 16,
      * PMR_FIR=pair|lds|global) would write every row: refuse instead of breaking the "closed rows stay untouched" promise */
-    if (q->sw.fir_mode != PMR_FIR_MFMA || q->sw.fir_mfma_global || !pmr_fir_mfma4_supported(M, q->hp_len))
+    if (q->sw.fir_mode != PMR_FIR_MFMA || !pmr_fir_mfma4_supported(M, q->hp_len))
         return fail(q, PMR_EINVAL, "channel mask needs the MFMA audio kernels (num_channels a multiple of 16)", hipSuccess);
     unsigned *list = (unsigned *)malloc((size_t)M * sizeof(unsigned));
     if (!list) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);

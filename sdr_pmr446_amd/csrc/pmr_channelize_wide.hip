@@ -318,8 +318,6 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
     if (ntiles_out) *ntiles_out = 0;
     if (!p->ns) return 0;
     hipStream_t st = (hipStream_t)s;
-    const int fpw3 = unfused & 2;                               /* experiment: three rows per FFT workgroup at M = 1024 */
-    unfused &= 1;
     if (p->M == 256 && !unfused) {
         const unsigned ntiles = (p->ns + PF_G - 1) / PF_G;
         if (ntiles_out) *ntiles_out = ntiles;
@@ -340,8 +338,8 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
     switch (p->M) {
     case 64:   return launch_fft_disc<64, 32>(st, p, (const cf *)x_scratch, ntiles_out);
     case 256:  return launch_fft_disc<256, 8>(st, p, (const cf *)x_scratch, ntiles_out);
-    case 1024: return fpw3 ? launch_fft_disc<1024, 3>(st, p, (const cf *)x_scratch, ntiles_out)
-                           : launch_fft_disc<1024, 2>(st, p, (const cf *)x_scratch, ntiles_out);
+    case 1024: return launch_fft_disc<1024, 2>(st, p, (const cf *)x_scratch, ntiles_out);   /* (three rows per workgroup -- 25 % fewer
+                  transforms, half the workgroups -- measured neutral at cfg5, round 3) */
     case 4096: return launch_fft_disc<4096, 2>(st, p, (const cf *)x_scratch, ntiles_out);
     }
     return (int)hipErrorInvalidValue;
