@@ -723,7 +723,12 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
      * starves nobody.  One-level plans are the opposite (cfg3 -6.5 %, cfg2 -13 %): channelizer and audio FIR need a front-end
      * tile's LDS to become resident at all.  PMR_STREAM_PRIO=0 / =1 / =fe force equal / back end high / front end high. */
     const int fe_high = q->sw.be_prio == 2 || (q->sw.be_prio == 0 && !frontend_only && fe_wants_two_levels(&q->d, &q->sw));
-    int prio_be = q->sw.be_prio == 1 ? prio_hi : prio_lo, prio_fe = fe_high ? prio_hi : prio_lo;
+    /* The base priority is NORMAL (0), not the range's least (1 on ROCm 7.2, what rounds 1-2 used for both streams): a process that
+     * had held a handle with a high-priority stream and then created a handle with two LEAST-priority streams saw those two
+     * serialise (cfg2 276 instead of 381 GS/s as bench.py's second workload) -- they apparently end up on one hardware queue.  With
+     * normal / high that does not happen (profiles/r03_stream_priority.txt). */
+    const int prio_base = (prio_hi <= 0 && 0 <= prio_lo) ? 0 : prio_lo;
+    int prio_be = q->sw.be_prio == 1 ? prio_hi : prio_base, prio_fe = fe_high ? prio_hi : prio_base;
     if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_be) != hipSuccess ||
         hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_fe) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
