@@ -55,11 +55,17 @@ for w in ("cfg5", "cfg3", "cfg2"):
             pm.setdefault(n, {})[cname + "_KB"] = sum(v) / len(v)
     if pm:
         chain_bytes = 0.0
+        # the bench command also runs its one-open-channel leg (pmr_chain_set_channel_mask): the GATHER form of the audio FIR appears in
+        # the trace but is not part of the all-channel chain whose bytes are compared with the algorithmic figure
+        mask_only = ("k_fir_mfma4<true", "k_fir_mfma16<false, 1, true, true")
         for n, e in pm.items():
             if "FETCH_SIZE_KB" in e and "WRITE_SIZE_KB" in e:
                 # gfx950: FETCH_SIZE counts a 128-byte request of a wide streaming read as 64 B (MI355X_MICROARCH.md, HBM) -> doubled
                 e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024.0
-                chain_bytes += e["hbm_bytes_per_launch"]
+                if n.startswith(mask_only):
+                    e["note"] = "masked (one open channel) leg of the bench command: not counted in _chain"
+                else:
+                    chain_bytes += e["hbm_bytes_per_launch"]
         alg = BALG[w] * BLOCK
         pm["_chain"] = {"hbm_bytes_per_block": chain_bytes, "algorithmic_bytes_per_block": alg, "ratio": chain_bytes / alg}
         json.dump(pm, open(os.path.join(O, "%s_pmc_fetch_write_%s.json" % (tag, w)), "w"), indent=1)
