@@ -92,6 +92,7 @@ struct pmr_chain_s {
     uint64_t fm_mask;
     void *d_scratch; size_t scratch_bytes;
     float *d_rssi_part;
+    pmr_rssi_job rssi_job; int rssi_job_pending; /* RSSI finish of the block in hand, waiting to ride in the audio FIR's launch */
     size_t rssi_part_cap;
     pmr_slot slot[PIPE_DEPTH]; unsigned slot_head, n_inflight;
 
@@ -1189,7 +1190,7 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
     const unsigned M = q->M, N = PMR_CT_BLOCK;
     /* tmp1 = delay188(fm) - hp(fm) (:884-889) as one FIR with taps delta_188 - h */
     if (!fir_done) LAUNCH(K_CT_FIR, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
-                                       0.f, 0.f, 0.f, q->d_ctlp, NULL, NULL, 0, q->mask_on ? q->d_chan_list : NULL, q->n_enabled));
+                                       0.f, 0.f, 0.f, q->d_ctlp, NULL, NULL, 0, q->mask_on ? q->d_chan_list : NULL, q->n_enabled, NULL, NULL));
     if (q->dbg_on) {                                               /* the branch before ctcss_execute's dc blocker (:889 -> :606) */
         int rc_;
         if (!q->d_dbg_ct && (rc_ = dev_alloc(q, (void **)&q->d_dbg_ct, (size_t)q->chan_size * M * sizeof(float)))) return rc_;
@@ -1396,7 +1397,7 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
     int rc;
     /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906); with the CTCSS
      * detector on, its low-pass branch delay188(x) - hp(x) (:884-889) is a second tap set over the same samples: one pass */
-    int ct_fir_done = 0;
+    int ct_fir_done = 0, rssi_rode = 0;
     if (q->ct_on && q->d_ct_taps_ext && !q->sw.fir_nodual && (d_pcm || d_audio) && !q->cfg.deemph_fir && !q->cfg.lowpass) {
         prof_pending pp_; prof_begin(q, K_FIR_HP, &pp_, q->stream);
         const int rd = pmr_launch_fir_dual(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->d_ct_taps_ext,
@@ -1417,7 +1418,8 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
         LAUNCH(K_FIR_HP, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
                                            1.0f, 0, 0.f, 0.f, 0.f,      /* gain + de-emphasis are in the taps */
                                            more ? q->d_aux1 : NULL, more ? NULL : (int16_t *)d_pcm,
-                                           more ? NULL : (float *)d_audio, pcm_stride, more ? NULL : sel, q->n_enabled));
+                                           more ? NULL : (float *)d_audio, pcm_stride, more ? NULL : sel, q->n_enabled,
+                                           q->rssi_job_pending ? &q->rssi_job : NULL, &rssi_rode));
         const float *cur = q->d_aux1;
         const int sink = d_pcm || d_audio;                 /* (none: a pending block is only pushed through the stateful passes) */
         if (q->cfg.deemph_fir && (sink || q->cfg.lowpass)) {
@@ -1425,14 +1427,19 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
             LAUNCH(K_FIR_DE, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
                                                1.0f, 0, 0.f, 0.f, 0.f, last ? NULL : q->d_aux2,
                                                last ? (int16_t *)d_pcm : NULL, last ? (float *)d_audio : NULL,
-                                               pcm_stride, last ? sel : NULL, q->n_enabled));
+                                               pcm_stride, last ? sel : NULL, q->n_enabled, NULL, NULL));
             cur = q->d_aux2;
         }
         if (q->cfg.lowpass && sink) {
             LAUNCH(K_FIR_LP, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
                                                1.0f, 0, 0.f, 0.f, 0.f, NULL, (int16_t *)d_pcm, (float *)d_audio,
-                                               pcm_stride, sel, q->n_enabled));
+                                               pcm_stride, sel, q->n_enabled, NULL, NULL));
         }
+    }
+    if (q->rssi_job_pending) {
+        q->rssi_job_pending = 0;
+        if (!rssi_rode)
+            LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->rssi_job.rssi_part, q->rssi_job.ntiles, M, q->rssi_job.ns, q->rssi_job.rssi_db));
     }
     return PMR_OK;
 }
@@ -1461,6 +1468,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
                                      int phase /*0: whole block; 1: up to channelizer + RSSI, audio part left pending*/)
 {
     if (!q) return PMR_EINVAL;
+    q->rssi_job_pending = 0;
     if (phase == 1 && !single) return fail(q, PMR_EINVAL, "two-step form is synchronous", hipSuccess);
     if (q->pend_audio) {
         /* a channelized block was never demodulated: filters that carry state of their own through the audio part (CTCSS
@@ -1586,8 +1594,14 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
             if ((rc = ring_to_linear(q, q->d_dbg_fm, q->d_fm, q->fm_mask, (uint64_t)frame0, ns, (size_t)M * sizeof(float))))
                 return rc;
         }
-        if (d_rssi_db)
-            LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->d_rssi_part, ntiles, M, ns, (float *)d_rssi_db));
+        if (d_rssi_db) {
+            if (single && phase != 1 && !q->dbg_on) {
+                /* synchronous call: the RSSI finish rides in the audio FIR's launch where that kernel can take it (audio_part) */
+                q->rssi_job.rssi_part = q->d_rssi_part; q->rssi_job.ntiles = ntiles; q->rssi_job.M = M; q->rssi_job.ns = ns;
+                q->rssi_job.rssi_db = (float *)d_rssi_db; q->rssi_job_pending = 1;
+            } else
+                LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->d_rssi_part, ntiles, M, ns, (float *)d_rssi_db));
+        }
 
         if (phase != 1 && (rc = audio_part(q, frame0, ns, d_pcm, d_audio, pcm_stride))) return rc;
     }

@@ -267,17 +267,21 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
                                              tiles) 338 GS/s, 256: 346, 512: 351, 768: 350, 1024: 348 -- but with ONE open channel 512 costs
                                              17 % (350 vs 424 GS/s) and 3 us at the reference point: 256 stays */
 #endif
-#define CW_F 16                          /* frames per (channel, group) work item */
+#define CW_F 16                          /* frames per (channel, group) work item: big blocks */
+#define CW_F_SMALL 4                     /* ... blocks of a few thousand frames (the reference's 100 000-sample blocks: 1220 frames): 63-frame
+                                            tiles, 20 workgroups instead of 5, a third of the serial work per thread */
 
 // FIX: the front end's dc carry is subtracted from the samples as they are loaded (pmr_carry_fix / pmr_carry_load.hpp): a thread's
 // rows are 16 outputs apart, i.e. M * step / 2^24 ~ 24 decimated samples -- less than a tile (NOV = 1 compare-and-subtract per row).
-template <int M, int P, bool FIX>
+// (Letting the workgroup that finishes last also reduce the tiles' RSSI partial sums -- a launch less for the small synchronous
+// calls -- was measured: the device-scope fences it needs cost 6 us, the separate k_rssi_finish launch 4.6.)
+template <int M, int P, bool FIX, int F>
 __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) void k_channelize_win(pmr_chan_params q)
 {
     constexpr int L2M = log2c<M>::v;
     constexpr int FS = M + 2;                             // padded frame row in LDS (cf elements)
-    constexpr int NFT = CW_NT;                            // frames per tile; local frame 0 = frame t0-1 (recomputed)
-    static_assert(CW_NT % M == 0 && (CW_NT / M) * CW_F == NFT, "groups x frames must cover the tile");
+    constexpr int NFT = (CW_NT / M) * F;                  // frames per tile; local frame 0 = frame t0-1 (recomputed)
+    static_assert(CW_NT % M == 0 && NFT <= CW_NT, "pass 2 gives every frame of the tile a thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *Xs = reinterpret_cast<cf *>(smem);                // [NFT][FS]
     const cf *__restrict__ xr = (const cf *)q.xr;
@@ -298,15 +302,15 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
 
     // ---- pass 1: polyphase bank, X[f][brev(c)] ----
     {
-        const unsigned c = tid & (M - 1), f0 = (tid >> L2M) * CW_F;
+        const unsigned c = tid & (M - 1), f0 = (tid >> L2M) * F;
         // sample of (local frame f0 + r - P ... ) : absolute frame of row r is frame0 + t0 - 1 - (P - 1) + f0 + r  (k = 0 oldest)
         const long long fbase = (long long)q.frame0 + t0 - (long long)P + f0;
         float h[P];
 #pragma unroll
         for (int k = 0; k < P; k++) h[k] = q.taps_t[k * M + c];
-        cf acc[CW_F];
+        cf acc[F];
 #pragma unroll
-        for (int f = 0; f < CW_F; f++) acc[f] = cfm(0.f, 0.f);
+        for (int f = 0; f < F; f++) acc[f] = cfm(0.f, 0.f);
         const unsigned a0 = (unsigned)((unsigned long long)fbase * (unsigned long long)M) + c, xr_mask32 = (unsigned)q.xr_mask;
         // the NCO table's period divides 2 M (launcher), so a thread meets two factors: one on even rows of its window, one on odd rows
         const cf cs_e = nco_cs[a0 & nco_mask], cs_o = nco_cs[(a0 + M) & nco_mask];
@@ -317,12 +321,12 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
         // compiler from hoisting all 41 row loads (and their NCO factors) to the top, which costs > 128 registers
         constexpr int CW_RB = 8;
 #pragma unroll
-        for (int r0 = 0; r0 < CW_F + P - 1; r0 += CW_RB) {
+        for (int r0 = 0; r0 < F + P - 1; r0 += CW_RB) {
             cf xm[CW_RB];
 #pragma unroll
             for (int u = 0; u < CW_RB; u++) {
                 const int r = r0 + u;
-                if (r < CW_F + P - 1) {
+                if (r < F + P - 1) {
                     // low 32 bits of the absolute sample index (fbase + r) * M + c are all the ring / NCO masks need; indices
                     // before the stream start wrap into the zero-initialised top of the ring, as in k_channelize
                     const unsigned a = a0 + (unsigned)r * M;
@@ -334,13 +338,13 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
 #pragma unroll
             for (int u = 0; u < CW_RB; u++) {
                 const int r = r0 + u;
-                if (r < CW_F + P - 1) {
+                if (r < F + P - 1) {
                     cf x = xm[u];
                     if constexpr (FIX) x = pmr_carry_apply<1>(q.fix, ct, cst, x, M, dph);
                     const cf cs = (r & 1) ? cs_o : cs_e;
                     xm[u] = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));   // x * conj(e^{j theta})
 #pragma unroll
-                    for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < CW_F - 1 ? r : CW_F - 1); f++)
+                    for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < F - 1 ? r : F - 1); f++)
                         acc[f] = cfma(h[r - f], xm[u], acc[f]);
                 }
             }
@@ -348,14 +352,15 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
         }
         const unsigned rc = brev_rt(c, L2M);
 #pragma unroll
-        for (int f = 0; f < CW_F; f++) Xs[(f0 + f) * FS + rc] = acc[f];
+        for (int f = 0; f < F; f++) Xs[(f0 + f) * FS + rc] = acc[f];
     }
     __syncthreads();
 
     // ---- pass 2: thread = local frame tid; FFT in registers ----
+    const bool mine = NFT == CW_NT || tid < NFT;          // small tiles: the first NFT threads own a frame
     cf Y[M];
     {
-        const cf *row = Xs + (size_t)tid * FS;
+        const cf *row = Xs + (size_t)(mine ? tid : 0) * FS;
 #pragma unroll
         for (int c = 0; c < M; c += 2) {
             const float4 v = *reinterpret_cast<const float4 *>(row + c);
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
     }
     fft_dit<M>(Y, fft_tw);
     __syncthreads();                                      // every X row has been read
-    {
+    if (mine) {
         cf *ex = Xs + (size_t)tid * FS;
 #pragma unroll
         for (int c = 0; c < M; c += 2)
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
     }
     __syncthreads();
     const long tA = t0 - 1 + tid;                         // frame of this thread, relative to q.frame0
-    const bool outA = tid > 0 && tA < (long)ns;
+    const bool outA = tid > 0 && mine && tA < (long)ns;
     if (outA) {
         const cf *pvrow = Xs + (size_t)(tid - 1) * FS;
         float *o = q.fm + ((unsigned long long)(q.frame0 + tA) & q.fm_mask) * M;
@@ -427,22 +432,31 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
 {
     /* pair = two frames per thread (PMR_CHANNELIZER_SMALL=pair); the sliding-window kernel keeps two NCO factors per thread */
     const bool win = !pair && p->p == 26 && (2u * p->M) % p->nco_period == 0;
-    const unsigned ntiles = win ? (p->ns + CW_NT - 2) / (CW_NT - 1) : pmr_channelize_small_tiles(p->ns);
+    /* few frames: 4 instead of 16 frames per (channel, group) item -- more, shorter workgroups (latency of the synchronous calls) */
+    const bool fine = win && p->ns < 16u * CW_NT;
+    const unsigned nft = fine ? (CW_NT / 16) * CW_F_SMALL : CW_NT;
+    const unsigned ntiles = win ? (p->ns + nft - 2) / (nft - 1) : pmr_channelize_small_tiles(p->ns);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
     if (p->M != 16) return (int)hipErrorInvalidValue;
     if (win) {
         const bool fix = p->fix.V != nullptr;
-        const size_t lds_w = (size_t)CW_NT * (16 + 2) * sizeof(cf) + (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
+        const size_t lds_w = (size_t)nft * (16 + 2) * sizeof(cf) + (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
+        hipStream_t st = (hipStream_t)s;
         static pmr_attr_flags attr_w{0};
-        if (lds_w > 64 * 1024 && pmr_attr_needed(attr_w)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26, false>),
+        if (lds_w > 64 * 1024 && pmr_attr_needed(attr_w)) {      /* only -DCW_NT=1024 experiment builds get here */
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26, false, CW_F>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_win<16, 26, true, CW_F>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
-        if (fix) hipLaunchKernelGGL((k_channelize_win<16, 26, true>), dim3(ntiles), dim3(CW_NT), lds_w, (hipStream_t)s, *p);
-        else hipLaunchKernelGGL((k_channelize_win<16, 26, false>), dim3(ntiles), dim3(CW_NT), lds_w, (hipStream_t)s, *p);
+        if (fine) {
+            if (fix) hipLaunchKernelGGL((k_channelize_win<16, 26, true, CW_F_SMALL>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
+            else hipLaunchKernelGGL((k_channelize_win<16, 26, false, CW_F_SMALL>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
+        } else {
+            if (fix) hipLaunchKernelGGL((k_channelize_win<16, 26, true, CW_F>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
+            else hipLaunchKernelGGL((k_channelize_win<16, 26, false, CW_F>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
+        }
         return (int)hipGetLastError();
     }
     if (p->fix.V) return (int)hipErrorInvalidValue;            /* the two-frames-per-thread kernel expects corrected samples */

@@ -108,12 +108,27 @@ __global__ __launch_bounds__(F4_NT, 4) void k_fir_mfma4(const float *__restrict_
                                                       float *__restrict__ out_tm, int16_t *__restrict__ pcm,
                                                       float *__restrict__ audio, unsigned stride, unsigned M,
                                                       const unsigned *__restrict__ chan_list, unsigned n_units, unsigned nseg,
-                                                      const float *__restrict__ taps2_c, float *__restrict__ out2_tm)
+                                                      const float *__restrict__ taps2_c, float *__restrict__ out2_tm, pmr_rssi_job job)
 {
     unsigned bx = blockIdx.x, by = blockIdx.y;
     if constexpr (!GATHER) {
         const unsigned L = pmr_xcd_contiguous(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
         bx = L % gridDim.x; by = L / gridDim.x;
+    }
+    if (job.rssi_db) {
+        // the rider (launcher: small blocks only): one extra workgroup -- the last of a 1-D grid, workgroup 0 of an extra row of
+        // a 2-D one -- sums the channelizer tiles' partial |y| sums in tile order (k_rssi_finish, pmr_kernels.hip)
+        const bool rider = GATHER ? blockIdx.x == gridDim.x - 1 : by == gridDim.y - 1;
+        if (rider) {
+            if (GATHER || bx == 0) {
+                for (unsigned k = threadIdx.x; k < job.M; k += F4_NT) {
+                    float a = 0.f;
+                    for (unsigned t = 0; t < job.ntiles; t++) a += job.rssi_part[(size_t)t * job.M + k];
+                    job.rssi_db[k] = 20.f * log10f(a / (float)job.ns);       // average_power(), :330-336
+                }
+            }
+            return;
+        }
     }
     __shared__ unsigned s_ch[16];                                    // channel of column slot s
     __shared__ long s_t0[16];                                        // first frame of slot s
@@ -251,8 +266,10 @@ extern "C" int pmr_fir_mfma4_supported(unsigned M, unsigned ntaps)
 
 extern "C" int pmr_launch_fir_mfma4(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                                     const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
-                                    const unsigned *chan_list, unsigned n_chan, const float *taps2_pad, float *out2_tm)
+                                    const unsigned *chan_list, unsigned n_chan, const float *taps2_pad, float *out2_tm,
+                                    const pmr_rssi_job *job, int *job_done)
 {
+    if (job_done) *job_done = 0;
     if (!ns) return 0;
     if (!pmr_fir_mfma4_supported(M, ntaps)) return (int)hipErrorInvalidValue;
     const int dual = taps2_pad && out2_tm;
@@ -274,8 +291,14 @@ extern "C" int pmr_launch_fir_mfma4(pmr_stream_t s, const float *in, uint64_t ro
         n_units = n_chan * tiles;
         grid = dim3((n_units + 15) / 16);
     }
+    pmr_rssi_job jb = {nullptr, 0, 0, 0, nullptr};
+    if (job && job->rssi_db && job->rssi_part && tiles <= 64) {     /* the rider costs a workgroup (1-D grid) or a row of idle ones (2-D) */
+        jb = *job;
+        if (chan_list) grid.x += 1; else grid.y += 1;
+        if (job_done) *job_done = 1;
+    }
 #define F4_GO(G_, D_, T_) hipLaunchKernelGGL((k_fir_mfma4<G_, D_, T_>), grid, dim3(F4_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps, out_tm, \
-                                             pcm, audio, stride, M, chan_list, n_units, tiles, taps2_pad, out2_tm)
+                                             pcm, audio, stride, M, chan_list, n_units, tiles, taps2_pad, out2_tm, jb)
     if (chan_list) {
         if (dual) { if (out_tm) F4_GO(true, true, true); else F4_GO(true, true, false); }
         else      { if (out_tm) F4_GO(true, false, true); else F4_GO(true, false, false); }

@@ -153,9 +153,14 @@ int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsign
  *  first new frame.  pcm / audio are the caller's channel-major buffers, frame index relative to row0.          */
 /*  chan_list / n_chan: open-channel mask (device array of enabled channel indices; NULL = every channel).  Honoured by the
  *  MFMA kernel; the VALU A/B versions compute every channel (rows of disabled channels are then written too).   */
+/*  job / job_done: a small reduction that rides in the launch instead of costing a kernel boundary of its own (4.6 us at the
+ *  reference's block size): the RSSI finish of the block's channelizer (k_rssi_finish's arithmetic, one extra workgroup).  Taken by
+ *  the 16x16x4 MFMA kernel on blocks of a few tiles; *job_done says whether it was (otherwise the caller launches k_rssi_finish). */
+typedef struct { const float *rssi_part; unsigned ntiles, M, ns; float *rssi_db; } pmr_rssi_job;
 int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                       const float *taps_pad, unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
-                      float *out_tm, int16_t *pcm, float *audio, unsigned stride, const unsigned *chan_list, unsigned n_chan);
+                      float *out_tm, int16_t *pcm, float *audio, unsigned stride, const unsigned *chan_list, unsigned n_chan,
+                      const pmr_rssi_job *job /*nullable*/, int *job_done /*nullable*/);
 /* audio FIR (-> pcm / audio) and a second tap set of the same length (-> time-major out2_tm) in ONE pass over the samples;
  * returns -1 when the MFMA kernel cannot take it (caller then runs two passes) */
 int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
@@ -167,7 +172,8 @@ int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in,
 int pmr_fir_mfma4_supported(unsigned M, unsigned ntaps);
 int pmr_launch_fir_mfma4(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                          const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
-                         const unsigned *chan_list, unsigned n_chan, const float *taps2_pad, float *out2_tm);
+                         const unsigned *chan_list, unsigned n_chan, const float *taps2_pad, float *out2_tm,
+                         const pmr_rssi_job *job /*nullable*/, int *job_done /*nullable*/);
 /* the 32x32x2 form it replaced (PMR_FIR_MFMA=32: A/B reference) */
 int pmr_fir_mfma_supported(unsigned M, unsigned ntaps);
 int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,

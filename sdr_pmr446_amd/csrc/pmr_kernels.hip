@@ -777,7 +777,8 @@ extern "C" int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const
 {
     if (sw->fir_mode != PMR_FIR_MFMA || sw->fir_mfma_global) return -1;
     if (fir_use_mfma4(sw, M, ntaps, ns))
-        return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan, taps2_pad, out2_tm);
+        return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan, taps2_pad, out2_tm,
+                                    nullptr, nullptr);
     if (!pmr_fir_mfma_supported(M, ntaps)) return -1;
     if (!ns) return 0;
     return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan,
@@ -787,12 +788,14 @@ extern "C" int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const
 extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
                                  unsigned ns, unsigned M, const float *taps_pad, unsigned ntaps, float gain, int iir, float b0,
                                  float b1, float a1, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
-                                 const unsigned *chan_list, unsigned n_chan)
+                                 const unsigned *chan_list, unsigned n_chan, const pmr_rssi_job *job, int *job_done)
 {
+    if (job_done) *job_done = 0;
     if (!ns) return 0;
     const int mode = sw->fir_mode;           /* PMR_FIR_MFMA (default where supported), _PAIR, _LDS, _TM */
     if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && !sw->fir_mfma_global && fir_use_mfma4(sw, M, ntaps, ns))
-        return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr);
+        return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr,
+                                    job, job_done);
     if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
         return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr);
     if ((mode == PMR_FIR_PAIR || mode == PMR_FIR_MFMA) && M >= 2) {

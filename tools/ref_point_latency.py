@@ -24,6 +24,8 @@ for kind in ("pageable", "pinned"):
     t = np.array(t) * 1e6
     print("pmr_chain_process_block_f32 (%s input), 100000 samples (97.7 ms of signal): median %.0f us, p99 %.0f us -> %.0fx real time" %
           (kind, np.median(t), np.percentile(t, 99), 97656.0 / np.median(t)))
+if "--sync-only" in sys.argv:
+    sys.exit(0)
 # asynchronous pair, pipe kept full
 depth = g._L.pmr_chain_max_in_flight(g.h)
 bufs = [g.pinned_array(len(x)) for _ in range(depth)]
