@@ -125,17 +125,72 @@ __global__ __launch_bounds__(256) void k_ct_seg_scan(const float *__restrict__ a
 // frame first like the recurrence -- a small GEMM, so it runs on the matrix pipe: v_mfma_f32_16x16x4_f32 with
 //   A[i][kappa] = x[frame 4 s + kappa][slot i]          (64 consecutive floats of the staged, dc-blocked segment per step)
 //   B[kappa][c] = U-weight of frame 4 s + kappa for column c = 2 tone + (0: u0, 1: u1), five 16-column tiles (76 columns used)
-// exact f32, sequential in kappa: the sums are those of the scalar loop this replaces.  A workgroup (3 waves: column tiles 0/3,
-// 1/4, 2) walks the same segment position of CG_NB consecutive blocks: the window of U depends on the position inside the block
-// only, so it is staged once per workgroup.
-#define CG_T 192
-#define CG_NB 1                                                    /* blocks per workgroup */
+// exact f32, sequential in kappa: the sums are those of the scalar loop this replaces.  A workgroup = 5 waves, one column tile
+// each (equal MFMA work per wave: with 3 waves sharing 5 tiles 2 : 2 : 1 the busiest SIMD set the kernel's time).
+#define CG_T 320
+#define CG_DC 192                                                  /* threads of the dc-blocker pass: 12 slices x 16 slots */
 #define CG_ROWS 156                                                /* staged rows: SL = 153 rounded up to the MFMA's k step */
+#define CG_SLOTS 1024u                                             /* workgroups the chip holds at once (34 KB of LDS, 5 waves each: 4 per CU) */
 typedef float ct_f32x4 __attribute__((ext_vector_type(4)));
+
+// A workgroup walks the same segment position of `nb` consecutive blocks (the launcher sizes nb so that the grid is ONE round of
+// workgroups): the window of U depends on the position inside the block only and is staged once, and the samples + blocker state
+// of block i + 1 are requested BEFORE block i is processed -- per block the workgroup then pays arithmetic, not a chain of L2
+// round trips (U window, samples, carried state, one after the other: what made the one-block-per-workgroup form of this
+// kernel 39 us whatever the channel count).
+#define CG_NG ((CG_ROWS * 16 + CG_T - 1) / CG_T)                    /* staged 4-byte loads per thread (open-channel list) */
+#define CG_NX ((CG_ROWS * 4 + CG_T - 1) / CG_T)                     /* staged 16-byte loads per thread (all channels) */
+static_assert(CG_T % 16 == 0 && CG_NG <= 16 && 4 * CG_NX <= 16, "ct_xregs holds a thread's share");
+struct ct_xregs { float v[16]; float w; };                         // a thread's share of a staged segment + its slot's carried state
+
+template <bool GATHER>
+static __device__ __forceinline__ void ct_load_x(ct_xregs &x, const float *__restrict__ lp, unsigned long long row_mask, unsigned M,
+                                                 const ct_seg &sg, unsigned cg, unsigned n_chan, unsigned kch, unsigned tid,
+                                                 const float *__restrict__ W, unsigned gseg)
+{
+    if constexpr (GATHER) {                                        // open channels only: slot s of this workgroup = chan_list[cg + s]
+        const bool on = cg + (tid & 15u) < n_chan;
+#pragma unroll
+        for (int u = 0; u < CG_NG; u++) {                          // CG_NG x CG_T >= CG_ROWS x 16 (CG_T is a multiple of 16: one slot per thread)
+            const int r = (int)((tid + CG_T * u) >> 4);
+            x.v[u] = (r < sg.len && on) ? lp[((unsigned long long)(sg.lo + r) & row_mask) * M + kch] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < CG_NX; u++) {                          // samples: 64 bytes per frame
+            const int i = (int)tid + CG_T * u, r = i >> 2, q4 = (i & 3) * 4;
+            const float *src = lp + ((unsigned long long)(sg.lo + r) & row_mask) * M + cg + q4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < sg.len && i < CG_ROWS * 4) {
+                if (cg + q4 + 4 <= M) t = *reinterpret_cast<const float4 *>(src);         // M >= 4 is a power of two
+                else if (cg + q4 < M) { t.x = src[0]; if (cg + q4 + 1 < M) t.y = src[1]; }   // M = 2
+            }
+            x.v[4 * u] = t.x; x.v[4 * u + 1] = t.y; x.v[4 * u + 2] = t.z; x.v[4 * u + 3] = t.w;
+        }
+    }
+    x.w = cg + (tid & 15u) < n_chan ? W[(size_t)gseg * M + kch] : 0.f;
+}
+
+template <bool GATHER>
+static __device__ __forceinline__ void ct_store_x(const ct_xregs &x, float *xs, unsigned tid)
+{
+    if constexpr (GATHER) {
+#pragma unroll
+        for (int u = 0; u < CG_NG; u++) if (tid + CG_T * u < CG_ROWS * 16) xs[tid + CG_T * u] = x.v[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < CG_NX; u++) {
+            const int i = (int)tid + CG_T * u;
+            if (i < CG_ROWS * 4) *reinterpret_cast<float4 *>(xs + 4 * i) = make_float4(x.v[4 * u], x.v[4 * u + 1], x.v[4 * u + 2], x.v[4 * u + 3]);
+        }
+    }
+}
+
+template <bool GATHER>
 __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ lp, unsigned long long row_mask,
                                                      long long row0, unsigned ns, unsigned M, unsigned N,
                                                      const float *__restrict__ U /*[38][N+1], U[j][m+1] = U_m*/,
-                                                     float *__restrict__ part, long long b0, unsigned nblk,
+                                                     float *__restrict__ part, long long b0, unsigned nblk, unsigned nb,
                                                      const unsigned *__restrict__ chan_list, unsigned n_chan,
                                                      const float *__restrict__ W /*[segments][M] blocker state before each segment*/,
                                                      float dc_a1, const float *__restrict__ lampow)
@@ -147,13 +202,18 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
     const unsigned US = SL + 2 + ((SL & 1) ? 0 : 1);               // row stride of us, odd
     float *sagg = us + (size_t)PMR_CT_TONES * US;                  // [12][16]
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const unsigned seg = blockIdx.x % PMR_CT_SEG, blk0 = (blockIdx.x / PMR_CT_SEG) * CG_NB, cg = blockIdx.y * 16u;   // cg: first of 16 channel SLOTS
+    const unsigned seg = blockIdx.x % PMR_CT_SEG, blk0 = (blockIdx.x / PMR_CT_SEG) * nb, cg = blockIdx.y * 16u;   // cg: first of 16 channel SLOTS
+    const unsigned nbw = blk0 + nb <= nblk ? nb : nblk - blk0;     // blocks of this workgroup (>= 1: launcher)
     const unsigned e_pos = min(N, (seg + 1) * SL), s_pos = seg * SL;     // the FULL segment inside a block: [s_pos, e_pos)
     __shared__ float s_lam[16];                                    // lambda^n, n <= 13 (a table read inside the serial carry loop below
     if (tid < 16) s_lam[tid] = lampow[tid];                        //  must not be a global load per step)
-    // ---- U window of the full segment, once: weight of block position p is us[j][e_pos - p] (-> u0) and us[j][e_pos - p - 1] (-> u1) ----
+    const unsigned slot = cg + (tid & 15u);
+    const unsigned kch = slot < n_chan ? (GATHER ? chan_list[slot] : slot) : 0u;       // channel of this thread's slot (staging, carry)
+    // ---- U window of the full segment, once: weight of block position p is us[j][e_pos - p] (-> u0) and us[j][e_pos - p - 1] (-> u1);
+    //      and the first block's samples: every load of the thread is in flight before the first is used ----
+    ct_xregs xq;
+    ct_seg sg = ct_segment(b0 + blk0, seg, N, SL, row0, ns);
     {
-        // every load of the thread is in flight before the first is stored (a run-time-bounded loop pays the L2 latency per element)
         constexpr int NJ = (PMR_CT_TONES + CG_T / 64 - 1) / (CG_T / 64), NM = (CG_ROWS + 1 + 63) / 64;
         float uv[NJ][NM];
         const unsigned wlen = e_pos - s_pos;
@@ -166,55 +226,38 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
                 uv[jj][mm] = (j < PMR_CT_TONES && m <= wlen) ? U[(size_t)j * (N + 1) + (N - e_pos) + m] : 0.f;
             }
         }
+        ct_load_x<GATHER>(xq, lp, row_mask, M, sg, cg, n_chan, kch, tid, W, blk0 * PMR_CT_SEG + seg);
 #pragma unroll
         for (int jj = 0; jj < NJ; jj++) {
             const unsigned j = wave + (CG_T / 64) * jj;
 #pragma unroll
             for (int mm = 0; mm < NM; mm++) {
                 const unsigned m = lane + 64u * mm;
-                if (j < PMR_CT_TONES && m <= wlen) us[j * US + m] = uv[jj][mm];
+                if (j < PMR_CT_TONES && m < US) us[j * US + m] = uv[jj][mm];      // the row's tail (m > wlen) is zero
             }
         }
     }
+    ct_store_x<GATHER>(xq, xs, tid);
+    float wv = xq.w;
+    __syncthreads();
 
-    for (unsigned bi = 0; bi < CG_NB && blk0 + bi < nblk; bi++) {
+    for (unsigned bi = 0; bi < nbw; bi++) {
         const unsigned blk = blk0 + bi, gseg = blk * PMR_CT_SEG + seg;
-        const ct_seg sg = ct_segment(b0 + blk, seg, N, SL, row0, ns);
-        const long long lo = sg.lo;
         const int len = sg.len;
-        __syncthreads();                                           // the previous block's readers are done (and us is complete)
-        if (chan_list) {                                           // open channels only: slot s of this workgroup = chan_list[cg + s]
-            for (int i = tid; i < CG_ROWS * 16; i += CG_T) {
-                const int r = i >> 4, sl = i & 15;
-                xs[i] = (r < len && cg + sl < n_chan) ? lp[((unsigned long long)(lo + r) & row_mask) * M + chan_list[cg + sl]] : 0.f;
-            }
-        } else {
-            constexpr int NX = (CG_ROWS * 4 + CG_T - 1) / CG_T;    // samples: 64 bytes per frame; all loads first
-            float4 xv[NX];
-#pragma unroll
-            for (int u = 0; u < NX; u++) {
-                const int i = tid + CG_T * u, r = i >> 2, q4 = (i & 3) * 4;
-                const float *src = lp + ((unsigned long long)(lo + r) & row_mask) * M + cg + q4;
-                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < len) {
-                    if (cg + q4 + 4 <= M) xv[u] = *reinterpret_cast<const float4 *>(src);         // M >= 4 is a power of two
-                    else if (cg + q4 < M) { xv[u].x = src[0]; if (cg + q4 + 1 < M) xv[u].y = src[1]; }   // M = 2
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < NX; u++) {
-                const int i = tid + CG_T * u, r = i >> 2, q4 = (i & 3) * 4;
-                if (i < CG_ROWS * 4) *reinterpret_cast<float4 *>(xs + r * 16 + q4) = xv[u];
-            }
+        const unsigned n0 = sg.n0;
+        const bool more = bi + 1 < nbw;
+        if (more) {                                                // the next block's samples and state travel while this one is processed
+            sg = ct_segment(b0 + blk + 1, seg, N, SL, row0, ns);
+            ct_load_x<GATHER>(xq, lp, row_mask, M, sg, cg, n_chan, kch, tid, W, gseg + PMR_CT_SEG);
         }
-        __syncthreads();
         // ---- dc blocker of ctcss_execute (:606), pass 3, on the staged samples in place: thread (slot, slice of CT_SUBG frames)
         // strings the zero-state aggregates of the slices before its own onto the segment's carried state W, then runs the exact
         // recurrence v0 = x - a1 v1, y = v0 - v1 (liquid's iirfilt_rrrf, individually rounded) over its slice ----
         {
-            constexpr int CT_SUBG = 13;                            // 12 slices x 13 >= SL = 153; CG_T = 12 x 16 threads
+            constexpr int CT_SUBG = 13;                            // 12 slices x 13 >= SL = 153: the first CG_DC = 12 x 16 threads
             const unsigned sl = tid & 15u, ss = tid >> 4;
-            const int i0 = (int)ss * CT_SUBG, ln = len - i0 < 0 ? 0 : (len - i0 > CT_SUBG ? CT_SUBG : len - i0);
+            const bool dcw = tid < CG_DC;
+            const int i0 = (int)ss * CT_SUBG, ln = !dcw ? 0 : len - i0 < 0 ? 0 : (len - i0 > CT_SUBG ? CT_SUBG : len - i0);
             const float lam = -dc_a1;
             float x[CT_SUBG];
 #pragma unroll
@@ -222,12 +265,10 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
             float v = 0.f;
 #pragma unroll
             for (int u = 0; u < CT_SUBG; u++) if (u < ln) v = fmaf(lam, v, x[u]);
-            sagg[ss * 16 + sl] = v;
+            if (dcw) sagg[ss * 16 + sl] = v;
             __syncthreads();
-            const unsigned ci = cg + sl;
-            const unsigned kc = ci < n_chan ? (chan_list ? chan_list[ci] : ci) : 0u;
-            float v1 = ci < n_chan ? W[(size_t)gseg * M + kc] : 0.f;
-            for (unsigned q = 0; q < ss; q++) {
+            float v1 = wv;
+            for (unsigned q = 0; q < (dcw ? ss : 0u); q++) {
                 const int lq = len - (int)q * CT_SUBG;
                 v1 = fmaf(s_lam[lq < 0 ? 0 : (lq > CT_SUBG ? CT_SUBG : lq)], v1, sagg[q * 16 + sl]);
             }
@@ -244,45 +285,50 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
         // ---- the Goertzel sums on the matrix pipe.  Row r of the staged segment sits at block position p = n0 + r ----
         {
             const int col = lane & 15, kk = lane >> 4;
-            const int d0 = (int)e_pos - (int)sg.n0;                // us index of row r, column (tone, which): d0 - r - which
-            ct_f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            const int nct = wave < 2 ? 2 : 1;                      // column tiles of this wave: wave, wave + 3
-            const float *ub[2];
-            int ui[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int c = 16 * ((int)wave + 3 * t) + col, jt = c >> 1;              // column -> (tone, which); columns >= 76: tone 37 again, never stored
-                ub[t] = us + (size_t)(jt < (int)PMR_CT_TONES ? jt : (int)PMR_CT_TONES - 1) * US;
-                ui[t] = d0 - (c & 1) - kk;
-            }
+            const int d0 = (int)e_pos - (int)n0;                   // us index of row r, column (tone, which): d0 - r - which
+            ct_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // Every row of the staged segment beyond `len` is zero, so all CG_ROWS / 4 k steps always run (a zero sample times a finite
+            // weight adds nothing): a fixed trip count, fully unrolled, every LDS address = base + immediate, the reads of 13 steps
+            // issued ahead of their MFMAs.  (With a run-time trip count and a clamped weight index the compiler issued read, wait,
+            // MFMA one after the other: ~400 cycles per step, 21 of this kernel's 33 us.)  Weight index of step st: ui - 4 st, which
+            // runs below the row's start for the zero rows of a clipped segment -- into the previous tone's row or the sample area:
+            // finite numbers (the rows' tails are zero-filled above), multiplied by zero.
+            constexpr int NST = CG_ROWS / 4;
+            const int c = 16 * (int)wave + col, jt = c >> 1;       // column -> (tone, which); columns >= 76: tone 37 again, never stored
+            const float *pb = us + (size_t)(jt < (int)PMR_CT_TONES ? jt : (int)PMR_CT_TONES - 1) * US + (d0 - (c & 1) - kk) - 4 * (NST - 1);
             const float *xa = xs + lane;                           // step s: xa[64 s]
-            const int nst = (len + 3) >> 2;
-            for (int st = 0; st < nst; st++) {
-                const float a = xa[64 * st];
+            constexpr int CH = 13;                                 // k steps per chunk: the chunk's 26 LDS reads are issued together,
+            static_assert(NST % CH == 0, "chunks cover the steps");//  then its 13 MFMAs run (scheduling barriers keep it that way)
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    if (t < nct) {
-                        const int ix = ui[t] - 4 * st;
-                        const float b = ub[t][ix < 0 ? 0 : ix];    // rows beyond the segment are zero in xs: any finite weight does
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-                    }
+            for (int s0 = 0; s0 < NST; s0 += CH) {
+                float av[CH], bv[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    av[u] = xa[64 * (s0 + u)];
+                    bv[u] = pb[4 * (NST - 1 - s0 - u)];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // D: lane holds column `col` of its tile, register q = channel slot 4 kk + q
+            if (c < 2 * (int)PMR_CT_TONES) {
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const int c = 16 * ((int)wave + 3 * t) + col;
-                if (t < nct && c < 2 * (int)PMR_CT_TONES) {
-#pragma unroll
-                    for (int qq = 0; qq < 4; qq++) {
-                        const unsigned sl = cg + 4 * kk + qq;
-                        if (sl < n_chan) {
-                            const unsigned k = chan_list ? chan_list[sl] : sl;
-                            part[((size_t)gseg * M + k) * PMR_CT_TONES * 2 + c] = acc[t][qq];
-                        }
+                for (int qq = 0; qq < 4; qq++) {
+                    const unsigned sl = cg + 4 * kk + qq;
+                    if (sl < n_chan) {
+                        const unsigned k = GATHER ? chan_list[sl] : sl;
+                        part[((size_t)gseg * M + k) * PMR_CT_TONES * 2 + c] = acc[qq];
                     }
                 }
             }
+        }
+        if (more) {
+            __syncthreads();                                       // every reader of the staged segment is done
+            ct_store_x<GATHER>(xq, xs, tid);
+            wv = xq.w;
+            __syncthreads();
         }
     }
 }
@@ -350,8 +396,17 @@ extern "C" int pmr_launch_ct_detector(pmr_stream_t s, const float *lp, uint64_t 
                        b0, chan_list, nc);
     hipLaunchKernelGGL(k_ct_seg_scan, dim3(nc), dim3(256), 0, st, agg, nseg, M, N, (long long)row0, ns, b0, lampow, state, W, chan_list);
     const size_t lds = ((size_t)CG_ROWS * 16 + (size_t)PMR_CT_TONES * US + 12 * 16) * sizeof(float);
-    hipLaunchKernelGGL(k_ct_goertzel, dim3(((nblk + CG_NB - 1) / CG_NB) * PMR_CT_SEG, (nc + 15) / 16), dim3(CG_T), lds, st, lp, rm,
-                       (long long)row0, ns, M, N, U, part, b0, nblk, chan_list, nc, W, a1, lampow);
+    /* blocks per workgroup: the grid is one round of resident workgroups */
+    const unsigned ny = (nc + 15) / 16;
+    unsigned nb = (unsigned)(((unsigned long long)nblk * PMR_CT_SEG * ny + CG_SLOTS - 1) / CG_SLOTS);
+    if (nb < 1) nb = 1;
+    const dim3 grid(((nblk + nb - 1) / nb) * PMR_CT_SEG, ny);
+    if (chan_list)
+        hipLaunchKernelGGL(k_ct_goertzel<true>, grid, dim3(CG_T), lds, st, lp, rm, (long long)row0, ns, M, N, U, part, b0, nblk, nb, chan_list, nc,
+                           W, a1, lampow);
+    else
+        hipLaunchKernelGGL(k_ct_goertzel<false>, grid, dim3(CG_T), lds, st, lp, rm, (long long)row0, ns, M, N, U, part, b0, nblk, nb, chan_list, nc,
+                           W, a1, lampow);
     hipLaunchKernelGGL(k_ct_final, dim3(nblk * nc), dim3(64), 0, st, part, nblk, ncomplete, M, coef, carry_in, carry_out, events,
                        chan_list, nc);
     return (int)hipGetLastError();
