@@ -40,6 +40,15 @@ typedef __attribute__((address_space(3))) void lptr_t;
 // slot of 16-byte chunk g (and chunk of slot g: the map is an involution)
 static __device__ __forceinline__ int fe_swz(int g) { return (g & ~7) | ((g & 7) ^ ((g >> 4) & 7)); }
 
+#ifdef FE_STAMP
+// diagnostic build (tools/fe_phase_times.py): s_memtime at the phase boundaries of every tile, thread 0 -> fe_stamps[tile][8]
+__device__ unsigned long long fe_stamps[65536 * 8];
+#define FE_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) fe_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int pmr_debug_fe_stamps(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fe_stamps), bytes, 0, hipMemcpyDeviceToHost); }
+#else
+#define FE_STAMP_AT(i) do { } while (0)
+#endif
+
 template <int MODE, int N3, int TAIL>
 __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 {
@@ -58,6 +67,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     cf *bnd = wagg + NT / 64;                                 // [4][10]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FE_STAMP_AT(0);
     const cf *__restrict__ x = (const cf *)p.x;
     const cf *__restrict__ hist = (const cf *)p.hist;
     const float lam = -p.dc_a1;
@@ -112,6 +122,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     }
     const float lp = p.lam_lane_pow[lane], l15 = p.lam_lane_pow[(lane & 15) + 1], l31 = p.lam_lane_pow[(lane & 31) + 1];
     __syncthreads();                                       // (the compiler drains the DMA before the barrier)
+    FE_STAMP_AT(1);
     // (a wave-local wait instead -- each wave's DMA fetches exactly the chunks its own threads read back -- was measured: neutral
     //  in all three plans, round 3; and a build of this kernel with 101 instead of 88 VGPRs cost the cfg2 chain 10 %: the audio
     //  FIR's and the channelizer's waves no longer fit beside four of these tiles on a SIMD, so keep an eye on the register count)
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     }
         }
     __syncthreads();
+    FE_STAMP_AT(2);
 
     // ---- phase C: remaining stages, ping-pong R0 <-> R1; stage e (execution index) has 2048 >> e outputs ----
     cf *R0 = buf, *R1 = buf + R1_OFF;
@@ -215,6 +227,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     constexpr int PLAST = H == 1 ? 8 : (NLAST >= NT ? NLAST / NT : 1);
     constexpr int GS = PLAST >= 8 ? 3 : (PLAST == 4 ? 2 : 1);                   // final layout L(1 << GS)
     const cf *fin = ((H - 1) & 1) ? R1 : R0;                                      // stage e writes R1 when e is odd
+    FE_STAMP_AT(3);
 
     if constexpr (MODE == FE_L1) {
         // pairs of adjacent samples per lane through 16-byte stores (8-byte stores run at ~0.6x the rate); pairs start at
@@ -234,6 +247,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     } else {
         fe_arb_store<NT, GS>(p, ap, qa, fin, bk0, bk1, tid);
     }
+    FE_STAMP_AT(4);
     // ---- raw history for the next call (last hcap samples of old history || block), by tile 0 ----
     if (c == 0 && p.new_hist) {
         cf *__restrict__ nh = (cf *)p.new_hist;
