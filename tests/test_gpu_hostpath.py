@@ -205,3 +205,29 @@ def test_two_step_form_opens_the_squelch_on_the_same_block():
             assert np.abs(got).max() > 1000
     assert opened_at == 2
     g.close(); o.close()
+
+
+@pytest.mark.parametrize("mask", [None, [5], [0, 3, 15]], ids=["all-open", "one-open", "three-open"])
+def test_rssi_finish_riding_in_the_fir_launch_equals_its_own_kernel(mask):
+    """Synchronous small-block calls let the RSSI finish ride in the audio FIR's launch (one extra workgroup of k_fir_mfma4, a
+    kernel boundary less); the two-step form and blocks of many tiles launch k_rssi_finish.  Same sums in the same order: the
+    figures must be EQUAL, with every channel open (2-D grid + an extra row) and with a channel mask (1-D grid + an extra
+    workgroup)."""
+    from sdr_pmr446_amd import chain
+    fs, M = CFG_REF
+    sizes = [100000, 99999, 4000, 100000]
+    x = synth.synth_iq(sum(sizes), fs, M, dev_hz=1500.0)
+    ga = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(sizes))
+    gb = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(sizes))
+    for g in (ga, gb):
+        g.set_channel_mask(mask)
+    pos = 0
+    for n in sizes:
+        blk = x[pos:pos + n]
+        pos += n
+        a = ga.process_block(blk, want=("pcm", "rssi"))                      # rider
+        c = gb.channelize_block(blk, want=("rssi",))                          # k_rssi_finish
+        b = gb.demodulate_block(want=("pcm",))
+        assert a["rssi"].tobytes() == c["rssi"].tobytes(), n
+        assert np.array_equal(a["pcm"], b["pcm"])
+    ga.close(); gb.close()
