@@ -171,7 +171,11 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
 // FIX: the front end's dc carry is subtracted from the samples as they are loaded (pmr_carry_fix / pmr_carry_load.hpp).  A
 // thread's rows are 256 outputs apart = M * step / 2^24 ~ 307 decimated samples at cfg3, more than one front-end tile (217) and
 // less than two: NOV = 2 compare-and-subtract steps per row.
-#define PF_G 8
+#ifndef PF_G
+#define PF_G 8              /* new frames per workgroup.  16 is 10 % faster ALONE (0.031 vs 0.0345 ms at cfg3: 2.6 instead of 4.25 loads per
+                               sample) and 4 % slower IN THE CHAIN (380 vs 397 GS/s: 35 KB of LDS no longer fit beside four front-end tiles, the
+                               back-end stream becomes the critical one); 12: 391, 6: 391, 4: 367 (tools/variant_bench.sh, round 3) */
+#endif
 template <bool FIX>
 __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params q)
 {
