@@ -1595,8 +1595,8 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
                 return rc;
         }
         if (d_rssi_db) {
-            if (single && phase != 1 && !q->dbg_on) {
-                /* synchronous call: the RSSI finish rides in the audio FIR's launch where that kernel can take it (audio_part) */
+            if (phase != 1 && !q->dbg_on) {
+                /* the RSSI finish rides in the audio FIR's launch where that kernel takes it (blocks of a few tiles: audio_part) */
                 q->rssi_job.rssi_part = q->d_rssi_part; q->rssi_job.ntiles = ntiles; q->rssi_job.M = M; q->rssi_job.ns = ns;
                 q->rssi_job.rssi_db = (float *)d_rssi_db; q->rssi_job_pending = 1;
             } else

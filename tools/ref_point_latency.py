@@ -10,7 +10,7 @@ x = synth.synth_iq(100000, 1.024e6, 16)
 g = chain.PmrChain()
 S = g.max_frames
 pcm = np.zeros((16, S), np.int16); audio = np.zeros((16, S), np.float32); rssi = np.zeros(16, np.float32); ns = C.c_uint(0)
-for kind in ("pageable", "pinned"):
+for kind in (() if "--async-only" in sys.argv else ("pageable", "pinned")):
     xi = x
     if kind == "pinned":
         xi = g.pinned_array(len(x)); xi[:] = x
@@ -25,7 +25,8 @@ for kind in ("pageable", "pinned"):
     print("pmr_chain_process_block_f32 (%s input), 100000 samples (97.7 ms of signal): median %.0f us, p99 %.0f us -> %.0fx real time" %
           (kind, np.median(t), np.percentile(t, 99), 97656.0 / np.median(t)))
 if "--sync-only" in sys.argv:
-    sys.exit(0)
+    g.close()
+    raise SystemExit(0)
 # asynchronous pair, pipe kept full
 depth = g._L.pmr_chain_max_in_flight(g.h)
 bufs = [g.pinned_array(len(x)) for _ in range(depth)]
@@ -42,6 +43,9 @@ dt = time.perf_counter() - t0
 for i in range(depth): col()
 print("pmr_chain_submit_block / collect_block, %d blocks in flight: %.0f us per 100000-sample block (%.1f MS/s, %.0fx real time)" %
       (depth, dt / N * 1e6, N * 1e5 / dt / 1e6, 97656.0 / (dt / N * 1e6)))
+if "--async-only" in sys.argv:
+    g.close()
+    raise SystemExit(0)
 d = chain.PmrDsd()
 xd = synth.synth_iq(200000, 1.024e6, 1)
 out = np.zeros(d.max_out, np.int16); nz = C.c_uint(0)
