@@ -14,6 +14,24 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+class _stdout_to_stderr:
+    """gloo announces its connections on the C++ stdout; the bench contract is ONE JSON line there.  While the process groups come up,
+    file descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 class Dist:
     """What bench.py needs from torch.distributed: a barrier and the MAX of one number -- on the backend that actually came up."""
 
@@ -54,7 +72,10 @@ def init_dist(backend, device=None, nccl_timeout_s=120):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    with _stdout_to_stderr():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.zeros(1, dtype=torch.int32)
+        dist.all_reduce(t)                                   # connects the pairs now, while stdout is still diverted
     if backend != "nccl":
         return Dist(dist, None, "gloo", None)
     ok, note, grp = 1, None, None

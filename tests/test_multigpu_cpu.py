@@ -105,6 +105,7 @@ def test_self_launch_starts_the_ranks_relays_output_and_exit_code(tmp_path):
     assert r.returncode == 0, r.stderr[-800:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1
+    assert [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("{")] == [], r.stdout     # gloo's chatter went to stderr
     rec = json.loads(line[0])
     assert rec == {"world": 2, "backend_used": "gloo", "args": ["--x", "1"], "out": 1}
     r = subprocess.run([sys.executable, "-c", parent], env=dict(env, FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
