@@ -718,12 +718,14 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
      * bimodal (regions of 0.191 and 0.21 ms; median 337 vs 343 GS/s) -- not a default. */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       /* numerically lower = higher priority */
-    /* Round 3, per plan: the FRONT-END stream runs at the higher priority where the plan has the two-level front end (cfg5: +2.4 %,
-     * 527 -> 539 GS/s).  There the back end is light (1/16 of the data behind level 1) and its kernels -- level 2 19 KB of LDS, the
-     * filter bank none, the FFT 20 KB -- fit beside four level-1 tiles on a CU, so a front end that always gets the next free slot
-     * starves nobody.  One-level plans are the opposite (cfg3 -6.5 %, cfg2 -13 %): channelizer and audio FIR need a front-end
-     * tile's LDS to become resident at all.  PMR_STREAM_PRIO=0 / =1 / =fe force equal / back end high / front end high. */
-    const int fe_high = q->sw.be_prio == 2 || (q->sw.be_prio == 0 && !frontend_only && fe_wants_two_levels(&q->d, &q->sw));
+    /* Round 3: for a while the front-end stream ran at the higher priority in two-level plans (cfg5 +2.4 % with the level-1 kernel
+     * of that time).  It sits next to a cliff: the audio FIR's 36 KB of LDS do not fit beside four level-1 tiles, so a front end
+     * that always gets the next free slot lets FIR workgroups in only at its kernel's tail -- a level-1 kernel 2 % faster (taken
+     * branches out of its dc scan) turned 541 GS/s into 495 in steady state (540 again with an LDS-free FIR, or with equal
+     * priorities: profiles/r03_ab_log.txt r43-r46), and 20-step regions went bimodal (525 / 556).  Equal priorities have no such
+     * cliff: 537-541 at both region lengths.  One-level plans never wanted it (cfg3 -6.5 %, cfg2 -13 %).
+     * PMR_STREAM_PRIO=1 / =fe force back end high / front end high for A/B runs. */
+    const int fe_high = q->sw.be_prio == 2;
     /* The base priority is NORMAL (0), not the range's least (1 on ROCm 7.2, what rounds 1-2 used for both streams): a process that
      * had held a handle with a high-priority stream and then created a handle with two LEAST-priority streams saw those two
      * serialise (cfg2 276 instead of 381 GS/s as bench.py's second workload) -- they apparently end up on one hardware queue.  With

@@ -154,21 +154,42 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
         if (lane == 63) wagg[wave] = v;
         const cf ex = dpp0c<0x138>(v);                                     // wave_shr:1 (lane 0 <- 0)
         __syncthreads();                                                   // also: every thread holds its raw samples
-        cf cw = cfm(0.f, 0.f);                                             // v (local) at the end of the previous wave
-        for (int w = 0; w < wave; w++) cw = cfma(p.lam_wave, cw, wagg[w]);
+        // v (local) at the end of the previous wave: Horner over the aggregates of the waves before this one.  Branch-free (the
+        // three reads issued together, each step selected by the wave index): as a loop over `wave` it compiled to an exec-masked
+        // loop with one dependent LDS read per trip -- ~400 cycles for wave 3, which the whole tile waits for at the next barrier
+        cf cw = cfm(0.f, 0.f);
+        {
+            const cf a0 = wagg[0], a1 = wagg[1], a2 = wagg[2];
+            const cf c1 = cfma(p.lam_wave, cw, a0);
+            cw = wave > 0 ? c1 : cw;
+            const cf c2 = cfma(p.lam_wave, cw, a1);
+            cw = wave > 1 ? c2 : cw;
+            const cf c3 = cfma(p.lam_wave, cw, a2);
+            cw = wave > 2 ? c3 : cw;
+        }
         cf v1 = cfma(lp, cw, ex);
         // stray probes (block start - 1 in tile 0, block end in the last tile) sit at arbitrary offsets
         const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
         const int pE = (c == p.c_end) ? p.off_end : -1;
-        const bool stray = (pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid);
+        const cf v1s = v1;
 #pragma unroll
         for (int j = 0; j < SPT; j++) {
             const cf v0 = cfma(lam, v1, xs[j]);
             yb[j] = csub(v0, v1);                                          // y = v0 - v1
             v1 = v0;
-            if (stray) {
-                if (SPT * tid + j == pL) ((cf *)p.probeL)[0] = v0;
-                if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = v0;
+        }
+        if (pL >= 0 || pE >= 0) {
+            // only the block's first and last tile get here (uniform branch): the one thread that owns a stray probe runs its
+            // recurrence again.  Inside the loop above the test was an exec-mask branch per sample -- sixteen taken branches in
+            // the middle of the kernel's longest dependent chain, in every tile
+            if ((pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid)) {
+                cf u = v1s;
+#pragma unroll
+                for (int j = 0; j < SPT; j++) {
+                    u = cfma(lam, u, xs[j]);
+                    if (SPT * tid + j == pL) ((cf *)p.probeL)[0] = u;
+                    if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = u;
+                }
             }
         }
         if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;      // local v at tile offset Hh-1
