@@ -391,9 +391,12 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
             for (int i = 0; i < 4; i++) {
                 const cf cu = Y[k + i];
                 rr[i] = pmr_arg(fmaf(pv[i].x, cu.y, -(pv[i].y * cu.x)), fmaf(pv[i].x, cu.x, pv[i].y * cu.y)) * fm_ref;
-                if (tA == 0 && q.reset_flags && q.reset_flags[k + i]) rr[i] = 0.f;    // freqdem_reset: arg(0) = 0
             }
             *reinterpret_cast<float4 *>(o + k) = r;
+        }
+        if (tA == 0 && q.reset_flags) {                  // freqdem_reset: arg(0) = 0 -- one thread of the call, after its stores (a test
+#pragma unroll                                           //  per element sat in all sixteen arg() chains as a taken branch)
+            for (int k = 0; k < M; k++) if (q.reset_flags[k]) o[k] = 0.f;
         }
         cf *__restrict__ chan_out = (cf *)q.chan_out;
         if (chan_out) {

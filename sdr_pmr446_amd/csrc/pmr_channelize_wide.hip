@@ -145,14 +145,24 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
     const cf *Y = A;
     cf *__restrict__ chan_out = (cf *)q.chan_out;
     const unsigned nnew = nrow - 1;
-    for (unsigned wi = tid; wi < nnew * M; wi += 256) {
-        const unsigned f = wi / M, k = wi % M;
-        const cf pv = Y[f * M + k], cu = Y[(f + 1) * M + k];
-        const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
-        const unsigned t = row0 + f;                             // frame relative to frame0
-        const bool rst = t == 0 && q.reset_flags && q.reset_flags[k];        // freqdem_reset: previous sample = 0 -> arg(0) = 0
-        q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = rst ? 0.f : pmr_arg(im, re) * q.fm_ref;
-        if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
+    // compile-time trip count (guarded): the arg() chains of a thread's elements are independent and interleave -- as a loop
+    // bounded by nnew * M they ran one after the other
+    constexpr unsigned NW = ((FPW - 1) * M + 255) / 256;
+#pragma unroll
+    for (unsigned u = 0; u < NW; u++) {
+        const unsigned wi = tid + 256u * u;
+        if (wi < nnew * M) {
+            const unsigned f = wi / M, k = wi % M;
+            const cf pv = Y[f * M + k], cu = Y[(f + 1) * M + k];
+            const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
+            const unsigned t = row0 + f;                         // frame relative to frame0
+            q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = pmr_arg(im, re) * q.fm_ref;
+            if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
+        }
+    }
+    if (row0 == 0 && q.reset_flags && nnew) {                    // freqdem_reset: previous sample = 0 -> arg(0) = 0, flagged channels'
+        for (unsigned k = tid; k < M; k += 256)                  //  first output of the call (element (0, k) was written by thread k % 256)
+            if (q.reset_flags[k]) q.fm[((unsigned long long)q.frame0 & q.fm_mask) * M + k] = 0.f;
     }
     if (q.rssi_part) {
         for (unsigned k = tid; k < M; k += 256) {
@@ -279,14 +289,25 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
     // ---- discriminator, tap-off, RSSI partial sums (k_fft_disc's epilogue) ----
     cf *__restrict__ chan_out = (cf *)q.chan_out;
     const unsigned nnew = R0 >= ns ? 0u : min((unsigned)PF_G, ns - R0);
-    for (unsigned wi = tid; wi < nnew * M; wi += 256) {
-        const unsigned f = wi / M, k = wi % M;
-        const cf pv = A[f * M + k], cu = A[(f + 1) * M + k];
-        const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
-        const unsigned t = R0 + f;
-        const bool rst = t == 0 && q.reset_flags && q.reset_flags[k];
-        q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = rst ? 0.f : pmr_arg(im, re) * q.fm_ref;
-        if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
+    {
+        // thread = channel: the frame before is the previous iteration's `cu`; fixed trip count, so the eight arg() chains interleave
+        const unsigned k = (unsigned)tid;
+        cf pv = A[k];
+#pragma unroll
+        for (unsigned f = 0; f < (unsigned)PF_G; f++) {
+            const cf cu = A[(f + 1) * M + k];
+            if (f < nnew) {
+                const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
+                const unsigned t = R0 + f;
+                q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = pmr_arg(im, re) * q.fm_ref;
+                if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
+            }
+            pv = cu;
+        }
+    }
+    if (R0 == 0 && q.reset_flags && nnew) {              // freqdem_reset: arg(0) = 0 for the flagged channels' first output of the call;
+        const unsigned k = (unsigned)tid;                //  thread k wrote (frame 0, channel k) above (M = 256 threads)
+        if (q.reset_flags[k]) q.fm[((unsigned long long)q.frame0 & q.fm_mask) * M + k] = 0.f;
     }
     if (q.rssi_part) {
         const unsigned k = (unsigned)tid;
