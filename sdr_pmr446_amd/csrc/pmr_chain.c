@@ -165,7 +165,15 @@ static int fail(pmr_chain q, int code, const char *what, hipError_t e)
 {
     if (q) snprintf(q->err, sizeof(q->err), "%s%s%s", what, e != hipSuccess ? ": " : "",
                     e != hipSuccess ? hipGetErrorString(e) : "");
+    /* a runtime failure in the middle of a block leaves the stream position undefined (the host counters may be ahead of what the
+     * device did): the handle refuses further blocks until pmr_chain_reset */
+    if (q && code == PMR_EHIP && q->in_block) q->faulted = 1;
     return code;
+}
+
+static int refuse_faulted(pmr_chain q)
+{
+    return fail(q, PMR_EHIP, "an earlier block failed in the HIP runtime: the stream position is undefined, call pmr_chain_reset", hipSuccess);
 }
 
 #define HIPCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(q, PMR_EHIP, what, e_); } while (0)
@@ -833,6 +841,7 @@ int pmr_chain_reset(pmr_chain q)
     q->reset_pending = 0; memset(q->h_reset_flags, 0, M);
     HIPCHK(hipStreamSynchronize(q->stream_h2d), "reset");
     q->slot_head = 0; q->n_inflight = 0;                   /* blocks submitted but not collected are dropped */
+    q->faulted = 0; q->in_block = 0;
     for (unsigned i = 0; i < PIPE_DEPTH; i++) q->slot[i].used = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
     return PMR_OK;
@@ -1470,6 +1479,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
                                      int phase /*0: whole block; 1: up to channelizer + RSSI, audio part left pending*/)
 {
     if (!q) return PMR_EINVAL;
+    if (q->faulted) return refuse_faulted(q);
     q->rssi_job_pending = 0;
     if (phase == 1 && !single) return fail(q, PMR_EINVAL, "two-step form is synchronous", hipSuccess);
     if (q->pend_audio) {
@@ -1495,6 +1505,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     if (ns_plan > q->chan_size) return fail(q, PMR_ERANGE, "frame count exceeds max_frames", hipSuccess);
     if (ns_plan > pcm_stride && (d_pcm || d_audio || d_chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
     if (ny_plan > q->res_size) return fail(q, PMR_ERANGE, "resampled stream overflow", hipSuccess);
+    q->in_block = 1;                             /* from here on a runtime failure poisons the handle (fail()) */
 
     /* ---- front end of this block on stream_fe.  It may run while the back end of the PREVIOUS block is still
      * busy on q->stream; it must not start before the back end of the block before that has released its part
@@ -1611,6 +1622,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
     q->frames_done += ns;
     if (!single) HIPCHK(hipEventRecord(q->ev_be[par], q->stream), "record");
     q->n_calls++;
+    q->in_block = 0;
     return PMR_OK;
 }
 
