@@ -92,6 +92,7 @@ struct pmr_chain_s {
     uint64_t fm_mask;
     void *d_scratch; size_t scratch_bytes;
     float *d_rssi_part;
+    int faulted, in_block;                       /* PMR_EHIP inside a block: no further blocks until pmr_chain_reset */
     pmr_rssi_job rssi_job; int rssi_job_pending; /* RSSI finish of the block in hand, waiting to ride in the audio FIR's launch */
     size_t rssi_part_cap;
     pmr_slot slot[PIPE_DEPTH]; unsigned slot_head, n_inflight;
