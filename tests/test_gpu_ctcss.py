@@ -24,7 +24,8 @@ def _run(chain_obj, x, splits):
     CFG2 + (1300000, [1300000], None),
     CFG2 + (1300000, [400000, 1, 500000, 399999], None),          # 2441-frame Goertzel blocks straddle the calls
     CFG3 + (1 << 25, [1 << 24, 1 << 24], list(range(0, 256, 9))),
-])
+    CFG2 + (1 << 25, [(1 << 24) + 12345, (1 << 24) - 12345], None),   # > 64 Goertzel blocks per call: several blocks per workgroup
+], ids=["cfg2-one-call", "cfg2-ragged", "cfg3-2^24", "cfg2-2^24-blocks"])
 def test_ctcss_matches_oracle(fs, M, N, splits, ks):
     from sdr_pmr446_amd import chain
     x = synth.synth_iq(N, fs, M, channels=ks, dev_hz=1500.0, ctcss_dev_hz=700.0)
@@ -137,7 +138,8 @@ def test_ctcss_decisions_equal_the_references_own_detector_code():
 
 
 @pytest.mark.parametrize("cfg,k,n,splits", [(CFG2, 5, 1300000, [400000, 1, 500000, 399999]),
-                                             (CFG3, 100, 1 << 25, [1 << 24, 1 << 24])], ids=["cfg2-ch5", "cfg3-ch100"])
+                                             (CFG3, 100, 1 << 25, [1 << 24, 1 << 24]),
+                                             (CFG2, 9, 1 << 25, [1 << 25])], ids=["cfg2-ch5", "cfg3-ch100", "cfg2-ch9-72-blocks"])
 def test_ctcss_with_one_open_channel_is_the_references_mode(cfg, k, n, splits):
     """The reference runs ctcss_execute for the squelch-selected channel only (src/sdr_pmr446.c:893).  mask = {k}  <->
     OracleChain(only_channel=k): the open channel's events as in the all-channel comparison; every closed channel reports
