@@ -39,11 +39,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ int16_t pcm16_4(float y)
 {
-    const float s = y * 32767.0f;
-    if (!(s == s)) return 0;
-    if (s >= 32767.0f) return 32767;
-    if (s <= -32768.0f) return -32768;
-    return (int16_t)s;                            // truncation toward zero (src/dsd_in.c:174), saturated
+    // branch-free (four of these sit in every epilogue store): NaN -> 0, saturation by clamping, truncation toward zero by the cast
+    float s = y * 32767.0f;
+    s = s == s ? s : 0.f;
+    s = __builtin_fminf(__builtin_fmaxf(s, -32768.0f), 32767.0f);
+    return (int16_t)(int)s;                       // truncation toward zero (src/dsd_in.c:174), saturated
 }
 
 // The k loop of one wave: two 16-frame accumulators (frames 32 wave + 16 a + i of the window's tile) over `ngroups` groups of F4_GS

@@ -1,0 +1,51 @@
+"""The kernels' VGPR counts are part of the design: four front-end tiles (4 x 88 registers per SIMD) leave 160 for a back-end
+wave, so the 256-frame audio FIR must stay <= 160 and the front end <= 88 -- a build that crossed either line by five registers
+cost the cfg2 chain 8-10 % with no test failing (profiles/r03_ab_log.txt).  Cross-compiles the four units for
+gfx950 (no GPU needed) and reads the counts from the code objects' metadata."""
+import os
+import re
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "sdr_pmr446_amd", "csrc")
+HIPCC = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+
+BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, why)
+    ("pmr_fe_fast.hip", r"k_fe_fastILi0E", 88, "one-level front end: four tiles per SIMD + one 160-register back-end wave"),
+    ("pmr_fe_fast.hip", r"k_fe_fastILi1E", 64, "level 1 of the two-level front end"),
+    ("pmr_fe_fast.hip", r"k_fe_level2", 80, "level 2 runs beside four level-1 tiles"),
+    ("pmr_fir_mfma.hip", r"k_fir_mfma16ILb0ELi2ELb1ELb0ELb0E", 160, "256-frame audio FIR beside four front-end tiles (cfg2)"),
+    ("pmr_fir_mfma4.hip", r"k_fir_mfma4ILb0ELb0ELb0E", 64, "128-frame audio FIR: four workgroups per CU"),
+    ("pmr_channelize_small.hip", r"k_channelize_winILi16ELi26ELb1ELi16E", 128, "16-channel bank: four waves per SIMD"),
+    ("pmr_channelize_wide.hip", r"k_channelize_fused256ILb1E", 128, "256-channel bank: four waves per SIMD"),
+]
+
+
+def _counts(unit):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        flags = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S"] + flags +
+                              [os.path.join(CSRC, unit), "-o", out], stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    res = {}
+    for m in re.finditer(r"\.name:\s+(\S+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", txt, re.S):
+        res[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_kernels_stay_inside_their_register_budgets():
+    units = sorted({b[0] for b in BUDGET})
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        counts = dict(zip(units, ex.map(_counts, units)))
+    for unit, pat, limit, why in BUDGET:
+        hits = {k: v for k, v in counts[unit].items() if re.search(pat, k)}
+        assert hits, (unit, pat)
+        for name, (vgpr, spill) in hits.items():
+            assert spill == 0, (name, "spills")
+            assert vgpr <= limit, "%s uses %d VGPRs, budget %d (%s)" % (name, vgpr, limit, why)
