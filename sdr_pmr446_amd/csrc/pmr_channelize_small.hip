@@ -253,37 +253,47 @@ __global__ __launch_bounds__(CS_NT) void k_channelize_small(pmr_chan_params q)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Second mapping for M = 16 (the default): sliding-window filter bank + per-frame register FFT.
-//   pass 1  thread = (channel c, group of 16 consecutive frames): the 26 branch taps sit in registers, the group's
-//           16 + 25 input rows are read straight from the resampled ring (16 lanes = one 128-byte row; the NCO phase of
-//           a (c, row) pair has period 2 rows), every sample is loaded and mixed ONCE and feeds up to 16 frames.
-//           No staging pass, no sample window in LDS: X[frame][c] (36 KB per 256-frame tile) is all the LDS there is,
-//           so four tiles fit a CU where the two-frames-per-thread kernel above fits two.
-//   pass 2  thread = frame: FFT-16 in registers, previous frame through LDS, discriminator, stores (as above).
+// Second mapping for M = 16 (the default): staged window + sliding-window filter bank + per-frame register FFT.
+//   pass 0  the tile's NFT + 25 input rows go from the resampled ring to LDS ONCE: 8-byte coalesced loads (a wave = four 128-byte
+//           rows), the front end's dc carry subtracted (FIX) and the NCO factor applied on the way -- 17.6 samples per thread.
+//           (Round 3's first form read the rows straight from the ring in pass 1: every sample was loaded, corrected and mixed by
+//           each of the 2.6 threads that use it -- the carry arithmetic alone was 37 % of the kernel's vector instructions.)
+//   pass 1  thread = (channel c, group of F consecutive frames): the 26 branch taps sit in registers, the group's F + 25 rows
+//           come from LDS (row pitch 17: the four groups of a wave meet both bank halves), every sample feeds up to F frames.
+//           The bank outputs X[frame][c] then OVERWRITE the staged rows (barrier in between): 36 KB + the carry tables, four
+//           tiles per CU -- which is why a tile is 15 x 16 = 240 frames, not 256.
+//   pass 2  thread = frame: FFT-16 in registers, previous frame through LDS, discriminator, stores.
 // Same products and the same oldest-first accumulation order as k_channelize_small / the oracle.
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef CW_NT
-#define CW_NT 256                         /* threads = frames per tile (LDS 36 B x CW_NT).  cfg2, all channels: 128 (fits beside four front-end
-                                             tiles) 338 GS/s, 256: 346, 512: 351, 768: 350, 1024: 348 -- but with ONE open channel 512 costs
-                                             17 % (350 vs 424 GS/s) and 3 us at the reference point: 256 stays */
+#define CW_NT 256                         /* threads per tile */
 #endif
 #define CW_F 16                          /* frames per (channel, group) work item: big blocks */
 #define CW_F_SMALL 4                     /* ... blocks of a few thousand frames (the reference's 100 000-sample blocks: 1220 frames): 63-frame
                                             tiles, 20 workgroups instead of 5, a third of the serial work per thread */
+template <int F> struct cw_geom {
+    static constexpr int NG = F == CW_F ? CW_NT / 16 - 1 : CW_NT / 16;       // (channel, group) groups per tile
+    static constexpr int NFT = NG * F;                                       // frames per tile (local frame 0 = frame t0 - 1, recomputed)
+    static constexpr int NR = NFT + 26 - 1;                                  // staged rows
+    static constexpr int SS = 16 + 1, FS = 16 + 2;                           // pitches (cf) of the staged rows / the X rows
+    static constexpr int LDS_CF = NR * SS > NFT * FS ? NR * SS : NFT * FS;
+};
 
-// FIX: the front end's dc carry is subtracted from the samples as they are loaded (pmr_carry_fix / pmr_carry_load.hpp): a thread's
-// rows are 16 outputs apart, i.e. M * step / 2^24 ~ 24 decimated samples -- less than a tile (NOV = 1 compare-and-subtract per row).
+// FIX: the front end's dc carry is subtracted from the samples as they are staged (pmr_carry_fix / pmr_carry_load.hpp): a thread's
+// samples are CW_NT = 256 outputs apart, i.e. 16 frames ~ 400 decimated samples at cfg2 -- less than two front-end tiles (NOV = 2).
 // (Letting the workgroup that finishes last also reduce the tiles' RSSI partial sums -- a launch less for the small synchronous
 // calls -- was measured: the device-scope fences it needs cost 6 us, the separate k_rssi_finish launch 4.6.)
 template <int M, int P, bool FIX, int F>
 __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) void k_channelize_win(pmr_chan_params q)
 {
+    static_assert(M == 16 && P == 26, "geometry (cw_geom) is written for the PMR446 bank");
     constexpr int L2M = log2c<M>::v;
-    constexpr int FS = M + 2;                             // padded frame row in LDS (cf elements)
-    constexpr int NFT = (CW_NT / M) * F;                  // frames per tile; local frame 0 = frame t0-1 (recomputed)
-    static_assert(CW_NT % M == 0 && NFT <= CW_NT, "pass 2 gives every frame of the tile a thread");
+    typedef cw_geom<F> G;
+    constexpr int FS = G::FS, SS = G::SS, NFT = G::NFT, NR = G::NR, NG = G::NG;
+    static_assert(CW_NT % M == 0 && NFT <= CW_NT && (CW_NT % (2 * M)) == 0, "pass 2 gives every frame a thread; one NCO factor per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf *Xs = reinterpret_cast<cf *>(smem);                // [NFT][FS]
+    cf *Ss = reinterpret_cast<cf *>(smem);                // [NR][SS] staged, corrected, mixed samples
+    cf *Xs = Ss;                                          // [NFT][FS] bank outputs, over them
     const cf *__restrict__ xr = (const cf *)q.xr;
     const cf *__restrict__ nco_cs = (const cf *)q.nco_cs;
     const cf *__restrict__ fft_tw = (const cf *)q.fft_tw;
@@ -292,72 +302,82 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
     const int tid = threadIdx.x;
     const unsigned wg = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
     const long t0 = (long)wg * (NFT - 1);                 // first NEW frame of this tile, relative to q.frame0
+    const long long fb = (long long)q.frame0 + t0 - (long long)P;      // absolute frame of staged row 0
     pmr_carry_lds ct;
     if constexpr (FIX) {
-        // tables behind the X rows; the lowest sample of the tile is (frame0 + t0 - P) * M
-        ct = pmr_carry_setup<CW_NT>(q.fix, reinterpret_cast<float *>(Xs + NFT * FS),
-                                    ((long long)q.frame0 + t0 - (long long)P) * M - (long long)q.fix.pos0, tid);
+        ct = pmr_carry_setup<CW_NT>(q.fix, reinterpret_cast<float *>(Ss + G::LDS_CF), fb * M - (long long)q.fix.pos0, tid);
         __syncthreads();
     }
 
-    // ---- pass 1: polyphase bank, X[f][brev(c)] ----
+    // ---- pass 0: ring -> (carry fix) -> NCO mix -> LDS, sample i = tid + CW_NT * it of the tile's NR * M ----
     {
-        const unsigned c = tid & (M - 1), f0 = (tid >> L2M) * F;
-        // sample of (local frame f0 + r - P ... ) : absolute frame of row r is frame0 + t0 - 1 - (P - 1) + f0 + r  (k = 0 oldest)
-        const long long fbase = (long long)q.frame0 + t0 - (long long)P + f0;
-        float h[P];
-#pragma unroll
-        for (int k = 0; k < P; k++) h[k] = q.taps_t[k * M + c];
-        cf acc[F];
-#pragma unroll
-        for (int f = 0; f < F; f++) acc[f] = cfm(0.f, 0.f);
-        const unsigned a0 = (unsigned)((unsigned long long)fbase * (unsigned long long)M) + c, xr_mask32 = (unsigned)q.xr_mask;
-        // the NCO table's period divides 2 M (launcher), so a thread meets two factors: one on even rows of its window, one on odd rows
-        const cf cs_e = nco_cs[a0 & nco_mask], cs_o = nco_cs[(a0 + M) & nco_mask];
+        constexpr int NIT = (NR * M + CW_NT - 1) / CW_NT, CB = 6;
+        // low 32 bits of the absolute sample index are all the ring / NCO masks need; indices before the stream start wrap into the
+        // zero-initialised top of the ring.  CW_NT is a multiple of the NCO table's period (launcher): one factor per thread
+        const unsigned a0 = (unsigned)((unsigned long long)fb * (unsigned long long)M) + (unsigned)tid, xr_mask32 = (unsigned)q.xr_mask;
+        const cf cs = nco_cs[a0 & nco_mask];
         pmr_carry_state cst;
-        const unsigned long long dph = (unsigned long long)M * q.fix.step;
-        if constexpr (FIX) cst = pmr_carry_init(q.fix, ct, fbase * (long long)M + (long long)c - (long long)q.fix.pos0);
-        // rows in chunks of CW_RB: the chunk's loads are issued together, then its MACs; the scheduling barrier keeps the
-        // compiler from hoisting all 41 row loads (and their NCO factors) to the top, which costs > 128 registers
-        constexpr int CW_RB = 8;
+        const unsigned long long dph = (unsigned long long)CW_NT * q.fix.step;
+        if constexpr (FIX) cst = pmr_carry_init(q.fix, ct, fb * (long long)M + (long long)tid - (long long)q.fix.pos0);
 #pragma unroll
-        for (int r0 = 0; r0 < F + P - 1; r0 += CW_RB) {
-            cf xm[CW_RB];
+        for (int i0 = 0; i0 < NIT; i0 += CB) {
+            cf v[CB];
 #pragma unroll
-            for (int u = 0; u < CW_RB; u++) {
-                const int r = r0 + u;
-                if (r < F + P - 1) {
-                    // low 32 bits of the absolute sample index (fbase + r) * M + c are all the ring / NCO masks need; indices
-                    // before the stream start wrap into the zero-initialised top of the ring, as in k_channelize
-                    const unsigned a = a0 + (unsigned)r * M;
-                    const float2 v = reinterpret_cast<const float2 *>(xr)[a & xr_mask32];
-                    xm[u] = cfm(v.x, v.y);
+            for (int u = 0; u < CB; u++) {
+                const int it = i0 + u;
+                if (it < NIT) {
+                    const float2 w = reinterpret_cast<const float2 *>(xr)[(a0 + (unsigned)(CW_NT * it)) & xr_mask32];
+                    v[u] = cfm(w.x, w.y);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);            // the chunk's loads stay together, ahead of everything that consumes them
 #pragma unroll
-            for (int u = 0; u < CW_RB; u++) {
-                const int r = r0 + u;
-                if (r < F + P - 1) {
-                    cf x = xm[u];
-                    if constexpr (FIX) x = pmr_carry_apply<1>(q.fix, ct, cst, x, M, dph);
-                    const cf cs = (r & 1) ? cs_o : cs_e;
-                    xm[u] = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));   // x * conj(e^{j theta})
-#pragma unroll
-                    for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < F - 1 ? r : F - 1); f++)
-                        acc[f] = cfma(h[r - f], xm[u], acc[f]);
+            for (int u = 0; u < CB; u++) {
+                const int it = i0 + u;
+                if (it < NIT) {
+                    cf x = v[u];
+                    if constexpr (FIX) x = pmr_carry_apply<2>(q.fix, ct, cst, x, CW_NT, dph);
+                    x = cfm(fmaf(x.x, cs.x, x.y * cs.y), fmaf(x.y, cs.x, -(x.x * cs.y)));       // x * conj(e^{j theta})
+                    const int i = tid + CW_NT * it;
+                    if (CW_NT * (it + 1) <= NR * M || i < NR * M) Ss[(i >> L2M) * SS + (i & (M - 1))] = x;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const unsigned rc = brev_rt(c, L2M);
+    }
+    __syncthreads();
+
+    // ---- pass 1: polyphase bank, X[f][brev(c)] ----
+    {
+        const unsigned c = tid & (M - 1), g = tid >> L2M, f0 = g * F;
+        const bool work = NG * M == CW_NT || g < (unsigned)NG;
+        cf acc[F];
 #pragma unroll
-        for (int f = 0; f < F; f++) Xs[(f0 + f) * FS + rc] = acc[f];
+        for (int f = 0; f < F; f++) acc[f] = cfm(0.f, 0.f);
+        if (work) {
+            float h[P];
+#pragma unroll
+            for (int k = 0; k < P; k++) h[k] = q.taps_t[k * M + c];
+            const cf *row = Ss + (size_t)f0 * SS + c;     // staged row f0 + r <-> frame t0 - 1 - (P - 1) + f0 + r  (k = 0 oldest)
+#pragma unroll
+            for (int r = 0; r < F + P - 1; r++) {
+                const cf x = row[r * SS];
+#pragma unroll
+                for (int f = (r - P + 1 > 0 ? r - P + 1 : 0); f <= (r < F - 1 ? r : F - 1); f++)
+                    acc[f] = cfma(h[r - f], x, acc[f]);
+            }
+        }
+        __syncthreads();                                  // every staged row has been read: the X rows go over them
+        if (work) {
+            const unsigned rc = brev_rt(c, L2M);
+#pragma unroll
+            for (int f = 0; f < F; f++) Xs[(f0 + f) * FS + rc] = acc[f];
+        }
     }
     __syncthreads();
 
     // ---- pass 2: thread = local frame tid; FFT in registers ----
-    const bool mine = NFT == CW_NT || tid < NFT;          // small tiles: the first NFT threads own a frame
+    const bool mine = NFT == CW_NT || tid < NFT;          // the first NFT threads own a frame
     cf Y[M];
     {
         const cf *row = Xs + (size_t)(mine ? tid : 0) * FS;
@@ -437,14 +457,15 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
     const bool win = !pair && p->p == 26 && (2u * p->M) % p->nco_period == 0;
     /* few frames: 4 instead of 16 frames per (channel, group) item -- more, shorter workgroups (latency of the synchronous calls) */
     const bool fine = win && p->ns < 16u * CW_NT;
-    const unsigned nft = fine ? (CW_NT / 16) * CW_F_SMALL : CW_NT;
+    const unsigned nft = fine ? (unsigned)cw_geom<CW_F_SMALL>::NFT : (unsigned)cw_geom<CW_F>::NFT;
     const unsigned ntiles = win ? (p->ns + nft - 2) / (nft - 1) : pmr_channelize_small_tiles(p->ns);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
     if (p->M != 16) return (int)hipErrorInvalidValue;
     if (win) {
         const bool fix = p->fix.V != nullptr;
-        const size_t lds_w = (size_t)nft * (16 + 2) * sizeof(cf) + (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
+        const size_t lds_w = (size_t)(fine ? cw_geom<CW_F_SMALL>::LDS_CF : cw_geom<CW_F>::LDS_CF) * sizeof(cf) +
+                             (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
         hipStream_t st = (hipStream_t)s;
         static pmr_attr_flags attr_w{0};
         if (lds_w > 64 * 1024 && pmr_attr_needed(attr_w)) {      /* only -DCW_NT=1024 experiment builds get here */

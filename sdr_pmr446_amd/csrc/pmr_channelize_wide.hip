@@ -374,14 +374,15 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
 extern "C" int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco_period, int chan_small, int chan_wide, int pair,
                                             int unfused, unsigned adv_q, unsigned TQ)
 {
-    if (chan_small) return M == 16 && p == 26 && !pair && nco_period && 32u % nco_period == 0 && adv_q < TQ;   /* k_channelize_win<16, 26, true>: NOV = 1 */
+    /* k_channelize_win<16, 26, true>: a thread's staged samples are 256 outputs = 16 frames apart, NOV = 2 */
+    if (chan_small) return M == 16 && p == 26 && !pair && nco_period && 32u % nco_period == 0 && 16u * adv_q < 2u * TQ;
     if (chan_wide) return M == 256 && p == PW_P && !unfused && adv_q < 2 * TQ;         /* k_channelize_fused256<true>: NOV = 2 */
     return 0;
 }
 
 extern "C" unsigned pmr_channelize_carry_nv(unsigned M, unsigned adv_q, unsigned TQ)
 {
-    /* frames a workgroup stages: M = 16: 256 + 25 rows (k_channelize_win); M = 256: 9 + 25 rows */
+    /* frames a workgroup stages: M = 16: up to 256 + 25 rows (k_channelize_win: 240 + 25); M = 256: 9 + 25 rows */
     const unsigned rows = M == 16 ? 256u + 26u : (unsigned)(PF_G + 1 + PW_P);
     return (rows * adv_q) / TQ + 3u;
 }
