@@ -20,7 +20,7 @@ BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, w
     ("pmr_fe_fast.hip", r"k_fe_level2", 80, "level 2 runs beside four level-1 tiles"),
     ("pmr_fir_mfma.hip", r"k_fir_mfma16ILb0ELi2ELb1ELb0ELb0E", 160, "256-frame audio FIR beside four front-end tiles (cfg2)"),
     ("pmr_fir_mfma4.hip", r"k_fir_mfma4ILb0ELb0ELb0E", 64, "128-frame audio FIR: four workgroups per CU"),
-    ("pmr_channelize_small.hip", r"k_channelize_winILi16ELi26ELb1ELi16E", 128, "16-channel bank: four waves per SIMD"),
+    ("pmr_channelize_small.hip", r"k_channelize_winILi16ELi26ELb1ELi16E", 88, "16-channel bank: a wave fits beside four front-end tiles with room to spare"),
     ("pmr_channelize_wide.hip", r"k_channelize_fused256ILb1E", 128, "256-channel bank: four waves per SIMD"),
 ]
 
