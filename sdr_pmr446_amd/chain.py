@@ -362,6 +362,19 @@ def asgram_ascii(psd_db, nfft, n_transforms, ref=-40.0, div=2.0):
     return buf.raw[:int(nfft)].decode("ascii"), pv.value, pf.value
 
 
+class _PinnedBlock:
+    """Owner of one pmr_host_alloc range: rides on the ctypes buffer the numpy views are made of."""
+
+    def __init__(self, L, p):
+        self.L, self.p = L, p
+
+    def __del__(self):
+        try:
+            self.L.pmr_host_free(self.p)
+        except Exception:
+            pass
+
+
 class PmrChain:
     """One IQ stream on one GPU: pmr_chain_create / process_block / reset / destroy."""
 
@@ -404,9 +417,6 @@ class PmrChain:
         if getattr(self, "h", None):
             self._L.pmr_chain_destroy(self.h)
             self.h = None
-            for p in getattr(self, "_pinned", []):
-                self._L.pmr_host_free(p)
-            self._pinned = []
 
     def __del__(self):
         try:
@@ -515,14 +525,15 @@ class PmrChain:
         return out
 
     def pinned_array(self, n, dtype=np.complex64):
-        """numpy view of n elements of memory pinned in the library's HIP runtime (pmr_host_alloc); freed with the chain."""
+        """numpy view of n elements of memory pinned in the library's HIP runtime (pmr_host_alloc).  The memory lives as long as
+        any view of it does (it is NOT freed by close(): a view kept beyond the chain stays valid)."""
         nbytes = int(n) * np.dtype(dtype).itemsize
         p = self._L.pmr_host_alloc(nbytes)
         if not p:
             raise PmrError("pmr_host_alloc failed")
-        self._pinned = getattr(self, "_pinned", [])
-        self._pinned.append(p)
-        return np.frombuffer((C.c_char * nbytes).from_address(p), dtype=dtype)
+        buf = (C.c_char * nbytes).from_address(p)
+        buf._pmr_owner = _PinnedBlock(self._L, p)          # freed when the last view of `buf` is gone
+        return np.frombuffer(buf, dtype=dtype)
 
     # -- device-buffer entry point (bench / zero-copy callers) ----------------------------------
     def process_block_device(self, d_iq, n_in, d_pcm=None, d_audio=None, stride=None, d_chan=None, d_rssi=None):
