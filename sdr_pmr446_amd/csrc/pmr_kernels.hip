@@ -764,13 +764,17 @@ extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, un
  * the plan is 16 channels with big blocks: there the 32x32x2 kernel's 256-frame, two-tiles-per-workgroup form is faster IN THE
  * CHAIN (cfg2: 376 vs 345 GS/s on one box; see the header of pmr_fir_mfma4.hip), while blocks of a few thousand frames (the
  * reference's 100 000-sample blocks: 1220) want the finer tiles (10 workgroups instead of 5).  PMR_FIR_MFMA=4 / =32 force one. */
-static bool fir_use_mfma4(const pmr_switches *sw, unsigned M, unsigned ntaps, unsigned ns, const unsigned *chan_list, unsigned n_chan)
+static bool fir_use_mfma4(const pmr_switches *sw, unsigned M, unsigned ntaps, unsigned ns, const unsigned *chan_list, unsigned n_chan,
+                          bool dual = false)
 {
     if (!pmr_fir_mfma4_supported(M, ntaps) || sw->fir_mfma32) return false;
     if (sw->fir_mfma4 || !pmr_fir_mfma_supported(M, ntaps)) return true;
     /* open-channel mask: a workgroup takes 16 (channel, segment) units whatever their length, so few open channels want the SHORT
      * segments -- twice the workgroups, half the serial work each (one open channel at cfg2: 171 workgroups instead of 86) */
     if (chan_list && (unsigned long long)n_chan * ((ns + 255u) / 256u) < 16ull * 1024ull) return true;
+    /* two tap sets in one pass (CTCSS on): the 32x32x2 kernel then has registers for ONE tile per workgroup only and is the slower
+     * one in the chain too (cfg2, detector on, all channels: 254 vs 247 GS/s) */
+    if (dual) return true;
     return !(M == 16 && ns >= 65536);
 }
 
@@ -779,7 +783,7 @@ extern "C" int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const
                                    unsigned stride, float *out2_tm, const unsigned *chan_list, unsigned n_chan)
 {
     if (sw->fir_mode != PMR_FIR_MFMA || sw->fir_mfma_global) return -1;
-    if (fir_use_mfma4(sw, M, ntaps, ns, chan_list, n_chan))
+    if (fir_use_mfma4(sw, M, ntaps, ns, chan_list, n_chan, true))
         return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan, taps2_pad, out2_tm,
                                     nullptr, nullptr);
     if (!pmr_fir_mfma_supported(M, ntaps)) return -1;
