@@ -70,6 +70,9 @@ struct pmr_chain_s {
     hipEvent_t input_ready; int has_input_ready;   /* caller's "d_iq is complete" event for the NEXT device-entry call */
     hipStream_t stream_h2d;          /* input copies of the asynchronous host-buffer pair: H2D of block b+1 under the kernels of block b */
     hipEvent_t ev_fe[PIPE_DEPTH], ev_be[PIPE_DEPTH];   /* front end / back end of block (n mod PIPE_DEPTH) finished     */
+    /* CTCSS detector of pipelined calls on a stream of its own: four launch-latency-bound kernels that only the NEXT block's
+     * detector waits for -- behind them on the back-end stream, the next block's carry / channelizer / FIR waited too */
+    hipStream_t stream_ct; hipEvent_t ev_ct[PIPE_DEPTH], ev_ctlp; int ct_ev_used[PIPE_DEPTH], ct_async_last; unsigned ct_last_par, cur_par; int cur_single;
     int overlap;                     /* two-stream pipelining enabled (PMR_OVERLAP=0 disables)                     */
     uint64_t n_calls;
     unsigned M, res_size, chan_size;
@@ -681,6 +684,7 @@ static void read_switches(pmr_switches *w)
     w->no_overlap = env_is("PMR_OVERLAP", "0");
     w->be_prio = env_is("PMR_STREAM_PRIO", "1") ? 1 : env_is("PMR_STREAM_PRIO", "fe") ? 2 : env_is("PMR_STREAM_PRIO", "0") ? 3 : 0;
     w->host_gate = !env_is("PMR_HOST_GATE", "0");
+    w->ct_no_async = env_is("PMR_CT_STREAM", "0");
     w->fe_marker = env_is("PMR_FE_EVENT", "marker");
     w->tf_on_be = env_is("PMR_TILEFIX_STREAM", "be") ? 1 : env_is("PMR_TILEFIX_STREAM", "fe") ? 2 : 0;
     w->carry_inplace = env_is("PMR_CARRY", "inplace");
@@ -747,9 +751,12 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
     }
     if (hipEventCreateWithFlags(&q->ev_switch, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&q->stream_h2d, hipStreamNonBlocking) != hipSuccess) { pmr_design_free(&q->d); free(q); return NULL; }
+    if (hipStreamCreateWithPriority(&q->stream_ct, hipStreamNonBlocking, prio_base) != hipSuccess ||
+        hipEventCreateWithFlags(&q->ev_ctlp, hipEventDisableTiming) != hipSuccess) { pmr_design_free(&q->d); free(q); return NULL; }
     q->sfe = q->stream_fe;
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
         if (hipEventCreateWithFlags(&q->ev_fe[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&q->ev_ct[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q->ev_be[i], hipEventDisableTiming) != hipSuccess) {
             pmr_design_free(&q->d); free(q); return NULL;
         }
@@ -770,7 +777,9 @@ int pmr_chain_destroy(pmr_chain q)
     if (q->stream_fe) hipStreamSynchronize(q->stream_fe);
     if (q->stream) hipStreamSynchronize(q->stream);
     prof_resolve(q);
-    for (unsigned i = 0; i < PIPE_DEPTH; i++) { if (q->ev_fe[i]) hipEventDestroy(q->ev_fe[i]); if (q->ev_be[i]) hipEventDestroy(q->ev_be[i]); }
+    for (unsigned i = 0; i < PIPE_DEPTH; i++) { if (q->ev_fe[i]) hipEventDestroy(q->ev_fe[i]); if (q->ev_be[i]) hipEventDestroy(q->ev_be[i]); if (q->ev_ct[i]) hipEventDestroy(q->ev_ct[i]); }
+    if (q->ev_ctlp) hipEventDestroy(q->ev_ctlp);
+    if (q->stream_ct) { hipStreamSynchronize(q->stream_ct); hipStreamDestroy(q->stream_ct); }
     if (q->ev_switch) hipEventDestroy(q->ev_switch);
     if (q->stream_h2d) { hipStreamSynchronize(q->stream_h2d); hipStreamDestroy(q->stream_h2d); }
     if (q->stream_fe) hipStreamDestroy(q->stream_fe);
@@ -816,6 +825,9 @@ int pmr_chain_reset(pmr_chain q)
      * nothing may overwrite the zeroed state afterwards */
     HIPCHK(hipStreamSynchronize(q->stream_fe), "reset");
     HIPCHK(hipStreamSynchronize(q->stream), "reset");
+    HIPCHK(hipStreamSynchronize(q->stream_ct), "reset");
+    for (unsigned i = 0; i < PIPE_DEPTH; i++) q->ct_ev_used[i] = 0;
+    q->ct_async_last = 0;
     HIPCHK(hipMemsetAsync(q->d_dc_state, 0, sizeof(cfl), q->stream), "reset");
     for (unsigned e = 0; e <= h; e++)
         HIPCHK(hipMemsetAsync(q->d_z[e], 0, (size_t)q->keep[e] * sizeof(cfl), q->stream), "reset");
@@ -878,6 +890,7 @@ int pmr_chain_synchronize(pmr_chain q)
     if (!q) return PMR_EINVAL;
     HIPCHK(hipStreamSynchronize(q->stream_fe), "hipStreamSynchronize");
     HIPCHK(hipStreamSynchronize(q->stream), "hipStreamSynchronize");
+    HIPCHK(hipStreamSynchronize(q->stream_ct), "hipStreamSynchronize");
     prof_resolve(q);
     return PMR_OK;
 }
@@ -1216,10 +1229,25 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
     const unsigned nblk = (unsigned)((f1 - 1) / N - f0 / N + 1), ncomplete = (unsigned)(f1 / N - f0 / N);
     if (ncomplete > q->ct_max_ev) return fail(q, PMR_ERANGE, "ctcss events", hipSuccess);
     const int cur = q->ct_sel, nxt = cur ^ 1;
+    /* pipelined calls: the detector's four kernels run on their own stream behind this block's low-pass branch; only the next
+     * block's detector (same stream) and the ring-reuse gate wait for them */
+    const int async = !q->cur_single && !q->sw.ct_no_async && !q->dbg_on;
+    hipStream_t sct = async ? q->stream_ct : q->stream;
+    if (async) {
+        HIPCHK(hipEventRecord(q->ev_ctlp, q->stream), "record");
+        HIPCHK(hipStreamWaitEvent(q->stream_ct, q->ev_ctlp, 0), "wait low-pass branch");
+    } else if (q->ct_async_last) {                                /* the previous block's detector state comes first */
+        HIPCHK(hipStreamWaitEvent(q->stream, q->ev_ct[q->ct_last_par], 0), "wait detector");
+    }
     /* (k_ct_final writes every open channel's carry for the next call, zeros when the call ends on a block boundary) */
-    LAUNCH(K_CT_GOERTZEL, pmr_launch_ct_detector(q->stream, q->d_ctlp, q->fm_mask, frame0, ns, M, N, a1, q->d_ct_lampow, q->d_ct_dcstate,
+    LAUNCH_ON(sct, K_CT_GOERTZEL, pmr_launch_ct_detector(sct, q->d_ctlp, q->fm_mask, frame0, ns, M, N, a1, q->d_ct_lampow, q->d_ct_dcstate,
                                                  q->d_ct_agg, q->d_ct_W, q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[cur],
                                                  q->d_ct_carry[nxt], q->d_ct_events, nblk, ncomplete, sel, q->n_enabled));
+    if (async) {
+        HIPCHK(hipEventRecord(q->ev_ct[q->cur_par], q->stream_ct), "record");
+        q->ct_ev_used[q->cur_par] = 1; q->ct_last_par = q->cur_par;
+    }
+    q->ct_async_last = async;
     q->ct_sel = nxt;
     q->ct_nev_last = ncomplete;
     return PMR_OK;
@@ -1481,6 +1509,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
 {
     if (!q) return PMR_EINVAL;
     if (q->faulted) return refuse_faulted(q);
+    q->cur_single = single;
     q->rssi_job_pending = 0;
     if (phase == 1 && !single) return fail(q, PMR_EINVAL, "two-step form is synchronous", hipSuccess);
     if (q->pend_audio) {
@@ -1512,6 +1541,7 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
      * busy on q->stream; it must not start before the back end of the block before that has released its part
      * of the rings (they hold history + PIPE_DEPTH blocks). ---- */
     const unsigned par = (unsigned)(q->n_calls % PIPE_DEPTH);
+    q->cur_par = par;
     q->sfe = single ? q->stream : q->stream_fe;
     if (!single) {
         if (q->last_single && q->n_calls) {      /* everything the single-stream calls queued on q->stream comes first */
@@ -1525,7 +1555,14 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
             if (q->sw.host_gate) HIPCHK(hipEventSynchronize(q->ev_be[par]), "wait back end");
             else HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
         }
+        if (q->ct_ev_used[par]) {                /* ... and its CTCSS detector (own stream): it reads the low-pass ring's rows */
+            q->ct_ev_used[par] = 0;
+            if (q->sw.host_gate) HIPCHK(hipEventSynchronize(q->ev_ct[par]), "wait detector");
+            else HIPCHK(hipStreamWaitEvent(q->stream, q->ev_ct[par], 0), "wait detector");
+        }
     }
+    if (single && q->ct_async_last)              /* pipelined calls' detectors (own stream) still read the rings this call writes */
+        HIPCHK(hipStreamWaitEvent(q->stream, q->ev_ct[q->ct_last_par], 0), "wait detector");
     q->last_single = single;
     if (q->has_input_ready) {                    /* the caller's producer of d_iq finishes first (pmr_chain_wait_input_event) */
         q->has_input_ready = 0;
@@ -1953,6 +1990,7 @@ int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned
     for (unsigned k = 0; k < M; k++) if (mask_words[k >> 6] >> (k & 63) & 1ull) list[n++] = k;
     /* the list is read by kernels of calls already queued: let them finish before it changes */
     hipError_t e = hipStreamSynchronize(q->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(q->stream_ct);          /* the detector reads the list too */
     if (e == hipSuccess && n) e = hipMemcpy(q->d_chan_list, list, (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice);
     if (e == hipSuccess && q->d_ct_carry[0]) {
         /* ctcss_detector_reset of the channels that open now (:867): their partial Goertzel sums were frozen while closed */
@@ -1987,6 +2025,7 @@ int pmr_chain_reset_channel(pmr_chain q, unsigned channel)
     q->reset_pending = 1;
     if (q->d_ct_carry[0]) {
         HIPCHK(hipStreamSynchronize(q->stream), "reset channel");
+        HIPCHK(hipStreamSynchronize(q->stream_ct), "reset channel");
         for (int i = 0; i < 2; i++)
             HIPCHK(hipMemset((char *)q->d_ct_carry[i] + (size_t)channel * PMR_CT_TONES * 2 * sizeof(float), 0,
                              (size_t)PMR_CT_TONES * 2 * sizeof(float)), "reset channel");

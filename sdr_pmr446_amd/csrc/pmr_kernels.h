@@ -35,6 +35,7 @@ typedef struct {
     int no_overlap;         /* PMR_OVERLAP=0                                                                */
     int be_prio;            /* PMR_STREAM_PRIO: unset = equal priorities, "1" = 1 back end high (round-1 default), "fe" = 2 front end high */
     int host_gate;          /* default on; PMR_HOST_GATE=0: ring-reuse gating by a wait packet on the front-end stream */
+    int ct_no_async;        /* PMR_CT_STREAM=0: the CTCSS detector's kernels stay on the back-end stream (default: own stream, pipelined calls) */
     unsigned zc_max_in;     /* PMR_ZEROCOPY_MAX=n: largest block (samples) a synchronous call reads in place from pinned host memory */
     int no_zerocopy;        /* PMR_ZEROCOPY=0: synchronous host calls always go through the copy engines (H2D / D2H) */
     int tf_on_be;           /* PMR_TILEFIX_STREAM: unset = by load (pmr_chain.c tilefix_on_backend), "be" = 1 back-end stream, "fe" = 2 front-end stream */
