@@ -38,7 +38,7 @@ WORKLOADS = {
     "cfg5": (1.0e9, 1024, 26, 4),    # 1024-ch channelizer + demod @ 1 GS/s -- HBM-roofline config
 }
 HEADLINE = "cfg5"
-EVENT_EVERY = 8        # timed region: every 8th front-end launch carries start/stop events
+EVENT_EVERY = 8        # timed region: at least every 8th front-end launch carries start/stop events (fewer when that still gives ~24 samples)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 KERNEL_SYMBOLS = ("slot k_frontend = k_frontend_fast<MODE,N3,TAIL> (specialised cascades; MODE 1 = level 1 of the two-level "
                   "front end) or k_frontend<NT,SPT,MODE> in a rocprofv3 trace; k_fir_tm<hp> = k_fir_mfma16<...>")
@@ -229,7 +229,14 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
     # (the kernel's own begin..end) on every EVENT_EVERY-th launch: event RECORDS around every front-end launch are two
     # marker packets on the critical stream and cost 11 % of the step (cfg5: 0.146 vs 0.132 ms, tools/steps_ab.sh);
     # the full per-kernel breakdown is taken right after, outside the timed region
-    ch.profile_enable(0 if args.no_kernel_events else 1 + EVENT_EVERY)
+    n_regions = max(1, args.regions if headline or world == 1 else 1)
+    # a launch that carries events costs a marker packet on the critical stream (~1 % of the step at one in eight): thin them out
+    # to ~24 samples over the whole measurement, never denser than one in EVENT_EVERY nor sparser than one in 32
+    event_every = max(EVENT_EVERY, min(32, (n_regions * args.steps) // 24))
+    import math
+    while math.gcd(event_every, args.steps) != 1:      # ... and coprime with the region length: the sampled launch must walk through
+        event_every += 1                               # every position of a region (a region's first front end has the GPU to itself)
+    ch.profile_enable(0 if args.no_kernel_events else 1 + event_every)
 
     def run():
         n = 0
@@ -240,7 +247,7 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
 
     sync_dev = None                                   # (the Dist object knows where its MAX-reduce tensor lives)
     dts, frames = [], 0
-    for _ in range(max(1, args.regions if headline or world == 1 else 1)):
+    for _ in range(n_regions):
         dt, frames = multigpu.timed_region(run, dist, device_sync, sync_dev)
         dts.append(dt)
     ch.profile_enable(0)
@@ -283,7 +290,7 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": load_measured_traffic(name, block),
                     "avg_kernel_ms": ms / n, "launches_timed": n, "launches_per_step": launches_per_step,
-                    "events": "start/stop events carried by every %d-th launch of the kernel inside the timed regions" % EVENT_EVERY,
+                    "events": "start/stop events carried by every %d-th launch of the kernel inside the timed regions" % event_every,
                     "algorithmic_bytes_per_sample": b_alg, "algorithmic_bytes_per_launch": b_alg * block,
                     "kernel_symbols": KERNEL_SYMBOLS,
                     "kernels_ms_per_step_isolated": {k: v[0] / max(1, breakdown_steps) for k, v in sorted(prof.items())}}
