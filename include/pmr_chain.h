@@ -189,7 +189,8 @@ typedef struct { int index;        /* strongest of the 38 tones (ctcss_freqs[ind
                  float max_power, avg_power; } pmr_ctcss_event;
 int pmr_chain_ctcss_enable(pmr_chain q, int on);
 /* events of the LAST process_block call: events[k * cap + e], e < *n_events (same count for every channel).
- * Synchronises the chain's streams.                                                                       */
+ * Synchronises the chain's streams -- the detector of pipelined calls runs on an internal stream of its own, so the events
+ * are complete after this call (or pmr_chain_synchronize), not merely after work ordered behind pmr_chain_stream(). */
 int pmr_chain_ctcss_read(pmr_chain q, pmr_ctcss_event *events, unsigned cap, unsigned *n_events);
 /* frequency in Hz of tone `index` (0..37: ctcss_freqs, src/sdr_pmr446.c:138-141; what :611 stores in chain->ctcss_freq), 0 outside */
 float pmr_ctcss_freq(int index);
