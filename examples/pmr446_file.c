@@ -73,6 +73,7 @@ static int run_chan(const char *in, const char *out, double fs, unsigned M, int 
             if ((rc = pmr_chain_ctcss_read(q, ct, ct_cap, &nev))) break;
             for (unsigned e = 0; e < nev; e++) {
                 const pmr_ctcss_event *v = &ct[(size_t)only * ct_cap + e];
+                if (v->index < 0) continue;                                               /* incomplete block after (re)opening: no decision */
                 if (v->detected && !ct_on) fprintf(stderr, "Acquired CTCSS code: %d (frequency: %3.2fHz)\n", v->index + 1, pmr_ctcss_freq(v->index));
                 else if (v->detected && v->index != ct_code) fprintf(stderr, "CTCSS code change: %d (frequency: %3.2fHz)\n", v->index + 1, pmr_ctcss_freq(v->index));
                 else if (!v->detected && ct_on) fprintf(stderr, "Lost CTCSS code\n");

@@ -178,12 +178,27 @@ enum { PMR_DEBUG_RESAMPLED = 0,   /* cf32 [ny]  resampler output of the last blo
        PMR_DEBUG_CTCSS_LP = 2 };  /* f32 [ns][M] CTCSS low-pass branch delay188(x) - hp(x) (:889) of the last block (detector on) */
 int pmr_chain_debug_enable(pmr_chain q, int on);   /* capture the intermediates of subsequent blocks */
 int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes, size_t *n_bytes);
+/* TEST-ONLY poison mode, process-wide (also PMR_DEBUG_POISON=1 in the environment; returns the previous setting).  While on,
+ * every kernel launch of the library is preceded by a kernel that overwrites ALL LDS of EVERY CU with a signalling-NaN pattern,
+ * and handles created while it is on fill their scratch buffers with 0xFF bytes instead of zeros: a kernel whose result depends
+ * on bytes it did not write fails on every box.  Results are unchanged by it (tests/conftest.py runs the -m gpu tier under it);
+ * costs ~25 us per launch. */
+int pmr_debug_poison(int on);
+/* the checker's checker: n_wg workgroups copy the first `words` (<= 16384) 32-bit words of their UNINITIALISED dynamic LDS to
+ * d_out[n_wg][words] (device pointer) and the call waits for them; with the poison mode on every word reads 0x7FA0DEAD */
+int pmr_debug_lds_probe(void *d_out, unsigned words, unsigned n_wg);
 
 /* ---- CTCSS tone detection for every channel (complementary low-pass branch src/sdr_pmr446.c:884-889,
  * ctcss_execute :605-628, 38-tone Goertzel bank over 2441-sample blocks :366-409).  When enabled, every
  * process_block call also runs the detector; each Goertzel block completed by the call yields one event per channel.  With a
  * channel mask set the detector runs for the OPEN channels only (the reference calls ctcss_execute for the active channel, :893):
- * events of closed channels read {index -1, detected 0}, and a channel's partial Goertzel sums restart when it is opened. ---- */
+ * events of closed channels read {index -1, detected 0} (closed WHEN THE BLOCK RAN: a later set_channel_mask does not change
+ * what pmr_chain_ctcss_read returns for it), and a channel's partial Goertzel sums restart when it is opened or reset.
+ * Deviation from the reference, documented: the 2441-frame block GRID is the stream's, shared by all M channels, where the
+ * reference's single detector restarts its own sample count at ctcss_detector_reset (:348-357, :867).  The block in progress when
+ * a channel is opened / reset in mid-block is therefore incomplete for it and reports {-1, 0, 0, 0} ("no decision"); its first
+ * real event comes at the first grid boundary >= 2441 frames after the restart (reference: exactly 2441 frames after).  The
+ * detector's dc blocker (:606) is never reset, as in the reference. ---- */
 typedef struct { int index;        /* strongest of the 38 tones (ctcss_freqs[index], :138-141)          */
                  int detected;     /* avg power > 120 && max/avg > 10 (:403-404)                         */
                  float max_power, avg_power; } pmr_ctcss_event;

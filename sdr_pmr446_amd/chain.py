@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "pmr_chain_num_channels", "pmr_chain_last_error", "pmr_chain_process_block", "pmr_chain_process_block_f32",
     "pmr_chain_process_block_device", "pmr_chain_synchronize", "pmr_chain_set_overlap", "pmr_chain_stream", "pmr_chain_profile_enable",
     "pmr_chain_profile_reset", "pmr_chain_profile_count", "pmr_chain_profile_name", "pmr_chain_profile_get",
-    "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read",
+    "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read", "pmr_debug_poison", "pmr_debug_lds_probe",
     "pmr_cfg_info", "pmr_cfg_design", "pmr_cfg_max_frames", "pmr_cfg_plan_block",
     "pmr_squelch_init", "pmr_find_max_rssi_channel", "pmr_squelch_update",
     "pmr_chain_spectrum_enable", "pmr_chain_spectrum_read", "pmr_asgram_ascii",
@@ -151,6 +151,10 @@ def load(build_if_missing=True):
     L.pmr_chain_design.restype = u
     L.pmr_chain_debug_enable.argtypes = [vp, i]
     L.pmr_chain_debug_enable.restype = i
+    L.pmr_debug_poison.argtypes = [i]
+    L.pmr_debug_poison.restype = i
+    L.pmr_debug_lds_probe.argtypes = [vp, u, u]
+    L.pmr_debug_lds_probe.restype = i
     L.pmr_chain_debug_read.argtypes = [vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pmr_chain_debug_read.restype = i
     L.pmr_chain_submit_block.argtypes = [vp, vp, u, u]
@@ -543,6 +547,10 @@ class PmrChain:
                                                            stride if stride is not None else self.max_frames,
                                                            C.byref(ns), d_chan, d_rssi))
         return ns.value
+
+    def ctcss_enable(self, on=True):
+        """Run the CTCSS detector with every following block (pmr_chain_ctcss_enable; `want=("ctcss",)` does this implicitly)."""
+        self._check(self._L.pmr_chain_ctcss_enable(self.h, int(bool(on))))
 
     def ctcss_read(self):
         """CTCSS decisions of the Goertzel blocks completed by the last block: structured array [M][n_events]."""

@@ -109,6 +109,9 @@ struct pmr_chain_s {
     float *d_ct_taps_ext;            /* the low-pass-branch taps zero-extended to the folded audio filter's length (dual pass) */
     float *d_ctlp, *d_ct_taps, *d_ct_lampow, *d_ct_agg, *d_ct_W, *d_ct_dcstate, *d_ct_U, *d_ct_coef, *d_ct_part, *d_ct_carry[2];
     pmr_ctcss_event *d_ct_events;
+    uint8_t *d_ct_restart;           /* [M] 1: the channel's Goertzel sums were restarted inside the block in progress (reset / opened):
+                                        that block's event is reported as "no decision" (k_ct_final clears the flag)              */
+    uint8_t *ct_open_last; int ct_masked_last;   /* the mask the LAST block's detector ran under (pmr_chain_ctcss_read)           */
     unsigned hp_len_raw;             /* length of the un-folded high-pass table (377)                 */
 
     /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
@@ -169,28 +172,36 @@ static int fail(pmr_chain q, int code, const char *what, hipError_t e)
 {
     if (q) snprintf(q->err, sizeof(q->err), "%s%s%s", what, e != hipSuccess ? ": " : "",
                     e != hipSuccess ? hipGetErrorString(e) : "");
-    /* a runtime failure in the middle of a block leaves the stream position undefined (the host counters may be ahead of what the
-     * device did): the handle refuses further blocks until pmr_chain_reset */
-    if (q && code == PMR_EHIP && q->in_block) q->faulted = 1;
+    /* ANY failure in the middle of a block (q->in_block: between the first launch / counter update of a block and its last) leaves
+     * the stream position undefined -- the host counters may be ahead of what the device did, whether the cause was the HIP runtime,
+     * an allocation or a capacity check that could only be made mid-way: the handle refuses further blocks until pmr_chain_reset */
+    if (q && q->in_block) q->faulted = 1;
     return code;
 }
 
 static int refuse_faulted(pmr_chain q)
 {
-    return fail(q, PMR_EHIP, "an earlier block failed in the HIP runtime: the stream position is undefined, call pmr_chain_reset", hipSuccess);
+    return fail(q, PMR_EHIP, "an earlier block failed mid-way: the stream position is undefined, call pmr_chain_reset", hipSuccess);
 }
 
 #define HIPCHK(call, what) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(q, PMR_EHIP, what, e_); } while (0)
 
-static int dev_alloc(pmr_chain q, void **p, size_t bytes)
+/* Two kinds of device buffer.  STATE (filter histories, rings whose older indices are "the samples before the stream began",
+ * carried sums): zero is part of the algorithm -- dev_alloc_state.  SCRATCH (everything a kernel writes before another reads it):
+ * zero-filled too, so that a run is reproducible, EXCEPT in the test-only poison mode (pmr_debug_poison, pmr_poison.hip), where
+ * scratch is filled with 0xFF bytes (NaN as f32, -1 as an integer): a kernel that reads scratch nobody wrote then fails loudly
+ * instead of passing on zeros. */
+static int dev_alloc_fill(pmr_chain q, void **p, size_t bytes, int fill)
 {
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return fail(q, PMR_ENOMEM, "hipMalloc", e);
-    e = hipMemsetAsync(*p, 0, bytes, q->stream);
+    e = hipMemsetAsync(*p, fill, bytes, q->stream);
     if (e != hipSuccess) return fail(q, PMR_EHIP, "hipMemsetAsync", e);
     return PMR_OK;
 }
+static int dev_alloc(pmr_chain q, void **p, size_t bytes) { return dev_alloc_fill(q, p, bytes, pmr_debug_poison_enabled() ? 0xFF : 0); }
+static int dev_alloc_state(pmr_chain q, void **p, size_t bytes) { return dev_alloc_fill(q, p, bytes, 0); }
 
 static int dev_upload(pmr_chain q, float **p, const float *src, size_t n)
 {
@@ -412,7 +423,7 @@ static int fe_init(pmr_chain q)
         uint64_t need = (uint64_t)q->fe2_Hh + D2 + (uint64_t)PIPE_DEPTH * ((q->cfg.max_block >> s1) + 2) + 64, cap = 1;
         while (cap < need) cap <<= 1;
         q->ring1_mask = cap - 1;
-        if ((rc = dev_alloc(q, (void **)&q->d_fe_ring1, (size_t)cap * sizeof(cfl)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_fe_ring1, (size_t)cap * sizeof(cfl)))) return rc;
     }
 
     /* branch taps of all stages, execution order */
@@ -503,8 +514,8 @@ static int fe_init(pmr_chain q)
         q->fe_lam_wave = (float)pow(lam, 64.0 * spt);
     }
     for (int i = 0; i < 2; i++) {
-        if ((rc = dev_alloc(q, (void **)&q->d_fe_hist[i], (size_t)q->fe_hcap * sizeof(cfl)))) return rc;
-        if ((rc = dev_alloc(q, (void **)&q->d_fe_vstate[i], sizeof(cfl)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_fe_hist[i], (size_t)q->fe_hcap * sizeof(cfl)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_fe_vstate[i], sizeof(cfl)))) return rc;
     }
     /* probes / tile ranges: one set per block in flight (the carry kernel of block b runs on the back-end stream while the
      * front end of block b+1 is already writing its own) */
@@ -603,7 +614,7 @@ static int chain_init(pmr_chain q)
     /* state + work buffers */
     const unsigned mb = q->cfg.max_block;
     if ((rc = dev_alloc(q, (void **)&q->d_in, (size_t)mb * sizeof(cfl)))) return rc;
-    if ((rc = dev_alloc(q, (void **)&q->d_dc_state, sizeof(cfl)))) return rc;
+    if ((rc = dev_alloc_state(q, (void **)&q->d_dc_state, sizeof(cfl)))) return rc;
     const unsigned max_tiles = (mb + PMR_DC_TILE - 1) / PMR_DC_TILE + 1;
     if ((rc = dev_alloc(q, (void **)&q->d_dc_agg, (size_t)max_tiles * sizeof(cfl)))) return rc;
     if ((rc = dev_alloc(q, (void **)&q->d_dc_W, (size_t)max_tiles * sizeof(cfl)))) return rc;
@@ -611,7 +622,7 @@ static int chain_init(pmr_chain q)
         /* stage e (execution order) is design stage h-1-e; z_h feeds the arbitrary resampler */
         q->keep[e] = e < h ? 4 * d->m_stage[h - 1 - e] : ARB_KEEP;
         size_t cap = (size_t)q->keep[e] + ((size_t)mb >> e) + 2;
-        if ((rc = dev_alloc(q, (void **)&q->d_z[e], cap * sizeof(cfl)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_z[e], cap * sizeof(cfl)))) return rc;
     }
     /* rings sized for the filter history plus PIPE_DEPTH blocks, so block b+1's front end never overwrites what block b's
      * back end still reads */
@@ -619,14 +630,14 @@ static int chain_init(pmr_chain q)
         uint64_t need = (uint64_t)(p + 1) * M + (uint64_t)PIPE_DEPTH * q->res_size + 64, cap = 1;
         while (cap < need) cap <<= 1;
         q->xr_mask = cap - 1;
-        if ((rc = dev_alloc(q, (void **)&q->d_xr, (size_t)cap * sizeof(cfl)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_xr, (size_t)cap * sizeof(cfl)))) return rc;
         need = (uint64_t)FM_HIST_FRAMES + (uint64_t)PIPE_DEPTH * q->chan_size + 64; cap = 1;
         while (cap < need) cap <<= 1;
         q->fm_mask = cap - 1;
-        if ((rc = dev_alloc(q, (void **)&q->d_fm, (size_t)cap * M * sizeof(float)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_fm, (size_t)cap * M * sizeof(float)))) return rc;
         if (q->cfg.deemph_fir || q->cfg.lowpass) {
-            if ((rc = dev_alloc(q, (void **)&q->d_aux1, (size_t)cap * M * sizeof(float)))) return rc;
-            if ((rc = dev_alloc(q, (void **)&q->d_aux2, (size_t)cap * M * sizeof(float)))) return rc;
+            if ((rc = dev_alloc_state(q, (void **)&q->d_aux1, (size_t)cap * M * sizeof(float)))) return rc;
+            if ((rc = dev_alloc_state(q, (void **)&q->d_aux2, (size_t)cap * M * sizeof(float)))) return rc;
         }
     }
     q->scratch_bytes = 4096;         /* history shifts of the staged front end only (<= 40 samples each) */
@@ -794,7 +805,7 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_fe_T1, q->d_fe_T2, q->d_fe_lam_lane, q->d_fe_hist[0], q->d_fe_hist[1], q->d_fe_vstate[0],
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
                      q->d_fe_V[1], q->d_fe_V[2], q->d_fe_G12, q->d_fe_GAK, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_lampow, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
-                     q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events,
+                     q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events, q->d_ct_restart,
                      q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1 };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
@@ -811,6 +822,7 @@ int pmr_chain_destroy(pmr_chain q)
     pmr_design_free(&q->d);
     free(q->h_reset_flags);
     free(q->h_open);
+    free(q->ct_open_last);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) free(q->slot[i].open_rows);
     free(q);
     return PMR_OK;
@@ -842,6 +854,7 @@ int pmr_chain_reset(pmr_chain q)
         HIPCHK(hipMemsetAsync(q->d_ct_dcstate, 0, (size_t)M * sizeof(float), q->stream), "reset");
         for (int i = 0; i < 2; i++)
             HIPCHK(hipMemsetAsync(q->d_ct_carry[i], 0, (size_t)M * PMR_CT_TONES * 2 * sizeof(float), q->stream), "reset");
+        HIPCHK(hipMemsetAsync(q->d_ct_restart, 0, M, q->stream), "reset");
     }
     if (q->d_fe_ring1) HIPCHK(hipMemsetAsync(q->d_fe_ring1, 0, (size_t)(q->ring1_mask + 1) * sizeof(cfl), q->stream), "reset");
     if (q->fe_on) for (int i = 0; i < 2; i++) {
@@ -1242,7 +1255,9 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
     /* (k_ct_final writes every open channel's carry for the next call, zeros when the call ends on a block boundary) */
     LAUNCH_ON(sct, K_CT_GOERTZEL, pmr_launch_ct_detector(sct, q->d_ctlp, q->fm_mask, frame0, ns, M, N, a1, q->d_ct_lampow, q->d_ct_dcstate,
                                                  q->d_ct_agg, q->d_ct_W, q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[cur],
-                                                 q->d_ct_carry[nxt], q->d_ct_events, nblk, ncomplete, sel, q->n_enabled));
+                                                 q->d_ct_carry[nxt], q->d_ct_events, q->d_ct_restart, nblk, ncomplete, sel, q->n_enabled));
+    q->ct_masked_last = q->mask_on;
+    if (q->mask_on) memcpy(q->ct_open_last, q->h_open, M);
     if (async) {
         HIPCHK(hipEventRecord(q->ev_ct[q->cur_par], q->stream_ct), "record");
         q->ct_ev_used[q->cur_par] = 1; q->ct_last_par = q->cur_par;
@@ -1342,6 +1357,10 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on)
     if (on && !q->d_ctlp) {
         const unsigned M = q->M, N = PMR_CT_BLOCK, n = q->hp_len_raw;
         if ((n & 1) == 0) return fail(q, PMR_EINVAL, "ctcss needs an odd-length high-pass", hipSuccess);
+        /* the dc-blocker scan strings at most 256 x 24 segments together per call (k_ct_seg_scan): checked HERE, before anything is
+         * allocated, not by a launch that fails in the middle of a block */
+        if ((q->chan_size / N + 3) * PMR_CT_SEG > pmr_ct_max_segments())
+            return fail(q, PMR_ERANGE, "ctcss: max_block yields more Goertzel blocks per call than the detector strings together", hipSuccess);
         const float *hp = q->cfg.hp_taps ? q->cfg.hp_taps : pmr446_hp_audio_taps;
         float *tc = (float *)calloc(n, sizeof(float));
         if (!tc) return fail(q, PMR_ENOMEM, "calloc", hipSuccess);
@@ -1378,14 +1397,17 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on)
             for (unsigned i = 0; i <= 160; i++) lp_[i] = (float)pow(-(double)a1_, (double)i);
             if ((rc = dev_upload(q, &q->d_ct_lampow, lp_, 161))) return rc;
         }
-        if ((rc = dev_alloc(q, (void **)&q->d_ctlp, rows * M * sizeof(float)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_ctlp, rows * M * sizeof(float)))) return rc;
         if ((rc = dev_alloc(q, (void **)&q->d_ct_agg, nch * M * sizeof(float)))) return rc;
         if ((rc = dev_alloc(q, (void **)&q->d_ct_W, nch * M * sizeof(float)))) return rc;
-        if ((rc = dev_alloc(q, (void **)&q->d_ct_dcstate, (size_t)M * sizeof(float)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_ct_dcstate, (size_t)M * sizeof(float)))) return rc;
         if ((rc = dev_alloc(q, (void **)&q->d_ct_part, (size_t)(q->ct_max_ev + 1) * PMR_CT_SEG * M * PMR_CT_TONES * 2 * sizeof(float)))) return rc;
         for (int i = 0; i < 2; i++)
-            if ((rc = dev_alloc(q, (void **)&q->d_ct_carry[i], (size_t)M * PMR_CT_TONES * 2 * sizeof(float)))) return rc;
+            if ((rc = dev_alloc_state(q, (void **)&q->d_ct_carry[i], (size_t)M * PMR_CT_TONES * 2 * sizeof(float)))) return rc;
         if ((rc = dev_alloc(q, (void **)&q->d_ct_events, (size_t)(q->ct_max_ev + 1) * M * sizeof(pmr_ctcss_event)))) return rc;
+        if ((rc = dev_alloc_state(q, (void **)&q->d_ct_restart, M))) return rc;
+        if (!q->ct_open_last && !(q->ct_open_last = (uint8_t *)malloc(M))) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
+        memset(q->ct_open_last, 1, M);
         HIPCHK(hipStreamSynchronize(q->stream), "ctcss init");
     }
     q->ct_on = on ? 1 : 0;
@@ -1408,7 +1430,7 @@ int pmr_chain_ctcss_read(pmr_chain q, pmr_ctcss_event *events, unsigned cap, uns
     hipError_t e = hipMemcpy(tmp, q->d_ct_events, (size_t)n * M * sizeof(*tmp), hipMemcpyDeviceToHost);
     if (e == hipSuccess)
         for (unsigned b = 0; b < n; b++) for (unsigned k = 0; k < M; k++) {
-            if (q->mask_on && !q->h_open[k]) {            /* closed channel: the detector did not run (index -1, nothing detected) */
+            if (q->ct_masked_last && !q->ct_open_last[k]) {   /* closed WHEN THE BLOCK RAN: the detector did not run (index -1, nothing detected) */
                 const pmr_ctcss_event none = { -1, 0, 0.0f, 0.0f };
                 events[(size_t)k * cap + b] = none;
             } else events[(size_t)k * cap + b] = tmp[(size_t)b * M + k];
@@ -1503,12 +1525,25 @@ static int tilefix_on_backend(const pmr_chain q)
 
 /* `single`: queue the whole block on ONE stream (no cross-stream events): what a caller that synchronises after every
  * block wants -- the two-stream pipeline only pays when consecutive blocks are in flight together. */
+static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
+                                     unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db, int single, int phase);
+
+/* every exit path of a block leaves in_block clear; an error return with in_block set has already marked the handle faulted (fail) */
 static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
                                      unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db, int single,
                                      int phase /*0: whole block; 1: up to channelizer + RSSI, audio part left pending*/)
 {
     if (!q) return PMR_EINVAL;
     if (q->faulted) return refuse_faulted(q);
+    const int rc = process_block_device_body(q, d_iq, n_in, d_pcm, d_audio, pcm_stride, n_frames, d_chan_out, d_rssi_db, single, phase);
+    if (rc && q->in_block) q->faulted = 1;
+    q->in_block = 0;
+    return rc;
+}
+
+static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_in, void *d_pcm, void *d_audio,
+                                     unsigned pcm_stride, unsigned *n_frames, void *d_chan_out, void *d_rssi_db, int single, int phase)
+{
     q->cur_single = single;
     q->rssi_job_pending = 0;
     if (phase == 1 && !single) return fail(q, PMR_EINVAL, "two-step form is synchronous", hipSuccess);
@@ -1517,8 +1552,10 @@ static int process_block_device_impl(pmr_chain q, const void *d_iq, unsigned n_i
          * detector, follow-on FIR passes) must still see it */
         q->pend_audio = 0;
         if (q->ct_on || q->cfg.deemph_fir || q->cfg.lowpass) {
+            q->in_block = 1;
             int rc_ = audio_part(q, q->pend_audio_frame0, q->pend_audio_ns, NULL, NULL, 0);
             if (rc_) return rc_;
+            q->in_block = 0;
         }
     }
     if (n_in > q->cfg.max_block) return fail(q, PMR_ERANGE, "n_in > max_block", hipSuccess);
@@ -1772,6 +1809,7 @@ static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigne
                                    (want & PMR_WANT_RSSI) ? o_out : NULL, single, phase);
     if (rc) return rc;
     sl->ns = ns; sl->stride = stride; sl->want = want;
+    q->in_block = 1;                              /* the block's state has advanced: losing its outputs now poisons the handle (slot_submit_end) */
     if ((rc = slot_snapshot_mask(q, sl))) return rc;
     if (ns && !zc_out) {
         const size_t lo = (want & PMR_WANT_RSSI) ? 0 : (want & PMR_WANT_PCM) ? sl->off_pcm : sl->off_audio;
@@ -1782,6 +1820,7 @@ static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigne
         if (want & PMR_WANT_CHAN) HIPCHK(hipMemcpyAsync(sl->h_chan, sl->d_chan, n * sizeof(cfl), hipMemcpyDeviceToHost, q->stream), "D2H chan");
     }
     HIPCHK(hipEventRecord(sl->done, q->stream), "record");
+    q->in_block = 0;
     return PMR_OK;
 }
 
@@ -1822,6 +1861,7 @@ int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, 
     const unsigned want = ((pcm || audio) ? PMR_WANT_PCM : 0) | (audio ? PMR_WANT_AUDIO : 0) | (chan_out ? PMR_WANT_CHAN : 0) |
                           (rssi_db ? PMR_WANT_RSSI : 0);
     int rc = slot_submit(q, 0, iq, 0, n_in, want, 1, 0);
+    q->in_block = 0;
     if (rc) return rc;
     rc = slot_collect(q, 0, pcm, audio, pcm_stride, n_frames, chan_out, rssi_db);      /* waits for the block's last copy */
     if (rc) return rc;
@@ -1845,6 +1885,7 @@ int pmr_chain_channelize_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, u
     if (ns_plan > chan_stride && chan_out) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
     const unsigned want = (chan_out ? PMR_WANT_CHAN : 0) | (rssi_db ? PMR_WANT_RSSI : 0);
     int rc = slot_submit(q, 0, iq, 0, n_in, want, 1, 1);
+    q->in_block = 0;
     if (rc) return rc;
     return slot_collect(q, 0, NULL, NULL, chan_stride, n_frames, chan_out, rssi_db);
 }
@@ -1853,6 +1894,7 @@ int pmr_chain_demodulate_block(pmr_chain q, int16_t *pcm, float *audio, unsigned
 {
     if (!q) return PMR_EINVAL;
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
+    if (q->faulted) return refuse_faulted(q);
     if (!q->pend_audio) return fail(q, PMR_EINVAL, "no channelized block is waiting for its audio part", hipSuccess);
     const unsigned ns = q->pend_audio_ns;
     if (n_frames) *n_frames = ns;
@@ -1869,13 +1911,18 @@ int pmr_chain_demodulate_block(pmr_chain q, int16_t *pcm, float *audio, unsigned
     const int zc_out = !q->sw.no_zerocopy && sl->hd_out && out_hi <= ZC_MAX_OUT;
     char *o_out = zc_out ? sl->hd_out : sl->d_out;
     q->pend_audio = 0;
-    if (ns && (rc = audio_part(q, q->pend_audio_frame0, ns, (want & PMR_WANT_PCM) ? o_out + sl->off_pcm : NULL,
-                               (want & PMR_WANT_AUDIO) ? o_out + sl->off_audio : NULL, stride))) return rc;
+    q->in_block = 1;                              /* the audio part advances the detector / follow-on filters: an error in it poisons the handle */
+    rc = ns ? audio_part(q, q->pend_audio_frame0, ns, (want & PMR_WANT_PCM) ? o_out + sl->off_pcm : NULL,
+                         (want & PMR_WANT_AUDIO) ? o_out + sl->off_audio : NULL, stride) : PMR_OK;
     sl->ns = ns; sl->stride = stride; sl->want = want;
-    if ((rc = slot_snapshot_mask(q, sl))) return rc;
-    if (ns && !zc_out && want)
-        HIPCHK(hipMemcpyAsync(sl->h_out + sl->off_pcm, sl->d_out + sl->off_pcm, out_hi - sl->off_pcm, hipMemcpyDeviceToHost, q->stream), "D2H");
-    HIPCHK(hipEventRecord(sl->done, q->stream), "record");
+    if (!rc) rc = slot_snapshot_mask(q, sl);
+    if (!rc && ns && !zc_out && want) {
+        hipError_t e_ = hipMemcpyAsync(sl->h_out + sl->off_pcm, sl->d_out + sl->off_pcm, out_hi - sl->off_pcm, hipMemcpyDeviceToHost, q->stream);
+        if (e_ != hipSuccess) rc = fail(q, PMR_EHIP, "D2H", e_);
+    }
+    if (!rc) { hipError_t e_ = hipEventRecord(sl->done, q->stream); if (e_ != hipSuccess) rc = fail(q, PMR_EHIP, "record", e_); }
+    q->in_block = 0;
+    if (rc) return rc;
     rc = slot_collect(q, 0, pcm, audio, pcm_stride, n_frames, NULL, NULL);
     if (rc) return rc;
     if (q->prof_on) prof_resolve(q);
@@ -1890,6 +1937,7 @@ int pmr_chain_submit_block_fmt(pmr_chain q, const void *iq, int iq_format, unsig
     if (q->n_inflight >= PIPE_DEPTH) return fail(q, PMR_ERANGE, "PIPE_DEPTH blocks already in flight: collect one first", hipSuccess);
     const unsigned i = (q->slot_head + q->n_inflight) % PIPE_DEPTH;
     int rc = slot_submit(q, i, iq, iq_format, n_in, want ? want : PMR_WANT_PCM, !q->overlap, 0);
+    q->in_block = 0;
     if (rc) return rc;
     q->n_inflight++;
     return PMR_OK;
@@ -1969,6 +2017,21 @@ int pmr_chain_process_block(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, int1
 
 /* ------------------------------------------------------------------------------------------- */
 
+/* ctcss_detector_reset of one channel (:348-357 via :867): u0 = u1 = 0 for every tone, samp_processed = 0.  The partial sums of
+ * the block in progress restart from zero; the 2441-frame block GRID stays the stream's (every channel shares it here, where the
+ * reference's single detector restarts its own count), so the block in progress is incomplete for this channel: flagged, and
+ * k_ct_final reports its event as "no decision" {-1, 0, 0, 0}.  Known deviation: the reference's first event after a reset comes
+ * exactly 2441 frames later, ours at the first grid boundary at least 2441 frames later (up to 2 x 2441 - 1).  Callers have
+ * synchronised the back-end and detector streams. */
+static hipError_t ct_restart_channel(pmr_chain q, unsigned k)
+{
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < 2 && e == hipSuccess; b++)
+        e = hipMemset((char *)q->d_ct_carry[b] + (size_t)k * PMR_CT_TONES * 2 * sizeof(float), 0, (size_t)PMR_CT_TONES * 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(q->d_ct_restart + k, q->frames_done % PMR_CT_BLOCK ? 1 : 0, 1);
+    return e;
+}
+
 /* Open-channel mask: the reference demodulates only the squelch-selected channel (src/sdr_pmr446.c:876-877, hand-off from the
  * squelch state machine :834-839).  Channelizer, RSSI and the discriminator keep running for EVERY channel (their state and the
  * audio filters' history therefore stay current for a channel that is opened later); the audio FIR / PCM / CTCSS branch run for
@@ -1978,7 +2041,17 @@ int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned
     if (!q) return PMR_EINVAL;
     const unsigned M = q->M;
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
-    if (!mask_words) { q->mask_on = 0; q->n_enabled = M; memset(q->h_open, 1, M); return PMR_OK; }
+    if (!mask_words) {
+        /* every channel opens: the detector of each channel that was closed restarts, like the explicit-list path below */
+        if (q->mask_on && q->d_ct_carry[0]) {
+            HIPCHK(hipStreamSynchronize(q->stream), "channel mask");
+            HIPCHK(hipStreamSynchronize(q->stream_ct), "channel mask");
+            for (unsigned k = 0; k < M; k++)
+                if (!q->h_open[k]) HIPCHK(ct_restart_channel(q, k), "channel mask");
+        }
+        q->mask_on = 0; q->n_enabled = M; memset(q->h_open, 1, M);
+        return PMR_OK;
+    }
     if ((uint64_t)n_words * 64 < M) return fail(q, PMR_EINVAL, "channel mask shorter than num_channels", hipSuccess);
     /* the mask is applied by the MFMA audio kernels (16 channels per tile); the VALU versions (num_channels not a multiple of 16,
      * PMR_FIR=pair|lds|global) would write every row: refuse instead of breaking the "closed rows stay untouched" promise */
@@ -1997,9 +2070,7 @@ int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned
         for (unsigned i = 0; i < n && e == hipSuccess; i++) {
             if (q->h_open[list[i]] && q->mask_on) continue;                /* was open already */
             if (!q->mask_on) break;                                        /* every channel was running */
-            for (int b = 0; b < 2 && e == hipSuccess; b++)
-                e = hipMemset((char *)q->d_ct_carry[b] + (size_t)list[i] * PMR_CT_TONES * 2 * sizeof(float), 0,
-                              (size_t)PMR_CT_TONES * 2 * sizeof(float));
+            e = ct_restart_channel(q, list[i]);
         }
     }
     if (e == hipSuccess) {
@@ -2026,10 +2097,9 @@ int pmr_chain_reset_channel(pmr_chain q, unsigned channel)
     if (q->d_ct_carry[0]) {
         HIPCHK(hipStreamSynchronize(q->stream), "reset channel");
         HIPCHK(hipStreamSynchronize(q->stream_ct), "reset channel");
-        for (int i = 0; i < 2; i++)
-            HIPCHK(hipMemset((char *)q->d_ct_carry[i] + (size_t)channel * PMR_CT_TONES * 2 * sizeof(float), 0,
-                             (size_t)PMR_CT_TONES * 2 * sizeof(float)), "reset channel");
-        HIPCHK(hipMemset(q->d_ct_dcstate + channel, 0, sizeof(float)), "reset channel");    /* iirfilt_rrrf_reset of :606's blocker */
+        HIPCHK(ct_restart_channel(q, channel), "reset channel");
+        /* (the detector's dc blocker, :606, is NOT reset: the reference's detune path calls freqdem_reset and ctcss_detector_reset
+         * only, :866-867 -- ctcss_dcblock keeps its state) */
     }
     return PMR_OK;
 }

@@ -475,11 +475,11 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         if (fine) {
-            if (fix) hipLaunchKernelGGL((k_channelize_win<16, 26, true, CW_F_SMALL>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
-            else hipLaunchKernelGGL((k_channelize_win<16, 26, false, CW_F_SMALL>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
+            if (fix) PMR_KLAUNCH((k_channelize_win<16, 26, true, CW_F_SMALL>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
+            else PMR_KLAUNCH((k_channelize_win<16, 26, false, CW_F_SMALL>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
         } else {
-            if (fix) hipLaunchKernelGGL((k_channelize_win<16, 26, true, CW_F>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
-            else hipLaunchKernelGGL((k_channelize_win<16, 26, false, CW_F>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
+            if (fix) PMR_KLAUNCH((k_channelize_win<16, 26, true, CW_F>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
+            else PMR_KLAUNCH((k_channelize_win<16, 26, false, CW_F>), dim3(ntiles), dim3(CW_NT), lds_w, st, *p);
         }
         return (int)hipGetLastError();
     }
@@ -490,6 +490,6 @@ extern "C" int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize_small<16>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL(k_channelize_small<16>, dim3(ntiles), dim3(CS_NT), lds, (hipStream_t)s, *p);
+    PMR_KLAUNCH(k_channelize_small<16>, dim3(ntiles), dim3(CS_NT), lds, (hipStream_t)s, *p);
     return (int)hipGetLastError();
 }

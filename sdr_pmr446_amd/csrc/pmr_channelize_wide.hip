@@ -327,7 +327,7 @@ static int launch_fft_disc(hipStream_t st, const pmr_chan_params *p, const cf *X
     if (lds > 64 * 1024 && pmr_attr_needed(attr_set)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_disc<M, FPW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL((k_fft_disc<M, FPW>), dim3(ntiles), dim3(256), lds, st, *p, Xg);
+    PMR_KLAUNCH((k_fft_disc<M, FPW>), dim3(ntiles), dim3(256), lds, st, *p, Xg);
     return (int)hipGetLastError();
 }
 
@@ -348,8 +348,8 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
         if (ntiles_out) *ntiles_out = ntiles;
         const bool fix = p->fix.V != nullptr;
         const size_t lds = ((size_t)(PF_G + 1) * 256 + 128) * sizeof(cf) + (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
-        if (fix) hipLaunchKernelGGL(k_channelize_fused256<true>, dim3(ntiles), dim3(256), lds, st, *p);
-        else hipLaunchKernelGGL(k_channelize_fused256<false>, dim3(ntiles), dim3(256), lds, st, *p);
+        if (fix) PMR_KLAUNCH(k_channelize_fused256<true>, dim3(ntiles), dim3(256), lds, st, *p);
+        else PMR_KLAUNCH(k_channelize_fused256<false>, dim3(ntiles), dim3(256), lds, st, *p);
         return (int)hipGetLastError();
     }
     if (p->fix.V) return (int)hipErrorInvalidValue;            /* the two-kernel form expects corrected samples */
@@ -357,7 +357,7 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
     while ((1u << log2M) < p->M) log2M++;
     const unsigned groups = (p->ns + 1 + PW_F - 1) / PW_F;
     const size_t threads = (size_t)groups * p->M;
-    hipLaunchKernelGGL(k_pfb_wide, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, *p, log2M, (cf *)x_scratch);
+    PMR_KLAUNCH(k_pfb_wide, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, *p, log2M, (cf *)x_scratch);
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     switch (p->M) {

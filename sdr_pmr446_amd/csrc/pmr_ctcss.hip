@@ -37,7 +37,11 @@ static __device__ __forceinline__ ct_seg ct_segment(long long b, unsigned seg, u
     ct_seg r;
     r.len = hi > lo ? (int)(hi - lo) : 0;
     r.lo = lo;
-    r.n0 = r.len ? (unsigned)(lo - b * (long long)N) : 0;
+    // position inside the block of the first staged row.  An EMPTY segment (the call does not reach it) keeps the segment's own
+    // start: k_ct_goertzel derives its weight-window index from n0 and runs its fixed-trip MFMA loop over the (all-zero) rows
+    // regardless -- with n0 = 0 (round 3) that index ran up to e_pos = 2441 floats past the window, through the rest of the
+    // workgroup's LDS and beyond its allocation, and 0 x (whatever the previous workgroup left there) is NaN when that is a NaN
+    r.n0 = r.len ? (unsigned)(lo - b * (long long)N) : seg * SL;
     return r;
 }
 
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(256) void k_ct_seg_scan(const float *__restrict__ a
         a[u] = in ? agg[(size_t)g * M + k] : 0.f;
         l[u] = in ? lampow[ct_segment(b0 + g / PMR_CT_SEG, g % PMR_CT_SEG, N, SL, row0, ns).len] : 1.f;
     }
+    const float s0 = state[k];                                     // read BEFORE the barriers below: thread 255 overwrites it at the end
     float P = 1.f, A = 0.f;                                        // run from zero state: v_out = P v_in + A
 #pragma unroll
     for (unsigned u = 0; u < CT_PER; u++) { A = fmaf(l[u], A, a[u]); P *= l[u]; }
@@ -110,7 +115,6 @@ __global__ __launch_bounds__(256) void k_ct_seg_scan(const float *__restrict__ a
         if (t >= d) { sA[t] = fmaf(sP[t], a2, sA[t]); sP[t] = sP[t] * p2; }
         __syncthreads();
     }
-    const float s0 = state[k];
     float v = t == 0 ? s0 : fmaf(sP[t - 1], s0, sA[t - 1]);        // state before this thread's run
 #pragma unroll
     for (unsigned u = 0; u < CT_PER; u++) {
@@ -292,7 +296,10 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
             // issued ahead of their MFMAs.  (With a run-time trip count and a clamped weight index the compiler issued read, wait,
             // MFMA one after the other: ~400 cycles per step, 21 of this kernel's 33 us.)  Weight index of step st: ui - 4 st, which
             // runs below the row's start for the zero rows of a clipped segment -- into the previous tone's row or the sample area:
-            // finite numbers (the rows' tails are zero-filled above), multiplied by zero.
+            // finite numbers (the rows' tails are zero-filled above, every staged sample row is written), multiplied by zero.
+            // Bounds: n0 in [s_pos, e_pos] (ct_segment, empty segments included) => d0 in [0, SL]; the highest index read is
+            // jt US + d0 <= 37 US + SL < 38 US (inside `us`), the lowest jt US + d0 - 1 - (CG_ROWS - 1) >= -CG_ROWS (inside `xs`,
+            // which lies directly below `us`): never outside what this workgroup wrote.  tests run under the LDS poison mode.
             constexpr int NST = CG_ROWS / 4;
             const int c = 16 * (int)wave + col, jt = c >> 1;       // column -> (tone, which); columns >= 76: tone 37 again, never stored
             const float *pb = us + (size_t)(jt < (int)PMR_CT_TONES ? jt : (int)PMR_CT_TONES - 1) * US + (d0 - (c & 1) - kk) - 4 * (NST - 1);
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
 __global__ __launch_bounds__(64) void k_ct_final(const float *__restrict__ part, unsigned nblk, unsigned ncomplete,
                                                  unsigned M, const float *__restrict__ coef,
                                                  const float *__restrict__ carry_in, float *__restrict__ carry_out,
-                                                 pmr_ctcss_event *__restrict__ events,
+                                                 pmr_ctcss_event *__restrict__ events, unsigned char *__restrict__ restart,
                                                  const unsigned *__restrict__ chan_list, unsigned n_chan)
 {
     __shared__ float spw[PMR_CT_TONES];
@@ -373,28 +380,33 @@ __global__ __launch_bounds__(64) void k_ct_final(const float *__restrict__ part,
         pmr_ctcss_event e;
         e.index = maxi; e.detected = (avg > 120.0f) && ((maxp / avg) > 10.0f);
         e.max_power = maxp; e.avg_power = avg;
+        // the block in progress when the channel's detector was restarted (ctcss_detector_reset, :867 -- pmr_chain.c
+        // ct_restart_channel) holds only the frames since: no decision.  (blk == 0: the one block that carries sums of earlier calls)
+        if (blk == 0 && restart[k]) { e.index = -1; e.detected = 0; e.max_power = 0.f; e.avg_power = 0.f; restart[k] = 0; }
         events[(size_t)blk * M + k] = e;
     }
 }
 
+extern "C" unsigned pmr_ct_max_segments(void) { return 256u * CT_PER; }
+
 extern "C" int pmr_launch_ct_detector(pmr_stream_t s, const float *lp, uint64_t row_mask, int64_t row0, unsigned ns,
                                       unsigned M, unsigned N, float a1, const float *lampow, float *state, float *agg, float *W,
                                       const float *U, const float *coef, float *part,
-                                      const float *carry_in, float *carry_out, pmr_ctcss_event *events,
+                                      const float *carry_in, float *carry_out, pmr_ctcss_event *events, unsigned char *restart,
                                       unsigned nblk, unsigned ncomplete, const unsigned *chan_list, unsigned n_chan)
 {
     const unsigned nc = chan_list ? n_chan : M;
     if (!ns || !nblk || !nc) return 0;
     const long long b0 = row0 / (long long)N;
     const unsigned nseg = nblk * PMR_CT_SEG;
-    if (nseg > 256u * CT_PER) return (int)hipErrorInvalidValue;
+    if (nseg > pmr_ct_max_segments()) return (int)hipErrorInvalidValue;        /* (pmr_chain_ctcss_enable checks the plan up front) */
     const unsigned SL = (N + PMR_CT_SEG - 1) / PMR_CT_SEG, US = SL + 2 + ((SL & 1) ? 0 : 1);
     if (SL > 16 * CT_SUB || SL > 12 * 13 || SL > CG_ROWS) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)s;
     const unsigned long long rm = (unsigned long long)row_mask;
-    hipLaunchKernelGGL(k_ct_seg_agg, dim3(nseg, (nc + 15) / 16), dim3(256), 0, st, lp, rm, (long long)row0, ns, M, N, -a1, lampow, agg,
+    PMR_KLAUNCH(k_ct_seg_agg, dim3(nseg, (nc + 15) / 16), dim3(256), 0, st, lp, rm, (long long)row0, ns, M, N, -a1, lampow, agg,
                        b0, chan_list, nc);
-    hipLaunchKernelGGL(k_ct_seg_scan, dim3(nc), dim3(256), 0, st, agg, nseg, M, N, (long long)row0, ns, b0, lampow, state, W, chan_list);
+    PMR_KLAUNCH(k_ct_seg_scan, dim3(nc), dim3(256), 0, st, agg, nseg, M, N, (long long)row0, ns, b0, lampow, state, W, chan_list);
     const size_t lds = ((size_t)CG_ROWS * 16 + (size_t)PMR_CT_TONES * US + 12 * 16) * sizeof(float);
     /* blocks per workgroup: the grid is one round of resident workgroups */
     const unsigned ny = (nc + 15) / 16;
@@ -402,12 +414,12 @@ extern "C" int pmr_launch_ct_detector(pmr_stream_t s, const float *lp, uint64_t 
     if (nb < 1) nb = 1;
     const dim3 grid(((nblk + nb - 1) / nb) * PMR_CT_SEG, ny);
     if (chan_list)
-        hipLaunchKernelGGL(k_ct_goertzel<true>, grid, dim3(CG_T), lds, st, lp, rm, (long long)row0, ns, M, N, U, part, b0, nblk, nb, chan_list, nc,
+        PMR_KLAUNCH(k_ct_goertzel<true>, grid, dim3(CG_T), lds, st, lp, rm, (long long)row0, ns, M, N, U, part, b0, nblk, nb, chan_list, nc,
                            W, a1, lampow);
     else
-        hipLaunchKernelGGL(k_ct_goertzel<false>, grid, dim3(CG_T), lds, st, lp, rm, (long long)row0, ns, M, N, U, part, b0, nblk, nb, chan_list, nc,
+        PMR_KLAUNCH(k_ct_goertzel<false>, grid, dim3(CG_T), lds, st, lp, rm, (long long)row0, ns, M, N, U, part, b0, nblk, nb, chan_list, nc,
                            W, a1, lampow);
-    hipLaunchKernelGGL(k_ct_final, dim3(nblk * nc), dim3(64), 0, st, part, nblk, ncomplete, M, coef, carry_in, carry_out, events,
-                       chan_list, nc);
+    PMR_KLAUNCH(k_ct_final, dim3(nblk * nc), dim3(64), 0, st, part, nblk, ncomplete, M, coef, carry_in, carry_out, events,
+                       restart, chan_list, nc);
     return (int)hipGetLastError();
 }

@@ -81,7 +81,7 @@ extern "C" int pmr_launch_dsd_fm(pmr_stream_t s, const void *xr, uint64_t xr_mas
                                  uint64_t fm_mask, float ref)
 {
     if (!ny) return 0;
-    hipLaunchKernelGGL(k_dsd_fm, dim3((ny + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)xr,
+    PMR_KLAUNCH(k_dsd_fm, dim3((ny + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)xr,
                        (unsigned long long)xr_mask, (unsigned long long)a0, ny, fm, (unsigned long long)fm_mask, ref);
     return (int)hipGetLastError();
 }
@@ -91,7 +91,7 @@ extern "C" int pmr_launch_dsd_arb(pmr_stream_t s, const float *fm, uint64_t fm_m
                                   float *audio)
 {
     if (!nu) return 0;
-    hipLaunchKernelGGL(k_dsd_arb, dim3((nu + 255) / 256), dim3(256), 0, (hipStream_t)s, fm, (unsigned long long)fm_mask,
+    PMR_KLAUNCH(k_dsd_arb, dim3((nu + 255) / 256), dim3(256), 0, (hipStream_t)s, fm, (unsigned long long)fm_mask,
                        (unsigned long long)j0, nu, step, bank, u, (unsigned long long)u_mask, pcm, audio);
     return (int)hipGetLastError();
 }
@@ -100,7 +100,7 @@ extern "C" int pmr_launch_dsd_hb(pmr_stream_t s, const float *in, uint64_t in_ma
                                  const float *h1, float *out, uint64_t out_mask, int16_t *pcm, float *audio)
 {
     if (!n) return 0;
-    hipLaunchKernelGGL(k_dsd_hb, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, in, (unsigned long long)in_mask,
+    PMR_KLAUNCH(k_dsd_hb, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, in, (unsigned long long)in_mask,
                        (unsigned long long)i0, n, m, h1, out, (unsigned long long)out_mask, pcm, audio);
     return (int)hipGetLastError();
 }

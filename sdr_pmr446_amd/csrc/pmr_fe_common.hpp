@@ -205,10 +205,11 @@ static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, cons
 // launch with optional per-launch events (pmr_launch_events, pmr_kernels.h)
 #define PMR_LAUNCH_EV(kern, grid, block, lds, st, ev, ...)                                                                        \
     do {                                                                                                                           \
-        if ((ev) && ((ev)->start || (ev)->stop))                                                                                   \
+        if ((ev) && ((ev)->start || (ev)->stop)) {                                                                                 \
+            if (pmr_debug_poison_enabled()) (void)pmr_debug_poison_lds((pmr_stream_t)(st));                                        \
             hipExtLaunchKernelGGL(kern, grid, block, (unsigned)(lds), st, (hipEvent_t)(ev)->start, (hipEvent_t)(ev)->stop, 0,      \
                                   __VA_ARGS__);                                                                                    \
-        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                          \
+        } else PMR_KLAUNCH(kern, grid, block, lds, st, __VA_ARGS__);                                                          \
     } while (0)
 
 #endif

@@ -401,6 +401,6 @@ extern "C" int pmr_launch_fe_level2_fast(pmr_stream_t s, const pmr_fe_params *p,
 {
     if (!ntiles) return 0;
     const size_t lds = (FE_PAD + (2048 + 256)) * sizeof(cf);          /* 18.9 KB: the stages run in place */
-    hipLaunchKernelGGL(k_fe_level2, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p);
+    PMR_KLAUNCH(k_fe_level2, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p);
     return (int)hipGetLastError();
 }

@@ -310,19 +310,19 @@ extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const
         const unsigned n_units = n_chan * tiles;
         const dim3 grid((n_units + 15) / 16);
         if (dual)
-            hipLaunchKernelGGL((k_fir_mfma16<false, 1, true, true, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
+            PMR_KLAUNCH((k_fir_mfma16<false, 1, true, true, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
                                out_tm, pcm, audio, stride, M, chan_list, n_units, tiles, taps2_pad, out2_tm);
         else if (!out_tm)
-            hipLaunchKernelGGL((k_fir_mfma16<false, 1, true, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
+            PMR_KLAUNCH((k_fir_mfma16<false, 1, true, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
                                out_tm, pcm, audio, stride, M, chan_list, n_units, tiles, (const float *)nullptr, (float *)nullptr);
         else
-            hipLaunchKernelGGL((k_fir_mfma16<false, 1, false, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
+            PMR_KLAUNCH((k_fir_mfma16<false, 1, false, true>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps,
                                out_tm, pcm, audio, stride, M, chan_list, n_units, tiles, (const float *)nullptr, (float *)nullptr);
         return (int)hipGetLastError();
     }
     if (dual) {
         if (nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_fir_mfma16<false, 1, true, false, true>), dim3(tiles, M / 16), dim3(FM_NT), lds, st, in, rm, r0, ns,
+        PMR_KLAUNCH((k_fir_mfma16<false, 1, true, false, true>), dim3(tiles, M / 16), dim3(FM_NT), lds, st, in, rm, r0, ns,
                            taps_pad, ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u, taps2_pad, out2_tm);
         return (int)hipGetLastError();
     }
@@ -331,7 +331,7 @@ extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const
      * LDS-window kernel stays the default. */
     if (sw->fir_mfma_global) {
         const size_t lds_g = (((size_t)qlen + 31) & ~(size_t)31) * sizeof(float);
-        hipLaunchKernelGGL((k_fir_mfma16<true, 1, false>), dim3(tiles, M / 16), dim3(FM_NT), lds_g, st, in, rm, r0, ns, taps_pad,
+        PMR_KLAUNCH((k_fir_mfma16<true, 1, false>), dim3(tiles, M / 16), dim3(FM_NT), lds_g, st, in, rm, r0, ns, taps_pad,
                            ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u, (const float *)nullptr, (float *)nullptr);
         return (int)hipGetLastError();
     }
@@ -339,7 +339,7 @@ extern "C" int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const
     const bool two = sw->fir_tpw == 2 && nrows * 4 <= FM_PRE * FM_NT && (size_t)((tiles + 1) / 2) * (M / 16) >= 384;
     if (!two && nrows * 4 > FM_PRE * FM_NT) return (int)hipErrorInvalidValue;
     const dim3 grid(two ? (tiles + 1) / 2 : tiles, M / 16);
-#define FM_GO(TPW_, SWAP_) hipLaunchKernelGGL((k_fir_mfma16<false, TPW_, SWAP_>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, \
+#define FM_GO(TPW_, SWAP_) PMR_KLAUNCH((k_fir_mfma16<false, TPW_, SWAP_>), grid, dim3(FM_NT), lds, st, in, rm, r0, ns, taps_pad, \
                                               ntaps, out_tm, pcm, audio, stride, M, (const unsigned *)nullptr, 0u, 0u, (const float *)nullptr, (float *)nullptr)
     if (two) { if (!out_tm) FM_GO(2, true); else FM_GO(2, false); }
     else     { if (!out_tm) FM_GO(1, true); else FM_GO(1, false); }

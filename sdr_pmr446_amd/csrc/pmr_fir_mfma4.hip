@@ -297,7 +297,7 @@ extern "C" int pmr_launch_fir_mfma4(pmr_stream_t s, const float *in, uint64_t ro
         if (chan_list) grid.x += 1; else grid.y += 1;
         if (job_done) *job_done = 1;
     }
-#define F4_GO(G_, D_, T_) hipLaunchKernelGGL((k_fir_mfma4<G_, D_, T_>), grid, dim3(F4_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps, out_tm, \
+#define F4_GO(G_, D_, T_) PMR_KLAUNCH((k_fir_mfma4<G_, D_, T_>), grid, dim3(F4_NT), lds, st, in, rm, r0, ns, taps_pad, ntaps, out_tm, \
                                              pcm, audio, stride, M, chan_list, n_units, tiles, taps2_pad, out2_tm, jb)
     if (chan_list) {
         if (dual) { if (out_tm) F4_GO(true, true, true); else F4_GO(true, true, false); }

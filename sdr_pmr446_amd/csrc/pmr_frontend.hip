@@ -593,7 +593,7 @@ extern "C" int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t,
 {
     if (!t->ntiles) return 0;
     const unsigned nb_tiles = (t->ntiles + 255) / 256, nb_fix = f->ny > f->j0 ? (f->ny - f->j0 + 255) / 256 : 0;
-    hipLaunchKernelGGL(k_fe_carry, dim3(nb_tiles + nb_fix), dim3(256), 0, (hipStream_t)s, *t, *f, nb_tiles);
+    PMR_KLAUNCH(k_fe_carry, dim3(nb_tiles + nb_fix), dim3(256), 0, (hipStream_t)s, *t, *f, nb_tiles);
     return (int)hipGetLastError();
 }
 

@@ -192,8 +192,10 @@ int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in,
  * agg / W: [segments][M] work arrays; state: [M] blocker state carried across calls */
 int pmr_launch_ct_detector(pmr_stream_t s, const float *lp, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M, unsigned N,
                            float a1, const float *lampow, float *state, float *agg, float *W, const float *U, const float *coef,
-                           float *part, const float *carry_in, float *carry_out, pmr_ctcss_event *events, unsigned nblk,
-                           unsigned ncomplete, const unsigned *chan_list, unsigned n_chan);
+                           float *part, const float *carry_in, float *carry_out, pmr_ctcss_event *events,
+                           unsigned char *restart /*[M] detector restarted inside the block in progress: its event = no decision*/,
+                           unsigned nblk, unsigned ncomplete, const unsigned *chan_list, unsigned n_chan);
+unsigned pmr_ct_max_segments(void);      /* segments (16 per Goertzel block) one call of the detector can cover */
 
 /* ---- `dsd_in` back end (pmr_dsd_kernels.hip): discriminator + msresamp_rrrf interpolator on absolute-indexed rings ---- */
 int pmr_launch_dsd_fm(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t a0, unsigned ny, float *fm,
@@ -279,11 +281,25 @@ unsigned pmr_spgram_max_workgroups(void);
 int pmr_launch_spgram(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t pos0, unsigned ny, unsigned wlen,
                       const float *win, const void *tw, float *partial /*[max workgroups][4 wlen]*/, float *psd_mag /*[4 wlen]*/);
 
+/* TEST-ONLY poison mode (pmr_poison.hip; pmr_debug_poison in include/pmr_chain.h, or PMR_DEBUG_POISON=1 in the environment):
+ * every launch of this library is preceded by a kernel that overwrites ALL LDS of EVERY CU with a signalling-NaN pattern, and the
+ * scratch buffers of pmr_chain.c are filled with 0xFF bytes instead of zeros -- a kernel whose result depends on bytes it did not
+ * write then fails on every box, not on the one box where the stale bytes happen to be a NaN. */
+int pmr_debug_poison_enabled(void);
+int pmr_debug_poison_lds(pmr_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif
 
 #if defined(__HIPCC__)
+/* every kernel launch of the library goes through here (poison mode above; otherwise exactly hipLaunchKernelGGL) */
+#define PMR_KLAUNCH(kern, grid, block, lds, st, ...)                                                                               \
+    do {                                                                                                                           \
+        if (pmr_debug_poison_enabled()) (void)pmr_debug_poison_lds((pmr_stream_t)(st));                                            \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                                               \
+    } while (0)
+
 /* arg(re + j im) for the discriminator (freqdem, reference src/sdr_pmr446.c:881: cargf(conj(r') r)): the library atan2f spends a
  * third of its ~38 instructions on range scaling (frexp / ldexp of both operands) and on inf / NaN classes.  Channelizer outputs
  * are ordinary floats, so: q = min / max by one v_rcp_f32, the same odd minimax polynomial the library evaluates, octant and

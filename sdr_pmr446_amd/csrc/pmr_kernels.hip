@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void k_iq_convert(const void *__restrict__ raw
 extern "C" int pmr_launch_iq_convert(pmr_stream_t s, const void *raw, void *out_cf32, unsigned n_in, int fmt)
 {
     if (!n_in) return 0;
-    hipLaunchKernelGGL(k_iq_convert, dim3((n_in + 1023) / 1024), dim3(256), 0, (hipStream_t)s, raw, (float4 *)out_cf32, n_in, fmt);
+    PMR_KLAUNCH(k_iq_convert, dim3((n_in + 1023) / 1024), dim3(256), 0, (hipStream_t)s, raw, (float4 *)out_cf32, n_in, fmt);
     return (int)hipGetLastError();
 }
 
@@ -693,7 +693,7 @@ extern "C" int pmr_launch_dc_agg(pmr_stream_t s, const void *x, unsigned n_in, v
 {
     const unsigned ntiles = (n_in + PMR_DC_TILE - 1) / PMR_DC_TILE;
     if (!ntiles) return 0;
-    hipLaunchKernelGGL(k_dcblock<false>, dim3(ntiles), dim3(256), 0, (hipStream_t)s, (const cf *)x, n_in,
+    PMR_KLAUNCH(k_dcblock<false>, dim3(ntiles), dim3(256), 0, (hipStream_t)s, (const cf *)x, n_in,
                        (const cf *)nullptr, (cf *)agg, (cf *)nullptr, *c, lam_thread_pow);
     return (int)hipGetLastError();
 }
@@ -703,7 +703,7 @@ extern "C" int pmr_launch_dc_scan(pmr_stream_t s, const void *agg, unsigned ntil
                                   float inv_last)
 {
     if (!ntiles) return 0;
-    hipLaunchKernelGGL(k_dc_scan, dim3(1), dim3(PMR_DC_SCAN_THREADS), 0, (hipStream_t)s, (const cf *)agg, ntiles,
+    PMR_KLAUNCH(k_dc_scan, dim3(1), dim3(PMR_DC_SCAN_THREADS), 0, (hipStream_t)s, (const cf *)agg, ntiles,
                        (cf *)W, (cf *)state, *c, lam_tile_idx_pow, lam_last, inv_last);
     return (int)hipGetLastError();
 }
@@ -713,7 +713,7 @@ extern "C" int pmr_launch_dc_apply(pmr_stream_t s, const void *x, unsigned n_in,
 {
     const unsigned ntiles = (n_in + PMR_DC_TILE - 1) / PMR_DC_TILE;
     if (!ntiles) return 0;
-    hipLaunchKernelGGL(k_dcblock<true>, dim3(ntiles), dim3(256), 0, (hipStream_t)s, (const cf *)x, n_in,
+    PMR_KLAUNCH(k_dcblock<true>, dim3(ntiles), dim3(256), 0, (hipStream_t)s, (const cf *)x, n_in,
                        (const cf *)W, (cf *)nullptr, (cf *)out, *c, lam_thread_pow);
     return (int)hipGetLastError();
 }
@@ -722,7 +722,7 @@ extern "C" int pmr_launch_halfband(pmr_stream_t s, const void *zin, void *zout, 
                                    int par, int m, const float *h1, float scale)
 {
     if (!n_out) return 0;
-    hipLaunchKernelGGL(k_halfband, dim3((n_out + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)zin,
+    PMR_KLAUNCH(k_halfband, dim3((n_out + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)zin,
                        (cf *)zout, n_out, keep_in, par, m, h1, scale);
     return (int)hipGetLastError();
 }
@@ -731,7 +731,7 @@ extern "C" int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out_ring, u
                               unsigned ny, uint32_t phase0, uint32_t step, const float *bank, int keep)
 {
     if (!ny) return 0;
-    hipLaunchKernelGGL(k_arb, dim3((ny + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)dec, (cf *)out_ring,
+    PMR_KLAUNCH(k_arb, dim3((ny + 255) / 256), dim3(256), 0, (hipStream_t)s, (const cf *)dec, (cf *)out_ring,
                        (unsigned long long)out_pos0, (unsigned long long)out_mask, ny, phase0, step, bank, keep);
     return (int)hipGetLastError();
 }
@@ -748,14 +748,14 @@ extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, u
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_channelize),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL(k_channelize, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p, ilog2(p->M), ft);
+    PMR_KLAUNCH(k_channelize, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p, ilog2(p->M), ft);
     return (int)hipGetLastError();
 }
 
 extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntiles, unsigned M,
                                       unsigned ns, float *rssi_db)
 {
-    hipLaunchKernelGGL(k_rssi_finish, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)s, rssi_part, ntiles, M, ns,
+    PMR_KLAUNCH(k_rssi_finish, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)s, rssi_part, ntiles, M, ns,
                        rssi_db);
     return (int)hipGetLastError();
 }
@@ -808,7 +808,7 @@ extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const f
     if ((mode == PMR_FIR_PAIR || mode == PMR_FIR_MFMA) && M >= 2) {
         const unsigned segs = (ns + FP_R - 1) / FP_R;
         const size_t threads = (size_t)segs * (M >> 1);
-        hipLaunchKernelGGL(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
+        PMR_KLAUNCH(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
                            (unsigned long long)row_mask, (long long)row0, ns, M,
                            ilog2(M >> 1), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
         return (int)hipGetLastError();
@@ -822,14 +822,14 @@ extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const f
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         const unsigned tiles = (ns + FL_T - 1) / FL_T;
-        hipLaunchKernelGGL(k_fir_lds, dim3(tiles * (M >> 4)), dim3(256), lds, (hipStream_t)s, in,
+        PMR_KLAUNCH(k_fir_lds, dim3(tiles * (M >> 4)), dim3(256), lds, (hipStream_t)s, in,
                            (unsigned long long)row_mask, (long long)row0, ns, M, taps_pad,
                            ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
         return (int)hipGetLastError();
     }
     const unsigned segs = (ns + PMR_AUDIO_R - 1) / PMR_AUDIO_R;
     const size_t threads = (size_t)segs * M;
-    hipLaunchKernelGGL(k_fir_tm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
+    PMR_KLAUNCH(k_fir_tm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
                        (unsigned long long)row_mask, (long long)row0, ns, M,
                        ilog2(M), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
     return (int)hipGetLastError();

@@ -104,8 +104,8 @@ extern "C" int pmr_launch_spgram(pmr_stream_t s, const void *xr, uint64_t xr_mas
     if (lds > 64 * 1024 && pmr_attr_needed(attr_set))
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgram), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(k_spgram, dim3(nwg), dim3(SG_NT), lds, st, (const cf *)xr, (unsigned long long)xr_mask, (unsigned long long)pos0,
+    PMR_KLAUNCH(k_spgram, dim3(nwg), dim3(SG_NT), lds, st, (const cf *)xr, (unsigned long long)xr_mask, (unsigned long long)pos0,
                        ny, wlen, log2P, n_tr, chunk, win, (const cf *)tw, partial);
-    hipLaunchKernelGGL(k_spgram_finish, dim3((P + SG_NT - 1) / SG_NT), dim3(SG_NT), 0, st, partial, nwg, P, n_tr, psd_mag);
+    PMR_KLAUNCH(k_spgram_finish, dim3((P + SG_NT - 1) / SG_NT), dim3(SG_NT), 0, st, partial, nwg, P, n_tr, psd_mag);
     return (int)hipGetLastError();
 }

@@ -8,13 +8,15 @@
 
 #include "../../include/pmr_mem.h"
 #include "../data/pmr446_taps.h"          /* pmr446_ctcss_freqs (reference :138-141) */
+#include "pmr_kernels.h"                  /* PMR_KLAUNCH, poison mode */
 
 extern "C" void *pmr_device_alloc(size_t bytes, int device)
 {
     if (device >= 0 && hipSetDevice(device) != hipSuccess) return NULL;
     void *p = NULL;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return NULL;
-    if (hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess) { (void)hipFree(p); return NULL; }
+    /* zero-filled; 0xFF bytes in the test-only poison mode (an output row the library was to write and did not then shows) */
+    if (hipMemset(p, pmr_debug_poison_enabled() ? 0xFF : 0, bytes ? bytes : 16) != hipSuccess) { (void)hipFree(p); return NULL; }
     return p;
 }
 extern "C" void pmr_device_free(void *p) { if (p) (void)hipFree(p); }
@@ -106,7 +108,7 @@ extern "C" int pmr_synth_iq_device(const pmr_synth_cfg *c, void *d_out, uint64_t
     const size_t chunk = (size_t)1 << 24;                                  // bounded launches
     for (size_t p0 = 0; p0 < n && e == hipSuccess; p0 += chunk) {
         const size_t m = n - p0 < chunk ? n - p0 : chunk;
-        hipLaunchKernelGGL(k_synth_iq, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, (float2 *)d_out + p0, n0 + p0, m, d_tab, nch,
+        PMR_KLAUNCH(k_synth_iq, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, (float2 *)d_out + p0, n0 + p0, m, d_tab, nch,
                            amp, sigma, seed);
         e = hipGetLastError();
     }

@@ -164,3 +164,118 @@ def test_ctcss_with_one_open_channel_is_the_references_mode(cfg, k, n, splits):
     g.set_channel_mask([k, ks[1] if ks[1] != k else ks[2]])
     e2 = g.process_block(x[:splits[0]], want=("pcm", "ctcss"))["ctcss"]
     assert e2.shape[0] == M
+
+
+def _feed_until(chains, x, pos, first, target_frames):
+    """Feed every chain the same blocks: `first` samples, then single frames' worth (192 samples at cfg2) until `target_frames`
+    frames have been channelized.  Returns (new position, [events per chain])."""
+    evs = [[] for _ in chains]
+    done = None
+    n = first
+    while done is None or done < target_frames:
+        nf = []
+        for i, c in enumerate(chains):
+            o = c.process_block(x[pos:pos + n], want=("pcm", "ctcss"))
+            evs[i].append(o["ctcss"]); nf.append(o["n_frames"])
+        assert len(set(nf)) == 1
+        done = nf[0] if done is None else done + nf[0]
+        pos += n
+        n = 192
+    assert done == target_frames
+    return pos, evs
+
+
+@pytest.mark.parametrize("extra_frames", [0, 700], ids=["on-a-block-boundary", "mid-block"])
+def test_reset_channel_with_the_detector_on(extra_frames):
+    """pmr_chain_reset_channel with the CTCSS detector running, against the oracle's freqdem_reset + ctcss_detector_reset
+    (reference src/sdr_pmr446.c:866-867).  The reference does NOT reset ctcss_dcblock (:606): every channel here
+    carries a 300 Hz carrier offset, i.e. dc in the discriminator output, so a wrongly zeroed blocker state would put a step
+    transient into the low Goertzel bins of the next block.
+    * reset on a Goertzel-block boundary: the GPU's shared 2441-frame grid and the oracle's restarted count coincide -- every event
+      of every channel, the reset one's first block included, equals the oracle's (powers within 0.5 %);
+    * reset in mid-block: the block in progress is incomplete for that channel -> {index -1, detected 0} (documented deviation:
+      the reference's single detector restarts its own block count instead, include/pmr_chain.h); the blocks after it decide like
+      the oracle's; every other channel is unaffected."""
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    N, k = 2441, 5
+    n = (5 * N + 1500) * 192
+    t = np.arange(n, dtype=np.float64) / fs
+    x = (synth.synth_iq(n, fs, M, dev_hz=1500.0, ctcss_dev_hz=700.0) * np.exp(2j * np.pi * 300.0 * t)).astype(np.complex64)
+    mb = 2 * N * 192
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb)
+    o_all = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=mb)
+    o_k = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=mb, only_channel=k)
+    chains = [g, o_all, o_k]
+    pos, ev1 = _feed_until(chains, x, 0, (2 * N - 30) * 192, 2 * N + extra_frames)
+    for c in chains:
+        c.reset_channel(k)
+    rest = [(N + 400) * 192, len(x) - pos - (N + 400) * 192]
+    ev2 = [[] for _ in chains]
+    for nb in rest:
+        for i, c in enumerate(chains):
+            ev2[i].append(c.process_block(x[pos:pos + nb], want=("pcm", "ctcss"))["ctcss"])
+        pos += nb
+    eg1, eo1 = np.concatenate(ev1[0], axis=1), np.concatenate(ev1[1], axis=1)
+    eg2, eo2, ek2 = (np.concatenate(e, axis=1) for e in ev2)
+    for c in chains:
+        c.close()
+    fm_ch = [c for c in active_channels(M) if synth.channel_kind(c) == "fm"]
+    assert k in fm_ch and eg1.shape == eo1.shape and eg1.shape[1] == 2
+    others = [c for c in fm_ch if c != k]
+
+    def same(a, b, chans):
+        for c in chans:
+            assert np.array_equal(a["index"][c], b["index"][c]) and np.array_equal(a["detected"][c], b["detected"][c]), c
+            assert np.allclose(a["max_power"][c], b["max_power"][c], rtol=5e-3), c
+            assert np.allclose(a["avg_power"][c], b["avg_power"][c], rtol=5e-3), c
+    same(eg1, eo1, fm_ch)                                     # before the reset
+    assert eg2.shape[1] >= 2
+    same(eg2, eo2[:, :eg2.shape[1]], others)                  # the other channels never notice
+    if extra_frames == 0:
+        assert ek2.shape[1] == eg2.shape[1]
+        same(eg2, ek2, [k])                                   # first block after the reset included: blocker state kept, sums from zero
+        assert np.all(ek2["detected"][k] == 1) and np.all(ek2["index"][k] == k % 38)
+    else:
+        assert eg2["index"][k, 0] == -1 and eg2["detected"][k, 0] == 0 and eg2["max_power"][k, 0] == 0.0
+        assert np.all(eg2["index"][k, 1:] == k % 38) and np.all(eg2["detected"][k, 1:] == 1)
+        assert np.all(ek2["index"][k] == k % 38) and np.all(ek2["detected"][k] == 1)      # ... as the reference decides on its own grid
+
+
+def test_reopened_channels_restart_and_events_follow_the_mask_of_their_block():
+    """(1) set_channel_mask(NULL) re-opens every channel -- the frozen partial Goertzel sums of the channels that were
+    closed must restart from zero like in the explicit-list path (their first, incomplete block reports no decision; afterwards
+    they decide like the oracle); (2) pmr_chain_ctcss_read reports a block's events under the mask THAT BLOCK ran with, not the
+    mask set since (reference: ctcss_execute runs for the active channel of the block in hand, src/sdr_pmr446.c:893)."""
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    N, k = 2441, 5
+    n = (6 * N) * 192
+    x = synth.synth_iq(n, fs, M, dev_hz=1500.0, ctcss_dev_hz=700.0)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=3 * N * 192)
+    fm_ch = [c for c in active_channels(M) if synth.channel_kind(c) == "fm"]
+    g.set_channel_mask([k])
+    n1 = (N + 900) * 192                                      # ends in mid-block
+    r1 = g.process_block(x[:n1], want=("pcm",))
+    g.ctcss_enable(True)
+    # (the detector was off for the first block: switch it on and run a block under the one-channel mask)
+    n2 = N * 192
+    g.process_block(x[n1:n1 + n2], want=("pcm", "ctcss"))
+    g.set_channel_mask([9])                                   # BEFORE reading: the events still describe the block run under {k}
+    ev = g.ctcss_read()
+    assert ev.shape[1] >= 1
+    assert ev["index"][k, -1] == k % 38 and ev["detected"][k, -1] == 1
+    assert np.all(ev["index"][[c for c in range(M) if c != k]] == -1)
+    g.set_channel_mask([k])
+    g.process_block(x[n1 + n2:n1 + 2 * n2], want=("pcm", "ctcss"))      # channel 9 closed again, k reopened in mid-block
+    g.set_channel_mask(None)                                  # everything opens, in mid-block
+    e3 = g.process_block(x[n1 + 2 * n2:n1 + 2 * n2 + 2 * N * 192 + 5000], want=("pcm", "ctcss"))["ctcss"]
+    g.close()
+    assert e3.shape[1] >= 2
+    for c in fm_ch:
+        if c == k:
+            continue
+        assert e3["index"][c, 0] == -1 and e3["detected"][c, 0] == 0, c        # incomplete block: no decision, and no stale sums
+        assert np.all(e3["index"][c, 1:] == c % 38) and np.all(e3["detected"][c, 1:] == 1), c
+    assert np.all(np.isfinite(e3["max_power"])) and np.all(np.isfinite(e3["avg_power"]))
+    assert r1["n_frames"] > N

@@ -18,7 +18,7 @@ from parity_util import CFG2, CFG3, CFG5, active_channels
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cfg,log2_block,floor_rest", [(CFG3, 24, 0.85), (CFG5, 24, 0.85)], ids=["cfg3", "cfg5"])
+@pytest.mark.parametrize("cfg,log2_block,floor_rest", [(CFG2, 22, 0.85), (CFG3, 24, 0.85), (CFG5, 24, 0.85)], ids=["cfg2", "cfg3", "cfg5"])
 def test_every_channel_loaded_pcm_within_one_lsb(cfg, log2_block, floor_rest):
     import oracle
     from sdr_pmr446_amd import chain, synth
