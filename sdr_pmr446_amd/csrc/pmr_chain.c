@@ -83,6 +83,8 @@ struct pmr_chain_s {
     float *d_arb_bank, *d_pfb_taps_t, *d_fft_tw, *d_nco_cs, *d_lam_thread_pow, *d_lam_tile_idx_pow;
     float *d_hp_pad, *d_lp_pad, *d_de_pad;
     unsigned hp_len, lp_len, de_len;
+    /* overlap-save FFT form of the audio FIR (pmr_fir_fft.hip): device tables per transform size (0: 1024, 1: 4096 points) */
+    int fft_ok; pmr_fir_fft_tab fft_tab[2]; float *d_fft_H[2], *d_fft_H2[2], *d_fft_TA[2], *d_fft_TB[2];
     pmr_dc_consts dcc;
 
     /* carried state / work buffers on the device */
@@ -224,6 +226,51 @@ static int upload_padded_taps(pmr_chain q, float **p, const float *h, unsigned n
     int rc = dev_upload(q, p, tmp, len);
     free(tmp);
     return rc;
+}
+
+/* Tables of the FFT form of the audio FIR for the folded tap set g[n] (pmr_fir_fft.hip): spectra in the kernel's position order and
+ * exact twiddles, both transform sizes.  h2 != NULL: the second tap set of the DUAL pass (CTCSS low-pass branch), zero-extended to n. */
+static int fir_fft_upload_spectrum(pmr_chain q, float **dst, unsigned N, const float *h, unsigned n)
+{
+    float *H = (float *)malloc((size_t)N * 2 * sizeof(float));
+    if (!H) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
+    pmr_fir_fft_spectrum(N, h, n, H);
+    const int rc = dev_upload(q, dst, H, (size_t)N * 2);
+    free(H);
+    return rc;
+}
+
+static int fir_fft_init(pmr_chain q, const float *g, unsigned n)
+{
+    q->fft_ok = 0;
+    if (q->sw.fir_mode != PMR_FIR_MFMA || q->sw.fir_direct || q->cfg.deemph_fir || q->cfg.lowpass || !pmr_fir_fft_supported(q->M, n))
+        return PMR_OK;
+    for (int w = 0; w < 2; w++) {
+        const unsigned N = pmr_fir_fft_size(w);
+        int rc = fir_fft_upload_spectrum(q, &q->d_fft_H[w], N, g, n);
+        if (rc) return rc;
+        float *ta = (float *)malloc((size_t)15 * (N / 16) * 2 * sizeof(float)), *tbv = (float *)malloc((size_t)(N / 256) * 16 * 2 * sizeof(float));
+        if (!ta || !tbv) { free(ta); free(tbv); return fail(q, PMR_ENOMEM, "malloc", hipSuccess); }
+        pmr_fir_fft_twiddles(N, ta, tbv);
+        rc = dev_upload(q, &q->d_fft_TA[w], ta, (size_t)15 * (N / 16) * 2);
+        if (!rc) rc = dev_upload(q, &q->d_fft_TB[w], tbv, (size_t)(N / 256) * 16 * 2);
+        free(ta); free(tbv);
+        if (rc) return rc;
+        q->fft_tab[w].H = q->d_fft_H[w]; q->fft_tab[w].H2 = NULL; q->fft_tab[w].TA = q->d_fft_TA[w]; q->fft_tab[w].TB = q->d_fft_TB[w];
+    }
+    q->fft_ok = 1;
+    return PMR_OK;
+}
+
+/* Which form runs the audio FIR of this block?  The FFT form where the block is large (>= 2^17 output samples: every 2^22+-sample
+ * block of cfg2 / cfg3 / cfg5, all channels or one), the 4096-point transform where a channel has at least one full block of it;
+ * small blocks (the reference's 100 000-sample calls: 1220 frames x 16) keep the direct MFMA form and its RSSI rider.
+ * Returns -1 (direct), 0 (1024 points) or 1 (4096 points). */
+static int fir_fft_pick(const struct pmr_chain_s *q, unsigned ns, unsigned nchan)
+{
+    if (!q->fft_ok || (unsigned long long)ns * nchan < (1ull << 17)) return -1;
+    if (q->sw.fir_fft_n) return q->sw.fir_fft_n == 4096 ? 1 : 0;
+    return ns >= 4096u ? 1 : 0;
 }
 
 /* ---- profiling helpers: HIP events on the chain's stream around every launch ---- */
@@ -603,6 +650,7 @@ static int chain_init(pmr_chain q)
             g[i] = (float)((double)q->cfg.audio_gain * acc);
         }
         rc = upload_padded_taps(q, &q->d_hp_pad, g, n);
+        if (!rc) rc = fir_fft_init(q, g, n);
         free(g);
         if (rc) return rc;
         q->hp_len_raw = q->hp_len;
@@ -687,6 +735,8 @@ static void read_switches(pmr_switches *w)
     { const char *e = getenv("PMR_CHAN_FT"); w->chan_ft = e ? atoi(e) : 0; }
     w->fir_mode = env_is("PMR_FIR", "pair") ? PMR_FIR_PAIR : env_is("PMR_FIR", "lds") ? PMR_FIR_LDS
                 : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
+    w->fir_direct = env_is("PMR_FIR", "direct");
+    { const char *e = getenv("PMR_FIR_FFT_N"); w->fir_fft_n = e ? atoi(e) : 0; }
     w->fir_mfma_global = env_is("PMR_FIR_MFMA", "global");
     w->fir_mfma32 = env_is("PMR_FIR_MFMA", "32");
     w->fir_mfma4 = env_is("PMR_FIR_MFMA", "4");
@@ -806,7 +856,8 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_fe_vstate[1], q->d_fe_probeA, q->d_fe_probeB, q->d_fe_probeL, q->d_fe_probeE, q->d_fe_V[0],
                      q->d_fe_V[1], q->d_fe_V[2], q->d_fe_G12, q->d_fe_GAK, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_lampow, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events, q->d_ct_restart,
-                     q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1 };
+                     q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1,
+                     q->d_fft_H[0], q->d_fft_H[1], q->d_fft_H2[0], q->d_fft_H2[1], q->d_fft_TA[0], q->d_fft_TA[1], q->d_fft_TB[0], q->d_fft_TB[1] };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
         pmr_slot *sl = &q->slot[i];
@@ -1372,7 +1423,15 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on)
              * in ONE pass of the MFMA kernel (pmr_launch_fir_dual) */
             float *te = (float *)calloc(q->hp_len, sizeof(float));
             if (!te) rc = fail(q, PMR_ENOMEM, "calloc", hipSuccess);
-            else { memcpy(te, tc, n * sizeof(float)); rc = upload_padded_taps(q, &q->d_ct_taps_ext, te, q->hp_len); free(te); }
+            else {
+                memcpy(te, tc, n * sizeof(float));
+                rc = upload_padded_taps(q, &q->d_ct_taps_ext, te, q->hp_len);
+                for (int w = 0; w < 2 && !rc && q->fft_ok; w++) {      /* the low-pass branch as the FFT form's second product */
+                    rc = fir_fft_upload_spectrum(q, &q->d_fft_H2[w], pmr_fir_fft_size(w), te, q->hp_len);
+                    q->fft_tab[w].H2 = q->d_fft_H2[w];
+                }
+                free(te);
+            }
         }
         free(tc);
         if (rc) return rc;
@@ -1459,8 +1518,19 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
     int rc;
     /* audio: HP (:882) -> gain (:890) -> de-emphasis (:895-899) -> optional LP (:900-902) -> sink (:903-906); with the CTCSS
      * detector on, its low-pass branch delay188(x) - hp(x) (:884-889) is a second tap set over the same samples: one pass */
-    int ct_fir_done = 0, rssi_rode = 0;
-    if (q->ct_on && q->d_ct_taps_ext && !q->sw.fir_nodual && (d_pcm || d_audio) && !q->cfg.deemph_fir && !q->cfg.lowpass) {
+    int ct_fir_done = 0, rssi_rode = 0, audio_done = 0;
+    {
+        /* large blocks: overlap-save FFT form (pmr_fir_fft.hip); with the detector on its low-pass branch is the second product */
+        const int dual = q->ct_on && q->fft_ok && q->fft_tab[0].H2 && !q->sw.fir_nodual;
+        const int which = (d_pcm || d_audio) && (!q->ct_on || dual) ? fir_fft_pick(q, ns, q->mask_on ? q->n_enabled : M) : -1;
+        if (which >= 0) {
+            LAUNCH(K_FIR_HP, pmr_launch_fir_fft(q->stream, which, &q->fft_tab[which], q->d_fm, q->fm_mask, frame0, ns, M, q->hp_len,
+                                                (int16_t *)d_pcm, (float *)d_audio, pcm_stride, dual ? q->d_ctlp : NULL,
+                                                q->mask_on ? q->d_chan_list : NULL, q->n_enabled));
+            audio_done = 1; ct_fir_done = dual;
+        }
+    }
+    if (!audio_done && q->ct_on && q->d_ct_taps_ext && !q->sw.fir_nodual && (d_pcm || d_audio) && !q->cfg.deemph_fir && !q->cfg.lowpass) {
         prof_pending pp_; prof_begin(q, K_FIR_HP, &pp_, q->stream);
         const int rd = pmr_launch_fir_dual(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->d_ct_taps_ext,
                                            q->hp_len, (int16_t *)d_pcm, (float *)d_audio, pcm_stride, q->d_ctlp,
@@ -1471,7 +1541,7 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
     }
     if (q->ct_on && (rc = ctcss_run(q, frame0, ns, ct_fir_done))) return rc;
 
-    if (!ct_fir_done && (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass)) {
+    if (!audio_done && !ct_fir_done && (d_pcm || d_audio || q->cfg.deemph_fir || q->cfg.lowpass)) {
         const int more = q->cfg.deemph_fir || q->cfg.lowpass;
         /* only the open channels are demodulated to audio.  With follow-on FIR passes (deemph_fir / lowpass) the mask
          * applies to the LAST pass only: the intermediate rings must keep every channel's history current, or a channel

@@ -1,0 +1,354 @@
+// pmr_fir_fft.hip -- the audio FIR of large blocks by overlap-save FFT convolution.
+//
+// reference: firfilt_rrrf_execute_block(ctcss_filt ...) src/sdr_pmr446.c:882 (377-tap high-pass), gain :890, de-emphasis :895-899,
+//            PCM hand-off :903-906 / src/dsd_in.c:172-175; the complementary CTCSS low-pass branch delay188(x) - hp(x) :884-889.
+//
+// Why: demodulating ALL M channels makes this filter the FLOP hot spot of the back end -- 383 MACs per audio sample (gain and the
+// truncated de-emphasis response are folded into the taps, pmr_chain.c).  The direct form on the matrix pipe (pmr_fir_mfma4.hip,
+// pmr_fir_mfma.hip: exact k-ordered f32 chains) is bound by the f32 MFMA rate: 0.030 ms per cfg2 block at the 155 TFLOP/s peak,
+// 0.055 measured -- a third of the back end's CU time, and the two streams of the chain time-slice the CUs.  The same LINEAR
+// filter through a 4096-point FFT costs ~50 vector instructions per output sample instead of 766 FLOP:
+//     y = IFFT( FFT(x block) . H ),   H = FFT(taps),   block = N samples, the last N - (ntaps-1) outputs of each are valid,
+// i.e. the identical filter, evaluated with different f32 roundings (|error| ~ 6e-7 of the signal scale against 1e-5 allowed;
+// int16 PCM within +-1 LSB of the CPU reference as before -- tests/test_gpu_fir_fft.py; the direct MFMA form stays the path of
+// small blocks, of the open-channel gather and of the follow-on FIR passes, and `PMR_FIR=direct` selects it everywhere).
+//
+// Formulation (one workgroup = one PAIR of channels x one block of N frames):
+//  * the taps are real, so TWO channels share one complex transform: z = x_a + j x_b, y = h * z = (h * x_a) + j (h * x_b) -- no
+//    untangling pass, H is the plain N-point spectrum of the taps;
+//  * N = 16 . 16 . R2 (R2 = 16: N = 4096, 256 threads; R2 = 4: N = 1024, 64 threads), 16 points per thread, three register
+//    phases with two LDS exchanges per direction:
+//        forward  (decimation in frequency):  A: radix-16 over n0 (stride N/16), x W_N^(r k0)    B: radix-16 over n1, x W_(N/16)^(n2 k1)
+//                                             C: radix-R2 over n2 -> X[k0 + 16 k1 + 256 k2] at position k0 N/16 + k1 R2 + k2
+//        inverse  (decimation in time, the transposed graph, conjugate twiddles): C', B', A' -> natural order.
+//    The forward pass leaves the spectrum digit-reversed, the inverse pass accepts it that way: H is stored in position order by
+//    the host (pmr_fir_fft_tables), and phase C, the product with H and phase C' happen in registers without an exchange;
+//  * twiddles: exact tables computed in double by the host.  A thread keeps its 15 phase-A factors W_N^(t k0) in registers (they
+//    serve A and, conjugated, A'); the 16 x R2 phase-B factors sit in LDS;
+//  * LDS: position p at p + (p >> 4) (one float2 of padding per 16): every access pattern of the three phases is conflict-free;
+//    34.8 KB per workgroup at N = 4096 (8.7 KB at N = 1024);
+//  * loads: lane t of a wave reads the two channels' samples of row (block start + n0 N/16 + t) -- 8 bytes per row; the 8 / 128
+//    pair-workgroups that share a row's cache lines are made neighbours on ONE XCD (pmr_xcd_contiguous) so the rows come from HBM
+//    once; rows beyond the call's last frame read as zero (whatever the ring holds there never enters the transform);
+//  * stores: lane t holds frames (block start + n0 N/16 + t): consecutive lanes = consecutive int16 / float of a channel row;
+//  * DUAL (CTCSS detector on): the spectrum is parked in a second LDS buffer and multiplied by a second H (delta_188 - hp) ->
+//    second inverse transform -> time-major low-pass ring, same forward transform;
+//  * open-channel list (reference :876-877): the pairs are taken from the list (an odd last channel is paired with itself).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pmr_kernels.h"
+
+typedef float2 cf2;
+
+static __device__ __forceinline__ cf2 cmul(cf2 a, cf2 w) { return make_float2(fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y)); }
+static __device__ __forceinline__ cf2 cmulc(cf2 a, cf2 w) { return make_float2(fmaf(a.y, w.y, a.x * w.x), fmaf(a.y, w.x, -(a.x * w.y))); }   // a conj(w)
+
+static __device__ __forceinline__ int16_t ff_pcm16(float y)
+{
+    float s = y * 32767.0f;                                        // trunc(x * 32767), saturated (src/dsd_in.c:174); NaN -> 0
+    s = s == s ? s : 0.f;
+    s = __builtin_fminf(__builtin_fmaxf(s, -32768.0f), 32767.0f);
+    return (int16_t)(int)s;
+}
+
+// 4-point DFT in place: (a, b, c, d) = x[0..3] -> X[0..3]; forward kernel e^(-j 2 pi nk / 4), INV: e^(+j ...)
+template <bool INV>
+static __device__ __forceinline__ void r4(cf2 &a, cf2 &b, cf2 &c, cf2 &d)
+{
+    const cf2 s0 = make_float2(a.x + c.x, a.y + c.y), s1 = make_float2(a.x - c.x, a.y - c.y);
+    const cf2 s2 = make_float2(b.x + d.x, b.y + d.y), s3 = make_float2(b.x - d.x, b.y - d.y);
+    a = make_float2(s0.x + s2.x, s0.y + s2.y);
+    c = make_float2(s0.x - s2.x, s0.y - s2.y);
+    const cf2 p = make_float2(s1.x + s3.y, s1.y - s3.x), m = make_float2(s1.x - s3.y, s1.y + s3.x);   // s1 - j s3, s1 + j s3
+    b = INV ? m : p;
+    d = INV ? p : m;
+}
+
+// 16-point DFT of v[0..15] (natural order in).  OUT ORDER: X[k] is left in v[R16P(k)], R16P(k) = 4 (k & 3) + (k >> 2).
+#define R16P(k) (4 * ((k) & 3) + ((k) >> 2))
+template <bool INV>
+static __device__ __forceinline__ void r16(cf2 (&v)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, RH = 0.70710678118654752f;
+#pragma unroll
+    for (int b = 0; b < 4; b++) r4<INV>(v[b], v[4 + b], v[8 + b], v[12 + b]);            // over a (n = 4 a + b): v[4 c + b] = u_b[c]
+    // u_b[c] *= W16^(b c)   (conjugated for the inverse)
+    const float sg = INV ? 1.f : -1.f;
+    const cf2 w1 = make_float2(C1, sg * S1), w2 = make_float2(RH, sg * RH), w3 = make_float2(S1, sg * C1);
+    const cf2 w6 = make_float2(-RH, sg * RH), w9 = make_float2(-C1, -sg * S1);
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], w1);                                                  // (c, b) = (1, 1)
+    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], w2);
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], w3);
+    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], w2);
+    { const cf2 t = v[4 * 2 + 2]; v[4 * 2 + 2] = INV ? make_float2(-t.y, t.x) : make_float2(t.y, -t.x); }   // W16^4 = -j
+    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], w6);
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], w3);
+    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], w6);
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], w9);
+#pragma unroll
+    for (int c = 0; c < 4; c++) r4<INV>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   // over b: v[4 c + d] = X[c + 4 d]
+}
+
+struct ff_params {
+    const float *in; unsigned long long row_mask; long long row0; unsigned ns, M;
+    const cf2 *H, *H2;                 // [N] spectra of the taps / N, POSITION order (pmr_fir_fft_tables)
+    const cf2 *TA;                     // [15][N/16]  W_N^(t k0), k0 = 1..15
+    const cf2 *TB;                     // [R2][16]    W_(N/16)^(n2 k1)
+    int16_t *pcm; float *audio; unsigned stride;
+    float *out2_tm;                    // DUAL: time-major ring of the second product
+    const unsigned *chan_list; unsigned n_chan, npairs, ntaps;
+};
+
+#define FF_IDX(p) ((p) + ((p) >> 4))
+
+// Phases C, x H, C' of one thread, in registers.  PARK: `src` (= zs) holds phase B's output -- run the forward radix-R2 and (DUAL)
+// park the spectrum in zs2; !PARK: `src` (= zs2) holds the parked spectrum.  Leaves C' output in zs (own positions only).
+// R2 = 16: thread t owns positions 16 t .. 16 t + 15 (k0 = t >> 4, k1 = t & 15); R2 = 4: four runs of 4 (combo c = t + 64 j).
+template <int R2, bool DUAL, bool PARK>
+static __device__ __forceinline__ void ff_phase_c(cf2 *zs, cf2 *zs2, const cf2 *src, const cf2 *__restrict__ Hp, unsigned t)
+{
+    if constexpr (R2 == 16) {
+        cf2 u[16], w[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) u[n2] = src[FF_IDX(16 * t + n2)];
+        if constexpr (PARK) {
+            r16<false>(u);
+            if constexpr (DUAL) {
+#pragma unroll
+                for (int k2 = 0; k2 < 16; k2++) zs2[FF_IDX(16 * t + k2)] = u[R16P(k2)];
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) w[k2] = cmul(PARK ? u[R16P(k2)] : u[k2], Hp[16 * t + k2]);
+        r16<true>(w);
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) zs[FF_IDX(16 * t + n2)] = w[R16P(n2)];
+    } else {
+        static_assert(R2 == 4, "radix of the last phase");
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned c = t + 64u * j;
+            cf2 u[4];
+#pragma unroll
+            for (int n2 = 0; n2 < 4; n2++) u[n2] = src[FF_IDX(4 * c + n2)];
+            if constexpr (PARK) {
+                r4<false>(u[0], u[1], u[2], u[3]);
+                if constexpr (DUAL) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; k2++) zs2[FF_IDX(4 * c + k2)] = u[k2];
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) u[k2] = cmul(u[k2], Hp[4 * c + k2]);
+            r4<true>(u[0], u[1], u[2], u[3]);
+#pragma unroll
+            for (int n2 = 0; n2 < 4; n2++) zs[FF_IDX(4 * c + n2)] = u[n2];
+        }
+    }
+}
+
+template <int R2, bool DUAL>
+__global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
+{
+    constexpr int N0 = 16 * R2, N = 256 * R2, NT = N0;
+    extern __shared__ __attribute__((aligned(16))) char smem_ff[];
+    cf2 *zs = reinterpret_cast<cf2 *>(smem_ff);                    // [N + N / 16]
+    cf2 *tb = zs + (N + N / 16);                                   // [R2][16]
+    cf2 *zs2 = tb + R2 * 16;                                       // DUAL: the parked spectrum, [N + N / 16]
+    const unsigned t = threadIdx.x;
+    const unsigned unit = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
+    const unsigned blk = unit / P.npairs, pair = unit % P.npairs;
+    const unsigned L = (unsigned)N - (P.ntaps - 1);                // valid outputs per block
+    unsigned ca, cb; bool has_b;
+    {
+        const unsigned i0 = 2 * pair, i1 = 2 * pair + 1;
+        has_b = i1 < P.n_chan;
+        ca = P.chan_list ? P.chan_list[i0] : i0;
+        cb = has_b ? (P.chan_list ? P.chan_list[i1] : i1) : ca;
+    }
+    const bool adjacent = cb == ca + 1 && !(ca & 1u);
+    const long long blk_start = P.row0 + (long long)blk * L - (long long)(P.ntaps - 1);   // frame of transform index 0
+    const long long end = P.row0 + (long long)P.ns;
+
+    // phase-B twiddles -> LDS, phase-A twiddles -> registers, the block's samples -> registers: all in flight together
+    for (unsigned i = t; i < (unsigned)(R2 * 16); i += NT) tb[i] = P.TB[i];
+    // (the 15 + 15 twiddles of a thread are re-read where they are used -- global table through L1 for A / A', LDS for B / B' --
+    //  instead of living in 60 registers across the whole kernel: the register count decides whether a wave of this kernel still
+    //  fits on a SIMD beside four front-end tiles)
+    cf2 v[16];
+#pragma unroll
+    for (int n0 = 0; n0 < 16; n0++) {
+        const long long row = blk_start + n0 * N0 + (long long)t;
+        v[n0] = make_float2(0.f, 0.f);
+        if (row < end) {
+            const float *src = P.in + ((unsigned long long)row & P.row_mask) * P.M;
+            if (adjacent) v[n0] = *reinterpret_cast<const cf2 *>(src + ca);
+            else v[n0] = make_float2(src[ca], src[cb]);
+        }
+    }
+
+    // ---- A: radix-16 over n0, x W_N^(t k0), -> position k0 N0 + t ----
+    {
+        cf2 wA[16];
+#pragma unroll
+        for (int k0 = 1; k0 < 16; k0++) wA[k0] = P.TA[(k0 - 1) * N0 + t];
+        r16<false>(v);
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0++) {
+            const cf2 x = k0 ? cmul(v[R16P(k0)], wA[k0]) : v[R16P(0)];
+            zs[FF_IDX(k0 * N0 + t)] = x;
+        }
+    }
+    __syncthreads();
+
+    // ---- B: thread (k0, n2): radix-16 over n1 (positions k0 N0 + n1 R2 + n2), x W_N0^(n2 k1), in place ----
+    const unsigned k0B = t / R2, n2B = t % R2, baseB = k0B * N0 + n2B;
+    {
+        cf2 u[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) u[n1] = zs[FF_IDX(baseB + n1 * R2)];
+        r16<false>(u);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) zs[FF_IDX(baseB + k1 * R2)] = k1 ? cmul(u[R16P(k1)], tb[n2B * 16 + k1]) : u[R16P(0)];
+    }
+    __syncthreads();
+
+    // ---- C, x H, C': in registers (ff_phase_c) ----
+    // ---- B', A': the inverse of B and A (conjugate twiddles BEFORE the butterflies), result in v[R16P(n0)] ----
+    auto inverse_BA = [&]() {
+        __syncthreads();
+        {
+            cf2 u[16];
+#pragma unroll
+            for (int k1 = 0; k1 < 16; k1++) {
+                const cf2 x = zs[FF_IDX(baseB + k1 * R2)];
+                u[k1] = k1 ? cmulc(x, tb[n2B * 16 + k1]) : x;
+            }
+            r16<true>(u);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; n1++) zs[FF_IDX(baseB + n1 * R2)] = u[R16P(n1)];
+        }
+        cf2 wA[16];
+#pragma unroll
+        for (int k0 = 1; k0 < 16; k0++) wA[k0] = P.TA[(k0 - 1) * N0 + t];      // (in flight across the barrier)
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0++) {
+            const cf2 x = zs[FF_IDX(k0 * N0 + t)];
+            v[k0] = k0 ? cmulc(x, wA[k0]) : x;
+        }
+        r16<true>(v);
+    };
+
+    ff_phase_c<R2, DUAL, true>(zs, zs2, zs, P.H, t);
+    inverse_BA();
+    // ---- outputs: transform index n = n0 N0 + t is frame blk_start + n; indices >= ntaps - 1 are valid ----
+#pragma unroll
+    for (int n0 = 0; n0 < 16; n0++) {
+        const unsigned n = n0 * N0 + t;
+        const long long f = blk_start + (long long)n;
+        if (n >= P.ntaps - 1 && f < end) {
+            const cf2 y = v[R16P(n0)];
+            const size_t o = (size_t)(f - P.row0);
+            if (P.pcm) {
+                P.pcm[(size_t)ca * P.stride + o] = ff_pcm16(y.x);
+                if (has_b) P.pcm[(size_t)cb * P.stride + o] = ff_pcm16(y.y);
+            }
+            if (P.audio) {
+                P.audio[(size_t)ca * P.stride + o] = y.x;
+                if (has_b) P.audio[(size_t)cb * P.stride + o] = y.y;
+            }
+        }
+    }
+    if constexpr (DUAL) {
+        __syncthreads();                                           // every thread has read its A' inputs: zs is free again
+        ff_phase_c<R2, DUAL, false>(zs, zs2, zs2, P.H2, t);
+        inverse_BA();
+#pragma unroll
+        for (int n0 = 0; n0 < 16; n0++) {
+            const unsigned n = n0 * N0 + t;
+            const long long f = blk_start + (long long)n;
+            if (n >= P.ntaps - 1 && f < end) {
+                const cf2 y = v[R16P(n0)];
+                float *dst = P.out2_tm + ((unsigned long long)f & P.row_mask) * P.M;
+                if (adjacent) *reinterpret_cast<cf2 *>(dst + ca) = y;
+                else { dst[ca] = y.x; if (has_b) dst[cb] = y.y; }
+            }
+        }
+    }
+}
+
+// ---- host side: the tables of one transform size, in double ----
+// H[p] (position order): p = k0 N0 + k1 R2 + k2  <->  bin k = k0 + 16 k1 + 256 k2;  H[p] = (1/N) sum_d h[d] e^(-j 2 pi k d / N)
+extern "C" unsigned pmr_fir_fft_size(int which) { return which ? 4096u : 1024u; }
+
+extern "C" void pmr_fir_fft_spectrum(unsigned N, const float *h, unsigned ntaps, float *H_out /*[2 N]*/)
+{
+    const unsigned R2 = N / 256, N0 = N / 16;
+    const double w0 = -2.0 * M_PI / (double)N;
+    for (unsigned p = 0; p < N; p++) {
+        const unsigned k0 = p / N0, k1 = (p % N0) / R2, k2 = p % R2, k = k0 + 16 * k1 + 256 * k2;
+        double re = 0.0, im = 0.0;
+        for (unsigned d = 0; d < ntaps; d++) {
+            const double a = w0 * (double)(((unsigned long long)k * d) % N);
+            re += (double)h[d] * cos(a); im += (double)h[d] * sin(a);
+        }
+        H_out[2 * p] = (float)(re / (double)N); H_out[2 * p + 1] = (float)(im / (double)N);
+    }
+}
+
+extern "C" void pmr_fir_fft_twiddles(unsigned N, float *TA /*[15][N/16][2]*/, float *TB /*[N/256][16][2]*/)
+{
+    const unsigned R2 = N / 256, N0 = N / 16;
+    for (unsigned k0 = 1; k0 < 16; k0++)
+        for (unsigned t = 0; t < N0; t++) {
+            const double a = -2.0 * M_PI * (double)((t * k0) % N) / (double)N;
+            TA[2 * ((k0 - 1) * N0 + t)] = (float)cos(a); TA[2 * ((k0 - 1) * N0 + t) + 1] = (float)sin(a);
+        }
+    for (unsigned n2 = 0; n2 < R2; n2++)
+        for (unsigned k1 = 0; k1 < 16; k1++) {
+            const double a = -2.0 * M_PI * (double)((n2 * k1) % N0) / (double)N0;
+            TB[2 * (n2 * 16 + k1)] = (float)cos(a); TB[2 * (n2 * 16 + k1) + 1] = (float)sin(a);
+        }
+}
+
+extern "C" int pmr_fir_fft_supported(unsigned M, unsigned ntaps)
+{
+    return M >= 1 && ntaps >= 2 && ntaps <= 512;                   // >= half of the smallest transform stays output
+}
+
+// which: 0 = N 1024, 1 = N 4096.  tab: the device tables of that size.
+extern "C" int pmr_launch_fir_fft(pmr_stream_t s, int which, const pmr_fir_fft_tab *tab, const float *in, uint64_t row_mask, int64_t row0,
+                                  unsigned ns, unsigned M, unsigned ntaps, int16_t *pcm, float *audio, unsigned stride,
+                                  float *out2_tm, const unsigned *chan_list, unsigned n_chan)
+{
+    if (!ns) return 0;
+    const unsigned nc = chan_list ? n_chan : M;
+    if (!nc) return 0;
+    if (!tab || !tab->H || !tab->TA || !tab->TB || (out2_tm && !tab->H2)) return (int)hipErrorInvalidValue;
+    const unsigned N = which ? 4096u : 1024u, L = N - (ntaps - 1);
+    ff_params P;
+    P.in = in; P.row_mask = (unsigned long long)row_mask; P.row0 = (long long)row0; P.ns = ns; P.M = M;
+    P.H = (const cf2 *)tab->H; P.H2 = (const cf2 *)tab->H2; P.TA = (const cf2 *)tab->TA; P.TB = (const cf2 *)tab->TB;
+    P.pcm = pcm; P.audio = audio; P.stride = stride; P.out2_tm = out2_tm;
+    P.chan_list = chan_list; P.n_chan = nc; P.npairs = (nc + 1) / 2; P.ntaps = ntaps;
+    const unsigned nblk = (ns + L - 1) / L;
+    const unsigned long long units = (unsigned long long)nblk * P.npairs;
+    if (units > 0x7fffffffull) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)units);
+    const size_t buf = (size_t)(N + N / 16) * sizeof(cf2), tbb = (size_t)(N / 256) * 16 * sizeof(cf2);
+    hipStream_t st = (hipStream_t)s;
+    if (which) {
+        if (out2_tm) {
+            static pmr_attr_flags once;
+            if (pmr_attr_needed(once))
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_fft<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            PMR_KLAUNCH((k_fir_fft<16, true>), grid, dim3(256), 2 * buf + tbb, st, P);
+        } else PMR_KLAUNCH((k_fir_fft<16, false>), grid, dim3(256), buf + tbb, st, P);
+    } else {
+        if (out2_tm) PMR_KLAUNCH((k_fir_fft<4, true>), grid, dim3(64), 2 * buf + tbb, st, P);
+        else PMR_KLAUNCH((k_fir_fft<4, false>), grid, dim3(64), buf + tbb, st, P);
+    }
+    return (int)hipGetLastError();
+}

@@ -202,7 +202,7 @@ def test_reset_channel_with_the_detector_on(extra_frames):
     n = (5 * N + 1500) * 192
     t = np.arange(n, dtype=np.float64) / fs
     x = (synth.synth_iq(n, fs, M, dev_hz=1500.0, ctcss_dev_hz=700.0) * np.exp(2j * np.pi * 300.0 * t)).astype(np.complex64)
-    mb = 2 * N * 192
+    mb = 3 * N * 192
     g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb)
     o_all = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=mb)
     o_k = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=mb, only_channel=k)
