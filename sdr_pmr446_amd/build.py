@@ -12,6 +12,7 @@ C_SOURCES = ["pmr_chain.c", "pmr_design.c", "pmr_squelch.c", "pmr_dsd.c", "pmr_i
 HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_fe_fast.hip", "pmr_channelize_small.hip", "pmr_channelize_wide.hip", "pmr_fir_mfma.hip", "pmr_fir_mfma4.hip", "pmr_fir_fft.hip", "pmr_ctcss.hip", "pmr_synth.hip", "pmr_spectrum.hip",
                "pmr_dsd_kernels.hip", "pmr_poison.hip"]
 EXTRA_HIP_FLAGS = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
+EXTRA_C_FLAGS = os.environ.get("PMR_CC_FLAGS", "").split()          # experiment builds only (tools/variant_bench.sh)
 HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_internal.h", "pmr_fe_common.hpp", "pmr_carry_load.hpp", os.path.join("..", "..", "include", "pmr_chain.h"),
            os.path.join("..", "..", "include", "pmr_dsd.h"), os.path.join("..", "..", "include", "pmr_io.h"), os.path.join("..", "..", "include", "pmr_mem.h"),
            os.path.join("..", "data", "pmr446_taps.h")]
@@ -37,7 +38,7 @@ def build(force=False, verbose=False):
     for f in C_SOURCES:
         o = os.path.join(CSRC, f[:-2] + ".o")
         cmd = ["gcc", "-std=gnu11", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
-               "-I" + os.path.join(ROCM, "include"), "-c", os.path.join(CSRC, f), "-o", o]
+               "-I" + os.path.join(ROCM, "include")] + EXTRA_C_FLAGS + ["-c", os.path.join(CSRC, f), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

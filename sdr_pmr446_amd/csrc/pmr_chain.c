@@ -263,14 +263,19 @@ static int fir_fft_init(pmr_chain q, const float *g, unsigned n)
 }
 
 /* Which form runs the audio FIR of this block?  The FFT form where the block is large (>= 2^17 output samples: every 2^22+-sample
- * block of cfg2 / cfg3 / cfg5, all channels or one), the 4096-point transform where a channel has at least one full block of it;
- * small blocks (the reference's 100 000-sample calls: 1220 frames x 16) keep the direct MFMA form and its RSSI rider.
+ * block of cfg2 / cfg3 / cfg5, all channels or one); small blocks (the reference's 100 000-sample calls: 1220 frames x 16) keep the
+ * direct MFMA form and its RSSI rider.  Transform size: 1024 points -- one-wave workgroups with 8.7 KB of LDS that fit beside the
+ * front end's tiles.  The 4096-point form does 0.7x the arithmetic (92 % instead of 63 % of a block is output) and is the faster
+ * kernel alone at cfg3, but in the chain it measured 4 % slower at cfg2 and equal at cfg3 (profiles/r04_ab_log.txt): it is
+ * compiled in and selected from FF_N4096_MIN_NS frames per call on (tools/variant_bench.sh builds; default: never).
  * Returns -1 (direct), 0 (1024 points) or 1 (4096 points). */
+#ifndef FF_N4096_MIN_NS
+#define FF_N4096_MIN_NS 0xffffffffu
+#endif
 static int fir_fft_pick(const struct pmr_chain_s *q, unsigned ns, unsigned nchan)
 {
     if (!q->fft_ok || (unsigned long long)ns * nchan < (1ull << 17)) return -1;
-    if (q->sw.fir_fft_n) return q->sw.fir_fft_n == 4096 ? 1 : 0;
-    return ns >= 4096u ? 1 : 0;
+    return ns >= FF_N4096_MIN_NS ? 1 : 0;
 }
 
 /* ---- profiling helpers: HIP events on the chain's stream around every launch ---- */
@@ -736,7 +741,6 @@ static void read_switches(pmr_switches *w)
     w->fir_mode = env_is("PMR_FIR", "pair") ? PMR_FIR_PAIR : env_is("PMR_FIR", "lds") ? PMR_FIR_LDS
                 : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
     w->fir_direct = env_is("PMR_FIR", "direct");
-    { const char *e = getenv("PMR_FIR_FFT_N"); w->fir_fft_n = e ? atoi(e) : 0; }
     w->fir_mfma_global = env_is("PMR_FIR_MFMA", "global");
     w->fir_mfma32 = env_is("PMR_FIR_MFMA", "32");
     w->fir_mfma4 = env_is("PMR_FIR_MFMA", "4");
@@ -799,7 +803,10 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
      * priorities: profiles/r03_ab_log.txt r43-r46), and 20-step regions went bimodal (525 / 556).  Equal priorities have no such
      * cliff: 537-541 at both region lengths.  One-level plans never wanted it (cfg3 -6.5 %, cfg2 -13 %).
      * PMR_STREAM_PRIO=1 / =fe force back end high / front end high for A/B runs. */
-    const int fe_high = q->sw.be_prio == 2;
+    /* Round 4: with the FFT form of the audio FIR (8.7 KB of LDS per one-wave workgroup) that cliff is gone, and two-level plans get
+     * the front-end stream high again: cfg5 +1.5-2 % on three boxes (538 -> 547, 555 -> 562 GS/s); one-level plans stay equal (cfg3
+     * +-0 on one box, +2.6 % on another; cfg2 -9 %: its back-end stream is the critical one).  profiles/r04_ab_log.txt. */
+    const int fe_high = q->sw.be_prio == 2 || (q->sw.be_prio == 0 && fe_wants_two_levels(&q->d, &q->sw));
     /* The base priority is NORMAL (0), not the range's least (1 on ROCm 7.2, what rounds 1-2 used for both streams): a process that
      * had held a handle with a high-priority stream and then created a handle with two LEAST-priority streams saw those two
      * serialise (cfg2 276 instead of 381 GS/s as bench.py's second workload) -- they apparently end up on one hardware queue.  With

@@ -39,10 +39,46 @@
 
 #include "pmr_kernels.h"
 
-typedef float2 cf2;
-
-static __device__ __forceinline__ cf2 cmul(cf2 a, cf2 w) { return make_float2(fmaf(-a.y, w.y, a.x * w.x), fmaf(a.y, w.x, a.x * w.y)); }
-static __device__ __forceinline__ cf2 cmulc(cf2 a, cf2 w) { return make_float2(fmaf(a.y, w.y, a.x * w.x), fmaf(a.y, w.x, -(a.x * w.y))); }   // a conj(w)
+// complex = clang ext-vector pair: element-wise +, -, * and fma map onto v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, the swaps and
+// sign flips of a complex product or of a multiplication by +-j onto their op_sel / neg modifiers.  The kernel is VALU-issue-bound
+// (tools/ubench/valu_rate.hip: a packed instruction costs 5.3 cycles per wave against 4.7 for a scalar one and does twice the work)
+typedef float cf2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ cf2 mk2(float x, float y) { return cf2{x, y}; }
+static __device__ __forceinline__ cf2 jtimes(cf2 a) { return cf2{-a.y, a.x}; }                       // j a (constants / rare uses)
+// The swaps and sign flips of complex arithmetic as operand modifiers of ONE packed instruction (the compiler materialises them as
+// v_mov / v_xor pairs: a third of this kernel's instructions before these helpers).  op_sel / op_sel_hi pick the 32-bit half of
+// each 64-bit operand that feeds the low / high result lane, neg_lo / neg_hi negate it.
+static __device__ __forceinline__ cf2 add_mj(cf2 a, cf2 b)                                           // a - j b = (a.x + b.y, a.y - b.x)
+{
+    cf2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+static __device__ __forceinline__ cf2 add_pj(cf2 a, cf2 b)                                           // a + j b = (a.x - b.y, a.y + b.x)
+{
+    cf2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+static __device__ __forceinline__ cf2 cmul(cf2 a, cf2 w)                                             // a w   (w: run-time twiddle)
+{
+    cf2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                                   // (a.x w.x, a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));    // + (-a.y w.y, a.y w.x)
+    return r;
+}
+static __device__ __forceinline__ cf2 cmulc(cf2 a, cf2 w)                                            // a conj(w)
+{
+    cf2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                      // (a.x w.x, -a.x w.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));                   // + (a.y w.y, a.y w.x)
+    return r;
+}
+// a w for a COMPILE-TIME w: plain vector code, the swizzled constant folds
+static __device__ __forceinline__ cf2 cmulk(cf2 a, cf2 w)
+{
+    return __builtin_elementwise_fma(cf2{a.y, a.y}, cf2{-w.y, w.x}, cf2{a.x, a.x} * w);
+}
 
 static __device__ __forceinline__ int16_t ff_pcm16(float y)
 {
@@ -56,13 +92,11 @@ static __device__ __forceinline__ int16_t ff_pcm16(float y)
 template <bool INV>
 static __device__ __forceinline__ void r4(cf2 &a, cf2 &b, cf2 &c, cf2 &d)
 {
-    const cf2 s0 = make_float2(a.x + c.x, a.y + c.y), s1 = make_float2(a.x - c.x, a.y - c.y);
-    const cf2 s2 = make_float2(b.x + d.x, b.y + d.y), s3 = make_float2(b.x - d.x, b.y - d.y);
-    a = make_float2(s0.x + s2.x, s0.y + s2.y);
-    c = make_float2(s0.x - s2.x, s0.y - s2.y);
-    const cf2 p = make_float2(s1.x + s3.y, s1.y - s3.x), m = make_float2(s1.x - s3.y, s1.y + s3.x);   // s1 - j s3, s1 + j s3
-    b = INV ? m : p;
-    d = INV ? p : m;
+    const cf2 s0 = a + c, s1 = a - c, s2 = b + d, s3 = b - d;
+    a = s0 + s2;
+    c = s0 - s2;
+    b = INV ? add_pj(s1, s3) : add_mj(s1, s3);                     // forward: s1 - j s3
+    d = INV ? add_mj(s1, s3) : add_pj(s1, s3);
 }
 
 // 16-point DFT of v[0..15] (natural order in).  OUT ORDER: X[k] is left in v[R16P(k)], R16P(k) = 4 (k & 3) + (k >> 2).
@@ -75,17 +109,17 @@ static __device__ __forceinline__ void r16(cf2 (&v)[16])
     for (int b = 0; b < 4; b++) r4<INV>(v[b], v[4 + b], v[8 + b], v[12 + b]);            // over a (n = 4 a + b): v[4 c + b] = u_b[c]
     // u_b[c] *= W16^(b c)   (conjugated for the inverse)
     const float sg = INV ? 1.f : -1.f;
-    const cf2 w1 = make_float2(C1, sg * S1), w2 = make_float2(RH, sg * RH), w3 = make_float2(S1, sg * C1);
-    const cf2 w6 = make_float2(-RH, sg * RH), w9 = make_float2(-C1, -sg * S1);
-    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], w1);                                                  // (c, b) = (1, 1)
-    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], w2);
-    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], w3);
-    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], w2);
-    { const cf2 t = v[4 * 2 + 2]; v[4 * 2 + 2] = INV ? make_float2(-t.y, t.x) : make_float2(t.y, -t.x); }   // W16^4 = -j
-    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], w6);
-    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], w3);
-    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], w6);
-    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], w9);
+    const cf2 w1 = mk2(C1, sg * S1), w2 = mk2(RH, sg * RH), w3 = mk2(S1, sg * C1);
+    const cf2 w6 = mk2(-RH, sg * RH), w9 = mk2(-C1, -sg * S1);
+    v[4 * 1 + 1] = cmulk(v[4 * 1 + 1], w1);                                                  // (c, b) = (1, 1)
+    v[4 * 1 + 2] = cmulk(v[4 * 1 + 2], w2);
+    v[4 * 1 + 3] = cmulk(v[4 * 1 + 3], w3);
+    v[4 * 2 + 1] = cmulk(v[4 * 2 + 1], w2);
+    v[4 * 2 + 2] = INV ? jtimes(v[4 * 2 + 2]) : -jtimes(v[4 * 2 + 2]);                      // W16^4 = -j
+    v[4 * 2 + 3] = cmulk(v[4 * 2 + 3], w6);
+    v[4 * 3 + 1] = cmulk(v[4 * 3 + 1], w3);
+    v[4 * 3 + 2] = cmulk(v[4 * 3 + 2], w6);
+    v[4 * 3 + 3] = cmulk(v[4 * 3 + 3], w9);
 #pragma unroll
     for (int c = 0; c < 4; c++) r4<INV>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   // over b: v[4 c + d] = X[c + 4 d]
 }
@@ -94,7 +128,7 @@ struct ff_params {
     const float *in; unsigned long long row_mask; long long row0; unsigned ns, M;
     const cf2 *H, *H2;                 // [N] spectra of the taps / N, POSITION order (pmr_fir_fft_tables)
     const cf2 *TA;                     // [15][N/16]  W_N^(t k0), k0 = 1..15
-    const cf2 *TB;                     // [R2][16]    W_(N/16)^(n2 k1)
+    const cf2 *TB;                     // [16][R2]    W_(N/16)^(n2 k1) at [k1][n2]
     int16_t *pcm; float *audio; unsigned stride;
     float *out2_tm;                    // DUAL: time-major ring of the second product
     const unsigned *chan_list; unsigned n_chan, npairs, ntaps;
@@ -154,7 +188,7 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
     constexpr int N0 = 16 * R2, N = 256 * R2, NT = N0;
     extern __shared__ __attribute__((aligned(16))) char smem_ff[];
     cf2 *zs = reinterpret_cast<cf2 *>(smem_ff);                    // [N + N / 16]
-    cf2 *tb = zs + (N + N / 16);                                   // [R2][16]
+    cf2 *tb = zs + (N + N / 16);                                   // [16][R2]: tb[k1 R2 + n2] (lanes = n2: consecutive addresses)
     cf2 *zs2 = tb + R2 * 16;                                       // DUAL: the parked spectrum, [N + N / 16]
     const unsigned t = threadIdx.x;
     const unsigned unit = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
@@ -168,10 +202,12 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
         cb = has_b ? (P.chan_list ? P.chan_list[i1] : i1) : ca;
     }
     const bool adjacent = cb == ca + 1 && !(ca & 1u);
-    const long long blk_start = P.row0 + (long long)blk * L - (long long)(P.ntaps - 1);   // frame of transform index 0
-    const long long end = P.row0 + (long long)P.ns;
+    // 32-bit index arithmetic: frames relative to row0 (the launcher guarantees ring rows x M < 2^32 elements)
+    const int rel0 = (int)(blk * L) - (int)(P.ntaps - 1);          // frame of transform index 0, relative to row0
+    const int ns_i = (int)P.ns;
+    const unsigned r0lo = (unsigned)P.row0, mask32 = (unsigned)P.row_mask;
 
-    // phase-B twiddles -> LDS, phase-A twiddles -> registers, the block's samples -> registers: all in flight together
+    // phase-B twiddles -> LDS, the block's samples -> registers: all in flight together
     for (unsigned i = t; i < (unsigned)(R2 * 16); i += NT) tb[i] = P.TB[i];
     // (the 15 + 15 twiddles of a thread are re-read where they are used -- global table through L1 for A / A', LDS for B / B' --
     //  instead of living in 60 registers across the whole kernel: the register count decides whether a wave of this kernel still
@@ -179,12 +215,12 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
     cf2 v[16];
 #pragma unroll
     for (int n0 = 0; n0 < 16; n0++) {
-        const long long row = blk_start + n0 * N0 + (long long)t;
-        v[n0] = make_float2(0.f, 0.f);
-        if (row < end) {
-            const float *src = P.in + ((unsigned long long)row & P.row_mask) * P.M;
+        const int rel = rel0 + n0 * N0 + (int)t;
+        v[n0] = mk2(0.f, 0.f);
+        if (rel < ns_i) {
+            const float *src = P.in + (size_t)(((r0lo + (unsigned)rel) & mask32) * P.M);
             if (adjacent) v[n0] = *reinterpret_cast<const cf2 *>(src + ca);
-            else v[n0] = make_float2(src[ca], src[cb]);
+            else v[n0] = mk2(src[ca], src[cb]);
         }
     }
 
@@ -210,7 +246,7 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
         for (int n1 = 0; n1 < 16; n1++) u[n1] = zs[FF_IDX(baseB + n1 * R2)];
         r16<false>(u);
 #pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) zs[FF_IDX(baseB + k1 * R2)] = k1 ? cmul(u[R16P(k1)], tb[n2B * 16 + k1]) : u[R16P(0)];
+        for (int k1 = 0; k1 < 16; k1++) zs[FF_IDX(baseB + k1 * R2)] = k1 ? cmul(u[R16P(k1)], tb[k1 * R2 + n2B]) : u[R16P(0)];
     }
     __syncthreads();
 
@@ -223,7 +259,7 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
 #pragma unroll
             for (int k1 = 0; k1 < 16; k1++) {
                 const cf2 x = zs[FF_IDX(baseB + k1 * R2)];
-                u[k1] = k1 ? cmulc(x, tb[n2B * 16 + k1]) : x;
+                u[k1] = k1 ? cmulc(x, tb[k1 * R2 + n2B]) : x;
             }
             r16<true>(u);
 #pragma unroll
@@ -243,21 +279,19 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
 
     ff_phase_c<R2, DUAL, true>(zs, zs2, zs, P.H, t);
     inverse_BA();
-    // ---- outputs: transform index n = n0 N0 + t is frame blk_start + n; indices >= ntaps - 1 are valid ----
+    // ---- outputs: transform index n = n0 N0 + t is frame rel0 + n (relative to row0); indices >= ntaps - 1 are valid ----
+    {
+        // one base pointer per row and thread; the 16 stores of a row are base + n0 N0 (compile-time offsets)
+        const long relt = (long)rel0 + (long)t;
+        int16_t *pa = P.pcm ? P.pcm + (size_t)ca * P.stride + relt : nullptr, *pb = P.pcm ? P.pcm + (size_t)cb * P.stride + relt : nullptr;
+        float *aa = P.audio ? P.audio + (size_t)ca * P.stride + relt : nullptr, *ab = P.audio ? P.audio + (size_t)cb * P.stride + relt : nullptr;
 #pragma unroll
-    for (int n0 = 0; n0 < 16; n0++) {
-        const unsigned n = n0 * N0 + t;
-        const long long f = blk_start + (long long)n;
-        if (n >= P.ntaps - 1 && f < end) {
-            const cf2 y = v[R16P(n0)];
-            const size_t o = (size_t)(f - P.row0);
-            if (P.pcm) {
-                P.pcm[(size_t)ca * P.stride + o] = ff_pcm16(y.x);
-                if (has_b) P.pcm[(size_t)cb * P.stride + o] = ff_pcm16(y.y);
-            }
-            if (P.audio) {
-                P.audio[(size_t)ca * P.stride + o] = y.x;
-                if (has_b) P.audio[(size_t)cb * P.stride + o] = y.y;
+        for (int n0 = 0; n0 < 16; n0++) {
+            const int n = n0 * N0 + (int)t, rel = rel0 + n;
+            if (n >= (int)P.ntaps - 1 && rel < ns_i) {
+                const cf2 y = v[R16P(n0)];
+                if (pa) { pa[n0 * N0] = ff_pcm16(y.x); if (has_b) pb[n0 * N0] = ff_pcm16(y.y); }
+                if (aa) { aa[n0 * N0] = y.x; if (has_b) ab[n0 * N0] = y.y; }
             }
         }
     }
@@ -267,11 +301,10 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
         inverse_BA();
 #pragma unroll
         for (int n0 = 0; n0 < 16; n0++) {
-            const unsigned n = n0 * N0 + t;
-            const long long f = blk_start + (long long)n;
-            if (n >= P.ntaps - 1 && f < end) {
+            const int n = n0 * N0 + (int)t, rel = rel0 + n;
+            if (n >= (int)P.ntaps - 1 && rel < ns_i) {
                 const cf2 y = v[R16P(n0)];
-                float *dst = P.out2_tm + ((unsigned long long)f & P.row_mask) * P.M;
+                float *dst = P.out2_tm + (size_t)(((r0lo + (unsigned)rel) & mask32) * P.M);
                 if (adjacent) *reinterpret_cast<cf2 *>(dst + ca) = y;
                 else { dst[ca] = y.x; if (has_b) dst[cb] = y.y; }
             }
@@ -298,7 +331,7 @@ extern "C" void pmr_fir_fft_spectrum(unsigned N, const float *h, unsigned ntaps,
     }
 }
 
-extern "C" void pmr_fir_fft_twiddles(unsigned N, float *TA /*[15][N/16][2]*/, float *TB /*[N/256][16][2]*/)
+extern "C" void pmr_fir_fft_twiddles(unsigned N, float *TA /*[15][N/16][2]*/, float *TB /*[16][N/256][2]*/)
 {
     const unsigned R2 = N / 256, N0 = N / 16;
     for (unsigned k0 = 1; k0 < 16; k0++)
@@ -309,7 +342,7 @@ extern "C" void pmr_fir_fft_twiddles(unsigned N, float *TA /*[15][N/16][2]*/, fl
     for (unsigned n2 = 0; n2 < R2; n2++)
         for (unsigned k1 = 0; k1 < 16; k1++) {
             const double a = -2.0 * M_PI * (double)((n2 * k1) % N0) / (double)N0;
-            TB[2 * (n2 * 16 + k1)] = (float)cos(a); TB[2 * (n2 * 16 + k1) + 1] = (float)sin(a);
+            TB[2 * (k1 * R2 + n2)] = (float)cos(a); TB[2 * (k1 * R2 + n2) + 1] = (float)sin(a);
         }
 }
 
@@ -333,6 +366,8 @@ extern "C" int pmr_launch_fir_fft(pmr_stream_t s, int which, const pmr_fir_fft_t
     P.H = (const cf2 *)tab->H; P.H2 = (const cf2 *)tab->H2; P.TA = (const cf2 *)tab->TA; P.TB = (const cf2 *)tab->TB;
     P.pcm = pcm; P.audio = audio; P.stride = stride; P.out2_tm = out2_tm;
     P.chan_list = chan_list; P.n_chan = nc; P.npairs = (nc + 1) / 2; P.ntaps = ntaps;
+    if (((unsigned long long)row_mask + 1ull) * M > 0xffffffffull || (unsigned long long)ns + N > 0x7fffffffull)
+        return (int)hipErrorInvalidValue;                                /* the kernel indexes the ring with 32-bit arithmetic */
     const unsigned nblk = (ns + L - 1) / L;
     const unsigned long long units = (unsigned long long)nblk * P.npairs;
     if (units > 0x7fffffffull) return (int)hipErrorInvalidValue;

@@ -28,7 +28,6 @@ typedef struct {
     int chan_ft;            /* PMR_CHAN_FT=n: tile height of the generic channelizer (0 = automatic)        */
     int fir_mode;           /* PMR_FIR=pair|lds|global: VALU versions of the audio FIR (PMR_FIR_*)          */
     int fir_direct;         /* PMR_FIR=direct: the direct (MFMA) form of the audio FIR for every block (default: FFT form for large blocks) */
-    int fir_fft_n;          /* PMR_FIR_FFT_N=1024|4096: force the transform size of the FFT form (default: by block length) */
     int fir_mfma_global;    /* PMR_FIR_MFMA=global: MFMA FIR without the LDS sample window                  */
     int fir_mfma32;         /* PMR_FIR_MFMA=32: the 32x32x2 / 256-frame-tile form of the MFMA FIR (A/B reference) */
     int fir_mfma4;          /* PMR_FIR_MFMA=4: the 16x16x4 / 128-frame-tile form for every plan (default: by plan, pmr_launch_fir_tm) */
@@ -176,7 +175,7 @@ int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in,
 typedef struct { const float *H, *H2, *TA, *TB; } pmr_fir_fft_tab;
 unsigned pmr_fir_fft_size(int which);
 void pmr_fir_fft_spectrum(unsigned N, const float *h, unsigned ntaps, float *H_out /*[2 N]*/);
-void pmr_fir_fft_twiddles(unsigned N, float *TA /*[15][N/16][2]*/, float *TB /*[N/256][16][2]*/);
+void pmr_fir_fft_twiddles(unsigned N, float *TA /*[15][N/16][2]*/, float *TB /*[16][N/256][2]*/);
 int pmr_fir_fft_supported(unsigned M, unsigned ntaps);
 int pmr_launch_fir_fft(pmr_stream_t s, int which, const pmr_fir_fft_tab *tab, const float *in, uint64_t row_mask, int64_t row0,
                        unsigned ns, unsigned M, unsigned ntaps, int16_t *pcm, float *audio, unsigned stride,
