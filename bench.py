@@ -143,22 +143,23 @@ def load_measured_traffic(workload, block):
         return None
 
 
-def parity_check(ch, fs, M, iq, block, pcm_bufs, S, nblk):
-    """Outside the timed region: `nblk` consecutive process_block_device calls on the bench block, NOT synchronised in
-    between (the timed code path), PCM of every call vs the CPU oracle fed the same stream.  Returns the record."""
+def parity_check(ch, fs, M, iq, block, pcm_bufs, S, nblk, rot=1):
+    """Outside the timed region: `nblk` consecutive process_block_device calls on the bench stream (the rotation's blocks in
+    order), NOT synchronised in between (the timed code path), PCM of every call vs the CPU oracle fed the same stream."""
     import numpy as np
     import oracle
     from sdr_pmr446_amd import synth
-    x_host = iq.download(np.complex64, block)
+    x_host = iq.download(np.complex64, min(rot, nblk) * block)
     ref, err = [], []
 
     def run_oracle():
         try:
             chunk = 1 << 22
             o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=chunk)
-            for _ in range(nblk):
+            for b in range(nblk):
+                base = (b % rot) * block
                 for p in range(0, block, chunk):
-                    ref.append(o.process_block(x_host[p:p + chunk], want=("pcm",))["pcm"])
+                    ref.append(o.process_block(x_host[base + p:base + p + chunk], want=("pcm",))["pcm"])
             o.close()
         except Exception as e:                                          # reported below, never swallowed
             err.append(repr(e))
@@ -169,7 +170,7 @@ def parity_check(ch, fs, M, iq, block, pcm_bufs, S, nblk):
     ch.reset()
     ns = []
     for b in range(nblk):
-        ns.append(ch.process_block_device(iq.ptr, block, d_pcm=pcm_bufs[b].ptr, stride=S))
+        ns.append(ch.process_block_device(iq.ptr + (b % rot) * block * 8, block, d_pcm=pcm_bufs[b].ptr, stride=S))
     ch.synchronize()
     got = np.concatenate([pcm_bufs[b].download(np.int16, M * S).reshape(M, S)[:, :ns[b]] for b in range(nblk)],
                          axis=1).astype(np.int32)
@@ -187,6 +188,7 @@ def parity_check(ch, fs, M, iq, block, pcm_bufs, S, nblk):
                                     M - len(act) - sum(synth.channel_kind(k) == "empty" for k in range(M))),
             "within_1_lsb_frac_all_channels": float((np.abs(got - ref) <= 1).mean()) if ok else None,
             "mode": "consecutive process_block_device calls, no synchronisation in between, block pipelining on",
+            "input": "blocks 0..%d of the timed rotation, in order" % (min(rot, nblk) - 1) if rot > 1 else "the bench block, repeated",
             "oracle": "oracle.OracleChain (CPU restatement) on the same %d samples" % (nblk * block),
             "seconds": round(time.perf_counter() - t0, 1)}
 
@@ -208,7 +210,16 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
     # Resident in HBM before timing, generated there by the library's own kernel (include/pmr_mem.h: every buffer of this
     # program lives in the library's HIP runtime; torch is here for torch.distributed only).  period_log2: all frequencies
     # snapped to the block's grid, so the block repeated every step is one phase-continuous stream.
-    iq = pmr.synth_iq_device(block, fs, M, stream_id=multigpu.stream_id_for_rank(rank), period_log2=lb, device=local_rank)
+    # The timed steps ROTATE through `rot` distinct blocks (one phase-continuous stream of rot x block samples whose every frequency is
+    # snapped to the grid of the whole rotation, so block rot-1 runs into block 0 without a phase step; the noise is a counter-based
+    # stream of its own): a streaming receiver never sees the same block twice, and a block re-read every step next to a 256 MiB
+    # Infinity Cache would leave open how much of the "HBM" stream the cache served.
+    rot = max(1, args.rotate)
+    rot_log2 = rot.bit_length() - 1
+    if rot != 1 << rot_log2:
+        raise SystemExit("--rotate must be a power of two")
+    iq = pmr.synth_iq_device(rot * block, fs, M, stream_id=multigpu.stream_id_for_rank(rank), period_log2=lb + rot_log2,
+                             device=local_rank)
     nchk = max(1, args.parity_blocks)
     pcm_bufs = [pmr.DeviceBuffer(M * S * 2, local_rank) for _ in range(nchk)]                # PCM stays in HBM
     pcm = pcm_bufs[0]
@@ -218,8 +229,12 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
         torch.cuda.synchronize()
         pmr.device_synchronize()
 
+    pos = [0, rot]                                    # [next block of the rotation, blocks in the rotation (1 = same block every step)]
+
     def step():
-        return ch.process_block_device(iq.ptr, block, d_pcm=pcm.ptr, stride=S)
+        b = pos[0] % pos[1]
+        pos[0] += 1
+        return ch.process_block_device(iq.ptr + b * block * 8, block, d_pcm=pcm.ptr, stride=S)
 
     for _ in range(args.warmup):
         step()
@@ -252,6 +267,12 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
         dts.append(dt)
     ch.profile_enable(0)
     prof_roof = ch.profile()
+    # the same measurement on ONE block re-read every step (rounds 1-3's input), for the record: 5 regions
+    dts_same = []
+    if rot > 1:
+        pos[1] = 1
+        dts_same = [multigpu.timed_region(run, dist, device_sync, sync_dev)[0] for _ in range(5)]
+        pos[1] = rot
     breakdown_steps = 0
     if not args.no_kernel_events:
         # separate pass, outside the timed region: every kernel, blocks NOT pipelined (uncontended kernel times)
@@ -305,7 +326,15 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
             "value": value, "unit": "Msamples/s", "ms_per_step": dt_med / args.steps * 1e3,
             "timed_regions": {"n": len(dts), "steps_each": args.steps, "ms_per_step_first": ms_all[0],
                               "ms_per_step_min": min(ms_all), "ms_per_step_median": statistics.median(ms_all),
-                              "ms_per_step_max": max(ms_all), "value_is": "median region"},
+                              "ms_per_step_max": max(ms_all), "value_is": "median region",
+                              "input": ("%d distinct device-resident blocks (%.2f GB, one phase-continuous stream, period 2^%d samples) "
+                                        "rotated through the steps" % (rot, rot * block * 8 / 1e9, lb + rot_log2)) if rot > 1
+                                       else "one device-resident block re-read every step",
+                              "same_block_every_step": ({"value": multigpu.aggregate_throughput(world, args.steps, block,
+                                                                                                 statistics.median(dts_same)) / 1e6,
+                                                         "ms_per_step": statistics.median(dts_same) / args.steps * 1e3, "regions": len(dts_same),
+                                                         "note": "block 0 of the rotation re-read every step (the input of rounds 1-3)"}
+                                                        if dts_same else None)},
             "config": {"workload": ("cfg4 (BASELINE.json configs[3]): %d independent %d-ch streams @ %.4g MS/s, one per GPU (cfg3 on "
                                     "every GPU)" % (world, M, fs / 1e6)) if (name == "cfg3" and world > 1) else
                                    ("%s (BASELINE.json configs[%d]): %d-ch PMR446 chain @ %.4g MS/s, one independent IQ "
@@ -320,7 +349,7 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
                                          "channels, audio FIR / PCM for the one open channel (pmr_chain_set_channel_mask)" % M},
         }
         if world == 1 and args.parity_blocks > 0:
-            rec["parity_checked"] = parity_check(ch, fs, M, iq, block, pcm_bufs, S, nchk)
+            rec["parity_checked"] = parity_check(ch, fs, M, iq, block, pcm_bufs, S, nchk, rot)
         if headline and args.host_io and world == 1:
             rec["host_io"] = host_io(ch, iq, block, M, S)
         if world == 1 and not args.no_cpu_baseline:
@@ -408,10 +437,14 @@ def main():
     ap.add_argument("--regions", type=int, default=25, help="how often the timed K-step region is repeated")
     ap.add_argument("--parity-blocks", type=int, default=4, help="blocks of the un-synchronised oracle check (0 = skip)")
     ap.add_argument("--log2-block", type=int, default=None)
+    ap.add_argument("--rotate", type=int, default=4, help="distinct device-resident blocks the timed steps rotate through (a power "
+                    "of two; 1 = one block re-read every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs (falls back to gloo, and says so, if the "
                                                           "RCCL group does not come up); gloo lets two ranks share one GPU to "
                                                           "exercise the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--force-rccl", action="store_true", help="TEST ONLY: try the RCCL group even when ranks share a device (it must "
+                    "fail there and the ranks must agree to fall back to gloo: the failure path of multigpu.init_dist, exercised on a 1-GPU box)")
     ap.add_argument("--host-io", action="store_true",
                     help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
@@ -436,7 +469,7 @@ def main():
     ndev = torch.cuda.device_count()
     if args.dist_backend != "nccl" or ndev < world:
         local_rank = local_rank % ndev                               # ranks may share a device (self-test on a 1-GPU box)
-        if args.dist_backend == "nccl" and ndev < world:
+        if args.dist_backend == "nccl" and ndev < world and not args.force_rccl:
             args.dist_backend = "gloo"                               # RCCL needs one device per rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
