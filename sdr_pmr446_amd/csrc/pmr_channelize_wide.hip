@@ -186,6 +186,9 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
                                sample) and 4 % slower IN THE CHAIN (380 vs 397 GS/s: 35 KB of LDS no longer fit beside four front-end tiles, the
                                back-end stream becomes the critical one); 12: 391, 6: 391, 4: 367 (tools/variant_bench.sh, round 3) */
 #endif
+#ifndef PF_RB
+#define PF_RB 9             /* rows per load batch (two batches in flight) */
+#endif
 template <bool FIX>
 __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params q)
 {
@@ -221,19 +224,25 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
         pmr_carry_state cst;
         const unsigned long long dph = (unsigned long long)M * q.fix.step;
         if constexpr (FIX) cst = pmr_carry_init(q.fix, ct, fbase * (long long)M + (long long)c - (long long)q.fix.pos0);
-        constexpr int RB = 9;
-#pragma unroll
-        for (int rr0 = 0; rr0 < NROW; rr0 += RB) {
-            cf xm[RB];
+        // rows in batches of RB, SOFTWARE-PIPELINED: batch b + 1 is requested before batch b is consumed, so only the first batch's
+        // L2 / HBM latency is exposed (round 3 loaded, waited and computed batch by batch).  Measured neutral (26 us alone either
+        // way, profiles/r04_ab_log.txt r4g: the bank phase is 19.5 of the kernel's 26 us, 6.6 of them the carry arithmetic)
+        constexpr int RB = PF_RB, NBATCH = (NROW + RB - 1) / RB;
+        cf xq[2][RB];
+        const auto request = [&](int b, cf (&dst)[RB]) {
 #pragma unroll
             for (int u = 0; u < RB; u++) {
-                const int r = rr0 + u;
-                if (r < NROW) {
-                    const unsigned a = a0 + (unsigned)r * M;
-                    xm[u] = xr[a & xr_mask32];
-                }
+                const int r = b * RB + u;
+                if (r < NROW) dst[u] = xr[(a0 + (unsigned)r * M) & xr_mask32];
             }
-            __builtin_amdgcn_sched_barrier(0);            // the batch's loads stay together, ahead of everything that consumes them
+        };
+        request(0, xq[0]);
+#pragma unroll
+        for (int b = 0; b < NBATCH; b++) {
+            cf (&xm)[RB] = xq[b & 1];
+            if (b + 1 < NBATCH) request(b + 1, xq[(b + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);            // the next batch's loads are issued ahead of everything that consumes this one
+            const int rr0 = b * RB;
 #pragma unroll
             for (int u = 0; u < RB; u++) {
                 const int r = rr0 + u;
