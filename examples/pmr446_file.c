@@ -63,7 +63,7 @@ static int run_chan(const char *in, const char *out, double fs, unsigned M, int 
         unsigned ns = 0;
         rc = pmr_chain_process_block_f32(q, iq, (unsigned)n, pcm, audio, S, &ns, NULL, rssi);
         if (rc) { fprintf(stderr, "pmr446_file: %s\n", pmr_chain_last_error(q)); break; }
-        const int ev = pmr_squelch_update(&sq, rssi, M, ~0ull, 18.0f, 0);               /* :828-874 */
+        const int ev = pmr_squelch_update(&sq, rssi, M, NULL, 0, 18.0f, 0);               /* :828-874 */
         if (ev) fprintf(stderr, "block %lu: %s channel %d (%.1f dB)\n", blocks, sq.state == PMR_TUNED ? "tuned to" : "left",
                         sq.active_chan + 1, sq.rssi);
         rc = pmr_wav_writer_write_f32(w, only >= 0 ? audio + (size_t)only * S : audio, ns, S);
@@ -119,7 +119,7 @@ static int run_scan(const char *in, const char *out, double fs, unsigned M)
         rc = pmr_chain_channelize_block(q, iq, (unsigned)n, &ns, NULL, 0, rssi);        /* :795-823 + average_power */
         if (rc) { fprintf(stderr, "pmr446_file: %s\n", pmr_chain_last_error(q)); break; }
         const int was = sq.state == PMR_TUNED ? sq.active_chan : -1;
-        if (pmr_squelch_update(&sq, rssi, M, ~0ull, 18.0f, 0)) {                        /* :828-874 */
+        if (pmr_squelch_update(&sq, rssi, M, NULL, 0, 18.0f, 0)) {                        /* :828-874 */
             memset(mask, 0, sizeof(mask));
             if (sq.state == PMR_TUNED) {
                 mask[(unsigned)sq.active_chan >> 6] = 1ull << ((unsigned)sq.active_chan & 63);

@@ -85,6 +85,16 @@ int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in,
                                 int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames,
                                 pmr_cf32 *chan_out, float *rssi_db);
 
+/* Same call on the receiver's OWN sample format (include/pmr_io.h: iq_format 0 = cf32, 1 = interleaved int16 / 32768, 2 = interleaved
+ * uint8, (x - 127.5) / 127.5 -- the reference's radio is an RTL-SDR, README.md:12, whose uint8 pairs SoapySDR widens to the cf32 that
+ * readStream hands over, src/shared.c:62, src/sdr_pmr446.c:789).  The samples are converted on the device, by the front end as it
+ * loads them: a block in pmr_host_alloc memory of up to 2^18 samples is read IN PLACE, 2 or 4 bytes per sample instead of 8 on the
+ * host link (100 000 uint8 samples: 200 KB instead of 800 KB per call).  PCM / audio are bit-identical to
+ * pmr_chain_process_block_f32 on the converted samples. */
+int pmr_chain_process_block_fmt(pmr_chain q, const void *iq, int iq_format, unsigned n_in,
+                                int16_t *pcm, float *audio, unsigned pcm_stride, unsigned *n_frames,
+                                pmr_cf32 *chan_out, float *rssi_db);
+
 /* Two-step synchronous form, for a squelch that decides on THIS block before it is demodulated -- the reference's order: state
  * machine on chan_bufs (:828-874), then freqdem .. audio of the active channel (:876-906).  pmr_chain_channelize_block runs the
  * block up to channelizer / discriminator / RSSI (chan_out, rssi_db: as in pmr_chain_process_block); the caller updates
@@ -168,7 +178,13 @@ int         pmr_chain_profile_get(pmr_chain q, unsigned i, double *total_ms, uns
 enum { PMR_INFO_NUM_STAGES = 0, PMR_INFO_M_STAGE = 1, PMR_INFO_ARB_STEP = 2, PMR_INFO_NCO_DTHETA = 3,
        PMR_INFO_ARB_NPFB = 4, PMR_INFO_ARB_M = 5, PMR_INFO_PFB_P = 6,
        PMR_INFO_CARRY_AT_LOAD = 7 /* 1: the front end's dc carry is applied where the channelizer loads the resampled stream
-                                     (one-level front ends with the 16- / 256-channel kernels); handle only */ };
+                                     (one-level front ends with the 16- / 256-channel kernels); handle only */,
+       /* which kernels this handle's plan selected (handle only; tests assert that every fallback is reachable by a legal cfg) */
+       PMR_INFO_FE_PLAN = 8       /* 0 staged (one kernel per stage: cascades too deep for an LDS tile), 1 generic tile kernel,
+                                     2 specialised one-level (k_fe_fast), 3 two levels, specialised, 4 two levels, generic    */,
+       PMR_INFO_CHAN_PLAN = 9     /* 0 generic k_channelize, 1 16-channel k_channelize_win, 2 fused 256-channel kernel,
+                                     3 wide bank: k_pfb_wide + k_fft_disc                                                    */,
+       PMR_INFO_FIR_PLAN = 10     /* 0 k_fir_pair (VALU), 1 direct MFMA form only, 2 FFT form for large blocks + direct MFMA  */ };
 enum { PMR_DESIGN_HALFBAND = 0, PMR_DESIGN_ARB = 1, PMR_DESIGN_PFB = 2,
        PMR_DESIGN_DEEMPH = 3 /* {b0, b1, a1} of the de-emphasis IIR, normalised by a0 (src/sdr_pmr446.c:462-463) */ };
 unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx);
@@ -227,8 +243,10 @@ int pmr_asgram_ascii(const float *psd_db, unsigned nfft, unsigned n_transforms, 
 enum { PMR_SCANNING = 0, PMR_TUNED = 1 };
 typedef struct { int state; int active_chan; float rssi; } pmr_squelch;
 void pmr_squelch_init(pmr_squelch *s);
-int  pmr_find_max_rssi_channel(const float *rssi_db, unsigned M, uint64_t channel_mask, float *max_rssi);
-int  pmr_squelch_update(pmr_squelch *s, const float *rssi_db, unsigned M, uint64_t channel_mask,
+/* mask_words / n_words: the channels that take part, in the layout of pmr_chain_set_channel_mask (bit k & 63 of word k >> 6; the
+ * reference's uint64_t channel_mask :18 generalised to any M); NULL = all.  n_words * 64 < M: -1 / no change. */
+int  pmr_find_max_rssi_channel(const float *rssi_db, unsigned M, const uint64_t *mask_words, unsigned n_words, float *max_rssi);
+int  pmr_squelch_update(pmr_squelch *s, const float *rssi_db, unsigned M, const uint64_t *mask_words, unsigned n_words,
                         float squelch_level /* :34 default 18 dB */, int lock_mode_max);
 
 /* ---- host-only helpers: pure arithmetic, need no HIP device (used by the CPU test tier) ---- */

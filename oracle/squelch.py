@@ -15,7 +15,7 @@ def find_max_rssi_channel(rssi_db, channel_mask):
     rssi_max = np.float32(0.0)
     rssi_avg = np.float32(0.0)
     for i, r in enumerate(np.asarray(rssi_db, dtype=np.float32)):
-        if i < 64 and not (channel_mask >> i) & 1:
+        if not (channel_mask >> i) & 1:                  # channel_mask: a Python int of any width (bit i = channel i)
             continue
         ch_en += 1
         rssi_avg = np.float32(rssi_avg + r)

@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libpmr446_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 C_SOURCES = ["pmr_chain.c", "pmr_design.c", "pmr_squelch.c", "pmr_dsd.c", "pmr_io.c"]
-HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_fe_fast.hip", "pmr_channelize_small.hip", "pmr_channelize_wide.hip", "pmr_fir_mfma.hip", "pmr_fir_mfma4.hip", "pmr_fir_fft.hip", "pmr_ctcss.hip", "pmr_synth.hip", "pmr_spectrum.hip",
+HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_fe_fast.hip", "pmr_channelize_small.hip", "pmr_channelize_wide.hip", "pmr_fir_mfma4.hip", "pmr_fir_fft.hip", "pmr_ctcss.hip", "pmr_synth.hip", "pmr_spectrum.hip",
                "pmr_dsd_kernels.hip", "pmr_poison.hip"]
 EXTRA_HIP_FLAGS = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
 EXTRA_C_FLAGS = os.environ.get("PMR_CC_FLAGS", "").split()          # experiment builds only (tools/variant_bench.sh)

@@ -19,7 +19,7 @@ DEBUG_RESAMPLED, DEBUG_FM, DEBUG_CTCSS_LP = range(3)
 #: every symbol include/pmr_chain.h declares
 ABI_SYMBOLS = [
     "pmr_chain_default_cfg", "pmr_chain_create", "pmr_chain_reset", "pmr_chain_destroy", "pmr_chain_max_frames",
-    "pmr_chain_num_channels", "pmr_chain_last_error", "pmr_chain_process_block", "pmr_chain_process_block_f32",
+    "pmr_chain_num_channels", "pmr_chain_last_error", "pmr_chain_process_block", "pmr_chain_process_block_f32", "pmr_chain_process_block_fmt",
     "pmr_chain_process_block_device", "pmr_chain_synchronize", "pmr_chain_set_overlap", "pmr_chain_stream", "pmr_chain_profile_enable",
     "pmr_chain_profile_reset", "pmr_chain_profile_count", "pmr_chain_profile_name", "pmr_chain_profile_get",
     "pmr_chain_info", "pmr_chain_design", "pmr_chain_debug_enable", "pmr_chain_debug_read", "pmr_debug_poison", "pmr_debug_lds_probe",
@@ -135,6 +135,8 @@ def load(build_if_missing=True):
     L.pmr_chain_process_block.restype = i
     L.pmr_chain_process_block_f32.argtypes = [vp, vp, u, vp, vp, u, C.POINTER(u), vp, vp]
     L.pmr_chain_process_block_f32.restype = i
+    L.pmr_chain_process_block_fmt.argtypes = [vp, vp, i, u, vp, vp, u, C.POINTER(u), vp, vp]
+    L.pmr_chain_process_block_fmt.restype = i
     L.pmr_chain_process_block_device.argtypes = [vp, vp, u, vp, vp, u, C.POINTER(u), vp, vp]
     L.pmr_chain_process_block_device.restype = i
     L.pmr_chain_set_overlap.argtypes = [vp, i]
@@ -210,9 +212,9 @@ def load(build_if_missing=True):
     L.pmr_asgram_ascii.restype = i
     L.pmr_squelch_init.argtypes = [C.POINTER(Squelch)]
     L.pmr_squelch_init.restype = None
-    L.pmr_find_max_rssi_channel.argtypes = [vp, u, C.c_uint64, C.POINTER(C.c_float)]
+    L.pmr_find_max_rssi_channel.argtypes = [vp, u, vp, u, C.POINTER(C.c_float)]
     L.pmr_find_max_rssi_channel.restype = i
-    L.pmr_squelch_update.argtypes = [C.POINTER(Squelch), vp, u, C.c_uint64, C.c_float, i]
+    L.pmr_squelch_update.argtypes = [C.POINTER(Squelch), vp, u, vp, u, C.c_float, i]
     L.pmr_squelch_update.restype = i
     L.pmr_cfg_info.argtypes = [C.POINTER(PmrCfg), i, u]
     L.pmr_cfg_info.restype = u
@@ -453,9 +455,13 @@ class PmrChain:
         return self._L.pmr_chain_stream(self.h)
 
     # -- host-buffer entry point ----------------------------------------------------------------
-    def process_block(self, iq, want=("pcm",)):
-        """iq: complex64 numpy array.  Returns dict: n_frames + requested outputs trimmed to n_frames."""
-        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+    def process_block(self, iq, want=("pcm",), fmt=IQ_CF32):
+        """iq: complex64 numpy array (fmt IQ_CF32), or an int16 / uint8 array of interleaved I/Q (IQ_CS16 / IQ_CU8: converted on the
+        device by the front end -- pmr_chain_process_block_fmt).  Returns dict: n_frames + requested outputs trimmed to n_frames."""
+        if fmt == IQ_CF32:
+            iq = np.ascontiguousarray(iq, dtype=np.complex64); n_in = len(iq)
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.int16 if fmt == IQ_CS16 else np.uint8).reshape(-1); n_in = len(iq) // 2
         want = set(want)
         M, S = self.M, self.max_frames
         pcm = np.zeros((M, S), dtype=np.int16) if "pcm" in want else None
@@ -469,7 +475,7 @@ class PmrChain:
             self._check(self._L.pmr_chain_debug_enable(self.h, 1))
         ns = C.c_uint(0)
         ptr = lambda a: a.ctypes.data if a is not None else None
-        self._check(self._L.pmr_chain_process_block_f32(self.h, iq.ctypes.data if len(iq) else None, len(iq),
+        self._check(self._L.pmr_chain_process_block_fmt(self.h, iq.ctypes.data if n_in else None, fmt, n_in,
                                                         ptr(pcm), ptr(audio), S, C.byref(ns), ptr(chan), ptr(rssi)))
         n = ns.value
         out = {"n_frames": n}

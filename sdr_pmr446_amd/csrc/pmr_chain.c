@@ -122,6 +122,8 @@ struct pmr_chain_s {
     int chan_wide;                   /* wide-bank channelizer (pmr_channelize_wide.hip: filter bank + radix-4 FFT kernels) */
     cfl *d_chan_x;                   /* its scratch: polyphase bank outputs [chan_size + 1][M]         */
     int fe_on, fe_nt, fe_spt;        /* fused path selected; threads per tile workgroup, samples per thread */
+    int fe_fast_fmt;                 /* the plan's front-end kernel converts int16 / uint8 input as it loads (k_fe_fast, 256 x 16 tiles) */
+    int cur_in_fmt;                  /* sample format of THIS call's d_iq (0 cf32): set by the synchronous zero-copy path of slot_submit */
     int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
     int fe_m[PMR_FE_MAX_STAGES], fe_tap_off[PMR_FE_MAX_STAGES];
     float fe_Kgain, fe_lam_wave, fe_lam_pow16[6];
@@ -243,7 +245,7 @@ static int fir_fft_upload_spectrum(pmr_chain q, float **dst, unsigned N, const f
 static int fir_fft_init(pmr_chain q, const float *g, unsigned n)
 {
     q->fft_ok = 0;
-    if (q->sw.fir_mode != PMR_FIR_MFMA || q->sw.fir_direct || q->cfg.deemph_fir || q->cfg.lowpass || !pmr_fir_fft_supported(q->M, n))
+    if (q->sw.fir_direct || q->cfg.deemph_fir || q->cfg.lowpass || !pmr_fir_fft_supported(q->M, n))
         return PMR_OK;
     for (int w = 0; w < 2; w++) {
         const unsigned N = pmr_fir_fft_size(w);
@@ -396,14 +398,14 @@ void pmr_chain_default_cfg(pmr_chain_cfg *c)
 /* fused front end: tile geometry and the closed-form gains of the cascade for an exponential     */
 
 /* Does the plan's cascade get the two-level front end?  (Deep cascades: with 4096-sample tiles the halo would eat the tile.) */
-static int fe_wants_two_levels(const pmr_design *d, const pmr_switches *sw)
+static int fe_wants_two_levels(const pmr_design *d)
 {
     const unsigned h = d->num_stages, D = d->decim;
-    if (sw->fe_staged || h > PMR_FE_MAX_STAGES || h < 4) return 0;
+    if (h > PMR_FE_MAX_STAGES || h < 4) return 0;
     unsigned long S = 0;
     for (unsigned e = 0; e < h; e++) S += (unsigned long)(4 * d->m_stage[h - 1 - e] - 2) << e;
     const unsigned long H = S + 13ul * D;
-    if (!(sw->fe_levels ? sw->fe_levels == 2 : (h >= 5 && (4096ul - (H < 4096ul ? H : 4096ul)) * 4 < 4096ul * 3))) return 0;
+    if (!(h >= 5 && (4096ul - (H < 4096ul ? H : 4096ul)) * 4 < 4096ul * 3)) return 0;
     for (unsigned e = 0; e + 2 < h; e++) if (d->m_stage[h - 1 - e] != 3) return 0;
     return 1;
 }
@@ -414,7 +416,6 @@ static int fe_init(pmr_chain q)
     const unsigned h = d->num_stages, D = d->decim;
     int rc;
     q->fe_on = 0;
-    if (q->sw.fe_staged) return PMR_OK;
     if (h > PMR_FE_MAX_STAGES) return PMR_OK;
 
     /* raw-sample history the cascade needs: S = sum_e (4 m_e - 2) 2^e (execution order) + 13 decimated samples */
@@ -429,7 +430,7 @@ static int fe_init(pmr_chain q)
      * stages (6-tap filters, halo 10*(2^s1 - 1) raw samples) -> decimated ring; level 2 = the m = 5 and m = 10 stages +
      * resampler on the 2^s1-times decimated stream.  Costs 16/2^s1 B per raw sample of extra HBM traffic (1 B at s1 = 4). */
     q->fe_two = 0; q->fe_s1 = 0;
-    if (fe_wants_two_levels(d, &q->sw)) { q->fe_two = 1; q->fe_s1 = (int)h - 2; }
+    if (fe_wants_two_levels(d)) { q->fe_two = 1; q->fe_s1 = (int)h - 2; }
     const unsigned s1 = (unsigned)q->fe_s1, D1 = 1u << s1;
     if (q->fe_two) {                              /* level-1 geometry replaces the single-level one below */
         S = 0;
@@ -466,7 +467,7 @@ static int fe_init(pmr_chain q)
         for (unsigned e = s1; e < h; e++) S2 += (unsigned long)(4 * q->fe_m[e] - 2) << (e - s1);
         const unsigned long H2 = S2 + 13ul * D2, L2 = D2 > 16 ? D2 : 16;
         /* level-2 tile: 2048 ring samples for the specialised kernel (m = 5, 10: k_fe_level2), 4096 for the generic one */
-        q->fe2_fast = (h - s1 == 2 && q->fe_m[s1] == 5 && q->fe_m[s1 + 1] == 10 && !q->sw.fe_generic);
+        q->fe2_fast = (h - s1 == 2 && q->fe_m[s1] == 5 && q->fe_m[s1 + 1] == 10);
         const unsigned long N2 = q->fe2_fast ? 2048 : 4096;
         if (H2 + L2 > N2) return PMR_OK;
         const unsigned long t2 = (N2 - H2) / L2 * L2;
@@ -594,6 +595,8 @@ static int fe_init(pmr_chain q)
     }
     q->fe_sel = 0;
     q->fe_on = 1;
+    q->fe_fast_fmt = nt == 256 &&
+                     pmr_fe_fast_covers(q->fe_two ? 1 : 0, q->fe_m, q->fe_two ? q->fe_s1 : (int)h);
     return PMR_OK;
 }
 
@@ -706,15 +709,15 @@ static int chain_init(pmr_chain q)
     q->n_enabled = M; q->mask_on = 0; q->reset_pending = 0;
 
     if ((rc = fe_init(q))) return rc;
-    q->chan_small = !q->sw.chan_generic && pmr_channelize_small_supported(M, p, d->nco_period);
-    q->chan_wide = !q->sw.chan_generic && !q->chan_small && pmr_channelize_wide_supported(M, p, d->nco_period);
+    q->chan_small = pmr_channelize_small_supported(M, p, d->nco_period);
+    q->chan_wide = !q->chan_small && pmr_channelize_wide_supported(M, p, d->nco_period);
     if (q->chan_wide && (rc = dev_alloc(q, (void **)&q->d_chan_x, ((size_t)q->chan_size + 2) * M * sizeof(cfl)))) return rc;
-    q->l2_on_backend = !q->sw.l2_on_fe;
+    q->l2_on_backend = 1;
     q->tf_on_backend = 0;
     q->cal_ok = 0;
     if (q->fe_on && !q->fe_two && q->d_fe_G12 && !q->sw.carry_inplace) {
         q->cal_adv_q = (unsigned)(((uint64_t)M * d->arb_step) >> 24) + 1u;
-        q->cal_ok = pmr_channelize_carry_at_load(M, p, d->nco_period, q->chan_small, q->chan_wide, q->sw.chan_pair, q->sw.chan_unfused,
+        q->cal_ok = pmr_channelize_carry_at_load(M, p, d->nco_period, q->chan_small, q->chan_wide,
                                                  q->cal_adv_q, (unsigned)q->fe_TQ);
         q->cal_nv = pmr_channelize_carry_nv(M, q->cal_adv_q, (unsigned)q->fe_TQ);
         q->cal_nbias = (unsigned)(((uint64_t)(p + 4) * q->cal_adv_q) / (unsigned)q->fe_TQ) + 2u;
@@ -725,36 +728,18 @@ static int chain_init(pmr_chain q)
     return PMR_OK;
 }
 
-/* The A/B switches of DESIGN.md 7a: read from the environment ONCE per handle, here; nothing on a launch path calls getenv. */
+/* The environment switches of DESIGN.md 7a, read ONCE per handle, here; nothing on a launch path calls getenv.  Round 4 cut them
+ * down to what a user or a test has a reason to flip: the exact direct form of the audio FIR (the FFT form's reference), single-stream
+ * calls, the copy-engine path of small synchronous calls, and the in-place form of the dc carry (what the at-load form must equal
+ * bit for bit).  Kernel variants that lost their A/B live in git history and in tools/variant_bench.sh builds, not in the product. */
 static int env_is(const char *name, const char *val) { const char *e = getenv(name); return e && !strcmp(e, val); }
 static void read_switches(pmr_switches *w)
 {
     memset(w, 0, sizeof(*w));
-    w->fe_staged = env_is("PMR_FRONTEND", "staged");
-    w->fe_generic = env_is("PMR_FE_KERNEL", "generic");
-    { const char *e = getenv("PMR_FE_LEVELS"); w->fe_levels = e ? atoi(e) : 0; }
-    w->l2_on_fe = env_is("PMR_L2_STREAM", "fe");
-    w->chan_generic = env_is("PMR_CHANNELIZER", "generic");
-    w->chan_pair = env_is("PMR_CHANNELIZER_SMALL", "pair");
-    w->chan_unfused = env_is("PMR_CHAN_FUSED", "0");
-    { const char *e = getenv("PMR_CHAN_FT"); w->chan_ft = e ? atoi(e) : 0; }
-    w->fir_mode = env_is("PMR_FIR", "pair") ? PMR_FIR_PAIR : env_is("PMR_FIR", "lds") ? PMR_FIR_LDS
-                : env_is("PMR_FIR", "global") ? PMR_FIR_TM : PMR_FIR_MFMA;
     w->fir_direct = env_is("PMR_FIR", "direct");
-    w->fir_mfma_global = env_is("PMR_FIR_MFMA", "global");
-    w->fir_mfma32 = env_is("PMR_FIR_MFMA", "32");
-    w->fir_mfma4 = env_is("PMR_FIR_MFMA", "4");
-    { const char *e = getenv("PMR_FIR_TPW"); w->fir_tpw = e ? atoi(e) : 2; }
-    w->fir_nodual = env_is("PMR_FIR_DUAL", "0");
     w->no_overlap = env_is("PMR_OVERLAP", "0");
-    w->be_prio = env_is("PMR_STREAM_PRIO", "1") ? 1 : env_is("PMR_STREAM_PRIO", "fe") ? 2 : env_is("PMR_STREAM_PRIO", "0") ? 3 : 0;
-    w->host_gate = !env_is("PMR_HOST_GATE", "0");
-    w->ct_no_async = env_is("PMR_CT_STREAM", "0");
-    w->fe_marker = env_is("PMR_FE_EVENT", "marker");
-    w->tf_on_be = env_is("PMR_TILEFIX_STREAM", "be") ? 1 : env_is("PMR_TILEFIX_STREAM", "fe") ? 2 : 0;
     w->carry_inplace = env_is("PMR_CARRY", "inplace");
     w->no_zerocopy = env_is("PMR_ZEROCOPY", "0");
-    { const char *e = getenv("PMR_ZEROCOPY_MAX"); w->zc_max_in = e && atol(e) > 0 ? (unsigned)atol(e) : ZC_MAX_IN; }
 }
 
 static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only);
@@ -789,30 +774,20 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
     }
     q->M = cfg->num_channels;
     pmr_design_buffer_sizes(&q->d, cfg->max_block, &q->res_size, &q->chan_size);
-    /* Stream priorities: equal by default.  Round 1 gave the back end the higher priority (its kernels then were bulky: 77 KB /
-     * 45 KB of LDS per workgroup, and starved behind the front end's tiles).  With round 2's kernels that is neutral at cfg2 /
-     * cfg3 and costs 3.6 % at cfg5 (425 vs 440 GS/s, tools/env_ab.sh): PMR_STREAM_PRIO=1 restores it for A/B runs.
-     * PMR_STREAM_PRIO=fe puts the FRONT-END stream high instead: +3 % at cfg3 (354 -> 364 GS/s), -1.7 % at cfg5, and at cfg2
-     * bimodal (regions of 0.191 and 0.21 ms; median 337 vs 343 GS/s) -- not a default. */
+    /* Stream priorities (A/B history: profiles/r03_stream_priority.txt, r03_ab_log.txt r43-r46, r04_ab_log.txt r4d / r4e).  Equal for
+     * one-level plans: the back-end stream is critical at cfg2 (front end high: -9 %), cfg3 is indifferent.  Two-level plans put the
+     * FRONT-END stream high (cfg5 +1.5-2 % on three boxes); round 3 had to give that up because the direct audio FIR's 36 KB of LDS
+     * did not fit beside four level-1 tiles and starved (541 -> 495 GS/s in steady state) -- the FFT form's one-wave, 8.7 KB
+     * workgroups do. */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       /* numerically lower = higher priority */
-    /* Round 3: for a while the front-end stream ran at the higher priority in two-level plans (cfg5 +2.4 % with the level-1 kernel
-     * of that time).  It sits next to a cliff: the audio FIR's 36 KB of LDS do not fit beside four level-1 tiles, so a front end
-     * that always gets the next free slot lets FIR workgroups in only at its kernel's tail -- a level-1 kernel 2 % faster (taken
-     * branches out of its dc scan) turned 541 GS/s into 495 in steady state (540 again with an LDS-free FIR, or with equal
-     * priorities: profiles/r03_ab_log.txt r43-r46), and 20-step regions went bimodal (525 / 556).  Equal priorities have no such
-     * cliff: 537-541 at both region lengths.  One-level plans never wanted it (cfg3 -6.5 %, cfg2 -13 %).
-     * PMR_STREAM_PRIO=1 / =fe force back end high / front end high for A/B runs. */
-    /* Round 4: with the FFT form of the audio FIR (8.7 KB of LDS per one-wave workgroup) that cliff is gone, and two-level plans get
-     * the front-end stream high again: cfg5 +1.5-2 % on three boxes (538 -> 547, 555 -> 562 GS/s); one-level plans stay equal (cfg3
-     * +-0 on one box, +2.6 % on another; cfg2 -9 %: its back-end stream is the critical one).  profiles/r04_ab_log.txt. */
-    const int fe_high = q->sw.be_prio == 2 || (q->sw.be_prio == 0 && fe_wants_two_levels(&q->d, &q->sw));
+    const int fe_high = fe_wants_two_levels(&q->d);
     /* The base priority is NORMAL (0), not the range's least (1 on ROCm 7.2, what rounds 1-2 used for both streams): a process that
      * had held a handle with a high-priority stream and then created a handle with two LEAST-priority streams saw those two
      * serialise (cfg2 276 instead of 381 GS/s as bench.py's second workload) -- they apparently end up on one hardware queue.  With
      * normal / high that does not happen (profiles/r03_stream_priority.txt). */
     const int prio_base = (prio_hi <= 0 && 0 <= prio_lo) ? 0 : prio_lo;
-    int prio_be = q->sw.be_prio == 1 ? prio_hi : prio_base, prio_fe = fe_high ? prio_hi : prio_base;
+    const int prio_be = prio_base, prio_fe = fe_high ? prio_hi : prio_base;
     if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_be) != hipSuccess ||
         hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_fe) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
@@ -1095,7 +1070,8 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     fe_carry_params(q, &t, slot, ntiles, c_end, off_end, pend, cur, nxt);
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
-    p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr; p.out_pos0 = q->xr_abs; p.out_mask = q->xr_mask;
+    p.x = d_iq; p.in_fmt = q->cur_in_fmt;
+    p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr; p.out_pos0 = q->xr_abs; p.out_mask = q->xr_mask;
     p.probeA = (void *)t.probeA; p.probeB = (void *)t.probeB; p.probeL = (void *)t.probeL; p.probeE = (void *)t.probeE;
     p.tile_j = (void *)t.tile_j;
     p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
@@ -1109,7 +1085,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     {
         pmr_launch_events ev; prof_pending pe;
         fe_launch_events(q, K_FE, q->tf_on_backend && ntiles != 0, &ev, &pe);
-        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, q->sw.fe_generic, &ev));
+        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles, q->fe_nt, q->fe_spt, &ev));
         prof_push(q, &pe);
     }
 
@@ -1126,7 +1102,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
         q->cal_fix_limit = f.j0; q->cal_ntiles = ntiles; q->cal_slot = slot; q->cal_phi0 = q->arb_phase;
     }
     if (q->tf_on_backend) {
-        /* PMR_TILEFIX_STREAM=be: the carry pass heads the back-end stream's work for this block; the front-end stream then
+        /* the carry pass heads the back-end stream's work for this block; the front-end stream then
          * carries front-end kernels only, back to back */
         q->pend_t2 = t; q->pend_f2 = f; q->pend_tf_Q = Q; q->pend_tf = 1;
     } else {
@@ -1171,7 +1147,7 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
     p.mode = 1;
-    p.x = d_iq; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt];
+    p.x = d_iq; p.in_fmt = q->cur_in_fmt; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt];
     p.out = q->d_fe_ring1; p.out_pos0 = A; p.out_mask = q->ring1_mask;
     p.probeA = (void *)t.probeA; p.probeB = (void *)t.probeB; p.probeL = (void *)t.probeL; p.probeE = (void *)t.probeE;
     p.hb_taps = q->d_fe_taps; p.arb_bank = q->d_arb_bank; p.lam_lane_pow = q->d_fe_lam_lane;
@@ -1186,7 +1162,7 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
         /* with level 2 deferred to the back-end stream, level 1 is the front-end stream's last launch of this call */
         pmr_launch_events ev; prof_pending pe;
         fe_launch_events(q, K_FE, q->l2_on_backend && ntiles1 != 0, &ev, &pe);
-        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles1, 256, 16, q->sw.fe_generic, &ev));
+        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles1, 256, 16, &ev));
         prof_push(q, &pe);
     }
 
@@ -1285,7 +1261,7 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
 {
     const unsigned M = q->M, N = PMR_CT_BLOCK;
     /* tmp1 = delay188(fm) - hp(fm) (:884-889) as one FIR with taps delta_188 - h */
-    if (!fir_done) LAUNCH(K_CT_FIR, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
+    if (!fir_done) LAUNCH(K_CT_FIR, pmr_launch_fir_tm(q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_ct_taps, q->hp_len_raw, 1.0f, 0,
                                        0.f, 0.f, 0.f, q->d_ctlp, NULL, NULL, 0, q->mask_on ? q->d_chan_list : NULL, q->n_enabled, NULL, NULL));
     if (q->dbg_on) {                                               /* the branch before ctcss_execute's dc blocker (:889 -> :606) */
         int rc_;
@@ -1302,7 +1278,7 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
     const int cur = q->ct_sel, nxt = cur ^ 1;
     /* pipelined calls: the detector's four kernels run on their own stream behind this block's low-pass branch; only the next
      * block's detector (same stream) and the ring-reuse gate wait for them */
-    const int async = !q->cur_single && !q->sw.ct_no_async && !q->dbg_on;
+    const int async = !q->cur_single && !q->dbg_on;
     hipStream_t sct = async ? q->stream_ct : q->stream;
     if (async) {
         HIPCHK(hipEventRecord(q->ev_ctlp, q->stream), "record");
@@ -1528,7 +1504,7 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
     int ct_fir_done = 0, rssi_rode = 0, audio_done = 0;
     {
         /* large blocks: overlap-save FFT form (pmr_fir_fft.hip); with the detector on its low-pass branch is the second product */
-        const int dual = q->ct_on && q->fft_ok && q->fft_tab[0].H2 && !q->sw.fir_nodual;
+        const int dual = q->ct_on && q->fft_ok && q->fft_tab[0].H2 != NULL;
         const int which = (d_pcm || d_audio) && (!q->ct_on || dual) ? fir_fft_pick(q, ns, q->mask_on ? q->n_enabled : M) : -1;
         if (which >= 0) {
             LAUNCH(K_FIR_HP, pmr_launch_fir_fft(q->stream, which, &q->fft_tab[which], q->d_fm, q->fm_mask, frame0, ns, M, q->hp_len,
@@ -1537,9 +1513,9 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
             audio_done = 1; ct_fir_done = dual;
         }
     }
-    if (!audio_done && q->ct_on && q->d_ct_taps_ext && !q->sw.fir_nodual && (d_pcm || d_audio) && !q->cfg.deemph_fir && !q->cfg.lowpass) {
+    if (!audio_done && q->ct_on && q->d_ct_taps_ext && (d_pcm || d_audio) && !q->cfg.deemph_fir && !q->cfg.lowpass) {
         prof_pending pp_; prof_begin(q, K_FIR_HP, &pp_, q->stream);
-        const int rd = pmr_launch_fir_dual(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->d_ct_taps_ext,
+        const int rd = pmr_launch_fir_dual(q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->d_ct_taps_ext,
                                            q->hp_len, (int16_t *)d_pcm, (float *)d_audio, pcm_stride, q->d_ctlp,
                                            q->mask_on ? q->d_chan_list : NULL, q->n_enabled);
         prof_end(q, &pp_, q->stream);
@@ -1554,7 +1530,7 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
          * applies to the LAST pass only: the intermediate rings must keep every channel's history current, or a channel
          * opened later would start from a cold filter */
         const unsigned *sel = q->mask_on ? q->d_chan_list : NULL;
-        LAUNCH(K_FIR_HP, pmr_launch_fir_tm(&q->sw, q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
+        LAUNCH(K_FIR_HP, pmr_launch_fir_tm(q->stream, q->d_fm, q->fm_mask, frame0, ns, M, q->d_hp_pad, q->hp_len,
                                            1.0f, 0, 0.f, 0.f, 0.f,      /* gain + de-emphasis are in the taps */
                                            more ? q->d_aux1 : NULL, more ? NULL : (int16_t *)d_pcm,
                                            more ? NULL : (float *)d_audio, pcm_stride, more ? NULL : sel, q->n_enabled,
@@ -1563,14 +1539,14 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
         const int sink = d_pcm || d_audio;                 /* (none: a pending block is only pushed through the stateful passes) */
         if (q->cfg.deemph_fir && (sink || q->cfg.lowpass)) {
             const int last = !q->cfg.lowpass;
-            LAUNCH(K_FIR_DE, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
+            LAUNCH(K_FIR_DE, pmr_launch_fir_tm(q->stream, cur, q->fm_mask, frame0, ns, M, q->d_de_pad, q->de_len,
                                                1.0f, 0, 0.f, 0.f, 0.f, last ? NULL : q->d_aux2,
                                                last ? (int16_t *)d_pcm : NULL, last ? (float *)d_audio : NULL,
                                                pcm_stride, last ? sel : NULL, q->n_enabled, NULL, NULL));
             cur = q->d_aux2;
         }
         if (q->cfg.lowpass && sink) {
-            LAUNCH(K_FIR_LP, pmr_launch_fir_tm(&q->sw, q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
+            LAUNCH(K_FIR_LP, pmr_launch_fir_tm(q->stream, cur, q->fm_mask, frame0, ns, M, q->d_lp_pad, q->lp_len,
                                                1.0f, 0, 0.f, 0.f, 0.f, NULL, (int16_t *)d_pcm, (float *)d_audio,
                                                pcm_stride, sel, q->n_enabled, NULL, NULL));
         }
@@ -1590,10 +1566,9 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
  * that are demodulated to audio (the FIR is ~3/4 of it; twice the work with the CTCSS detector on).  Measured on MI355X
  * (tools/env_ab2.sh, 2^26-sample blocks):   cfg3 all channels (r = 0.052): 356 -> 378 GS/s on the back-end stream;
  * cfg2 all channels (r = 0.083): 352 -> 317;   one open channel: cfg2 404 -> 422, cfg3 408 -> 415.
- * PMR_TILEFIX_STREAM=be / =fe force it. */
+ * (Round 4, cfg2 with the carry at load: on the front-end stream 442 / 424 vs 422 / 424 GS/s -- bimodal, not taken.) */
 static int tilefix_on_backend(const pmr_chain q)
 {
-    if (q->sw.tf_on_be) return q->sw.tf_on_be == 1;
     const double r = (double)q->M * q->cfg.channel_width_hz / q->cfg.fs_in;
     const double f_open = q->mask_on ? (double)q->n_enabled / (double)q->M : 1.0;
     const double load = r * (1.0 + 3.0 * f_open) * (q->ct_on ? 2.0 : 1.0);
@@ -1664,15 +1639,13 @@ static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_i
         }
         if (q->n_calls >= PIPE_DEPTH) {
             /* ring reuse: the back end of block n - PIPE_DEPTH must be done.  The HOST waits for it (back-pressure: at most
-             * PIPE_DEPTH blocks are ever queued) -- a wait packet on the front-end stream instead (PMR_HOST_GATE=0) sits between
+             * PIPE_DEPTH blocks are ever queued) -- a wait packet on the front-end stream instead (round 2's PMR_HOST_GATE=0 form) sits between
              * two front-end launches and costs 3 % at cfg5 (439 vs 454 GS/s, tools/env_ab.sh) */
-            if (q->sw.host_gate) HIPCHK(hipEventSynchronize(q->ev_be[par]), "wait back end");
-            else HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[par], 0), "wait back end");
+            HIPCHK(hipEventSynchronize(q->ev_be[par]), "wait back end");
         }
         if (q->ct_ev_used[par]) {                /* ... and its CTCSS detector (own stream): it reads the low-pass ring's rows */
             q->ct_ev_used[par] = 0;
-            if (q->sw.host_gate) HIPCHK(hipEventSynchronize(q->ev_ct[par]), "wait detector");
-            else HIPCHK(hipStreamWaitEvent(q->stream, q->ev_ct[par], 0), "wait detector");
+            HIPCHK(hipEventSynchronize(q->ev_ct[par]), "wait detector");
         }
     }
     if (single && q->ct_async_last)              /* pipelined calls' detectors (own stream) still read the rings this call writes */
@@ -1688,12 +1661,12 @@ static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_i
     q->cal_now = q->cal_ok && !q->dbg_on && !q->spec_nfft;
     q->cal_fix_limit = 0;
     if (q->fe_on && !q->fe_two) {
-        q->tf_on_backend = !single && (q->sw.tf_on_be ? q->sw.tf_on_be == 1 : (q->cal_now || tilefix_on_backend(q)));
+        q->tf_on_backend = !single && (q->cal_now || tilefix_on_backend(q));
         if (!single && !q->tf_on_backend && q->tf_last_be)    /* this block's carry pass reads the dc state the previous one (back-end stream) wrote */
             HIPCHK(hipStreamWaitEvent(q->stream_fe, q->ev_be[(par + PIPE_DEPTH - 1) % PIPE_DEPTH], 0), "wait previous carry pass");
         q->tf_last_be = q->tf_on_backend;
     }
-    q->fe_done_ev = (single || q->sw.fe_marker) ? NULL : q->ev_fe[par];
+    q->fe_done_ev = single ? NULL : q->ev_fe[par];
     q->fe_done_used = 0;
     if ((rc = !q->fe_on ? frontend_staged(q, d_iq, n_in, &ny)
                         : q->fe_two ? frontend_two_level(q, d_iq, n_in, &ny) : frontend_fused(q, d_iq, n_in, &ny))) return rc;
@@ -1750,9 +1723,9 @@ static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_i
             HIPCHK(hipMemcpyAsync(q->d_reset_flags, q->h_reset_flags, M, hipMemcpyHostToDevice, q->stream), "reset flags");
             c.reset_flags = q->d_reset_flags;
         }
-        if (q->chan_small) LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles, q->sw.chan_pair));
-        else if (q->chan_wide) LAUNCH(K_CHANNELIZE, pmr_launch_channelize_wide(q->stream, &c, q->d_chan_x, &ntiles, q->sw.chan_unfused));
-        else LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles, q->sw.chan_ft));
+        if (q->chan_small) LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles));
+        else if (q->chan_wide) LAUNCH(K_CHANNELIZE, pmr_launch_channelize_wide(q->stream, &c, q->d_chan_x, &ntiles));
+        else LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles));
         if (q->reset_pending) { q->reset_pending = 0; memset(q->h_reset_flags, 0, M); }
         if (q->dbg_on) {
             /* discriminator rows of this block, time-major, linearised */
@@ -1860,9 +1833,12 @@ static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigne
      * runs under the kernels of block b; it may not overwrite the slot's staging before the front end that last read it is done */
     hipStream_t s_in = single ? q->stream : q->stream_h2d;
     const cfl *d_iq = sl->d_in;
-    if (single && fmt == 0 && n_in && n_in <= q->sw.zc_max_in && !q->sw.no_zerocopy) {
-        const void *z = host_zero_copy(iq, (size_t)n_in * sizeof(cfl));
-        if (z) d_iq = (const cfl *)z;
+    int in_fmt = 0;                               /* format the front end is handed: != 0 only on the zero-copy path below */
+    if (single && n_in && n_in <= ZC_MAX_IN && !q->sw.no_zerocopy && (fmt == 0 || q->fe_fast_fmt)) {
+        /* the front end reads the caller's pinned buffer in place -- cf32, or the receiver's own int16 / uint8 samples converted as
+         * the tile is loaded: 2 or 4 instead of 8 bytes per sample cross the host link, no copy-engine hand-over, no conversion pass */
+        const void *z = host_zero_copy(iq, (size_t)n_in * (fmt == 0 ? 8 : fmt == 1 ? 4 : 2));
+        if (z) { d_iq = (const cfl *)z; in_fmt = fmt; }
     }
     if (n_in && d_iq == sl->d_in) {
         if (!single && sl->used) HIPCHK(hipStreamWaitEvent(s_in, q->ev_fe[sl->par], 0), "wait front end");
@@ -1880,10 +1856,12 @@ static int slot_submit(pmr_chain q, unsigned i, const void *iq, int fmt, unsigne
     const int zc_out = single && !q->sw.no_zerocopy && sl->hd_out && out_hi <= ZC_MAX_OUT &&
                        (!(want & PMR_WANT_CHAN) || (sl->hd_chan && n * sizeof(cfl) <= ZC_MAX_OUT));
     char *o_out = zc_out ? sl->hd_out : sl->d_out;
+    q->cur_in_fmt = in_fmt;
     rc = process_block_device_impl(q, d_iq, n_in, (want & PMR_WANT_PCM) ? o_out + sl->off_pcm : NULL,
                                    (want & PMR_WANT_AUDIO) ? o_out + sl->off_audio : NULL, stride, &ns,
                                    (want & PMR_WANT_CHAN) ? (zc_out ? sl->hd_chan : sl->d_chan) : NULL,
                                    (want & PMR_WANT_RSSI) ? o_out : NULL, single, phase);
+    q->cur_in_fmt = 0;
     if (rc) return rc;
     sl->ns = ns; sl->stride = stride; sl->want = want;
     q->in_block = 1;                              /* the block's state has advanced: losing its outputs now poisons the handle (slot_submit_end) */
@@ -1927,6 +1905,14 @@ static int slot_collect(pmr_chain q, unsigned i, int16_t *pcm, float *audio, uns
 int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, int16_t *pcm, float *audio,
                                 unsigned pcm_stride, unsigned *n_frames, pmr_cf32 *chan_out, float *rssi_db)
 {
+    return pmr_chain_process_block_fmt(q, iq, 0, n_in, pcm, audio, pcm_stride, n_frames, chan_out, rssi_db);
+}
+
+/* the synchronous call on the receiver's own sample format (include/pmr_io.h: 0 cf32, 1 int16, 2 uint8 -- the reference's radio
+ * is an RTL-SDR, README.md:12, whose native samples are uint8 pairs that SoapySDR widens to the cf32 of readStream, src/shared.c:62) */
+int pmr_chain_process_block_fmt(pmr_chain q, const void *iq, int iq_format, unsigned n_in, int16_t *pcm, float *audio,
+                                unsigned pcm_stride, unsigned *n_frames, pmr_cf32 *chan_out, float *rssi_db)
+{
     if (!q) return PMR_EINVAL;
     HIPCHK(hipSetDevice(q->device), "hipSetDevice");
     if (q->n_inflight) return fail(q, PMR_EINVAL, "collect the submitted blocks first", hipSuccess);
@@ -1937,7 +1923,7 @@ int pmr_chain_process_block_f32(pmr_chain q, const pmr_cf32 *iq, unsigned n_in, 
     if (ns_plan > pcm_stride && (pcm || audio || chan_out)) return fail(q, PMR_ERANGE, "stride < frames", hipSuccess);
     const unsigned want = ((pcm || audio) ? PMR_WANT_PCM : 0) | (audio ? PMR_WANT_AUDIO : 0) | (chan_out ? PMR_WANT_CHAN : 0) |
                           (rssi_db ? PMR_WANT_RSSI : 0);
-    int rc = slot_submit(q, 0, iq, 0, n_in, want, 1, 0);
+    int rc = slot_submit(q, 0, iq, iq_format, n_in, want, 1, 0);
     q->in_block = 0;
     if (rc) return rc;
     rc = slot_collect(q, 0, pcm, audio, pcm_stride, n_frames, chan_out, rssi_db);      /* waits for the block's last copy */
@@ -2132,7 +2118,7 @@ int pmr_chain_set_channel_mask(pmr_chain q, const uint64_t *mask_words, unsigned
     if ((uint64_t)n_words * 64 < M) return fail(q, PMR_EINVAL, "channel mask shorter than num_channels", hipSuccess);
     /* the mask is applied by the MFMA audio kernels (16 channels per tile); the VALU versions (num_channels not a multiple of 16,
      * PMR_FIR=pair|lds|global) would write every row: refuse instead of breaking the "closed rows stay untouched" promise */
-    if (q->sw.fir_mode != PMR_FIR_MFMA || !pmr_fir_mfma4_supported(M, q->hp_len))
+    if (!pmr_fir_mfma4_supported(M, q->hp_len))
         return fail(q, PMR_EINVAL, "channel mask needs the MFMA audio kernels (num_channels a multiple of 16)", hipSuccess);
     unsigned *list = (unsigned *)malloc((size_t)M * sizeof(unsigned));
     if (!list) return fail(q, PMR_ENOMEM, "malloc", hipSuccess);
@@ -2226,6 +2212,12 @@ unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx)
     case PMR_INFO_ARB_M:      return PMR_ARB_M;
     case PMR_INFO_PFB_P:      return q->d.pfb_p;
     case PMR_INFO_CARRY_AT_LOAD: return (unsigned)q->cal_ok;
+    case PMR_INFO_FE_PLAN:
+        if (!q->fe_on) return 0;
+        if (!q->fe_two) return q->fe_fast_fmt ? 2 : 1;
+        return q->fe_fast_fmt && q->fe2_fast ? 3 : 4;
+    case PMR_INFO_CHAN_PLAN: return q->chan_small ? 1 : q->chan_wide ? (q->M == 256 ? 2 : 3) : 0;
+    case PMR_INFO_FIR_PLAN: return !pmr_fir_mfma4_supported(q->M, q->hp_len) ? 0 : q->fft_ok ? 2 : 1;
     default: return 0;
     }
 }

@@ -347,12 +347,12 @@ extern "C" int pmr_channelize_wide_supported(unsigned M, unsigned p, unsigned nc
 }
 
 /* scratch: (ns_max + 1) * M complex floats */
-extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out, int unfused)
+extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out)
 {
     if (ntiles_out) *ntiles_out = 0;
     if (!p->ns) return 0;
     hipStream_t st = (hipStream_t)s;
-    if (p->M == 256 && !unfused) {
+    if (p->M == 256) {
         const unsigned ntiles = (p->ns + PF_G - 1) / PF_G;
         if (ntiles_out) *ntiles_out = ntiles;
         const bool fix = p->fix.V != nullptr;
@@ -371,7 +371,6 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
     if (rc) return rc;
     switch (p->M) {
     case 64:   return launch_fft_disc<64, 32>(st, p, (const cf *)x_scratch, ntiles_out);
-    case 256:  return launch_fft_disc<256, 8>(st, p, (const cf *)x_scratch, ntiles_out);
     case 1024: return launch_fft_disc<1024, 2>(st, p, (const cf *)x_scratch, ntiles_out);   /* (three rows per workgroup -- 25 % fewer
                   transforms, half the workgroups -- measured neutral at cfg5, round 3) */
     case 4096: return launch_fft_disc<4096, 2>(st, p, (const cf *)x_scratch, ntiles_out);
@@ -380,12 +379,12 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
 }
 
 /* ---- which channelizers subtract the front end's dc carry at load (pmr_carry_fix) ---- */
-extern "C" int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco_period, int chan_small, int chan_wide, int pair,
-                                            int unfused, unsigned adv_q, unsigned TQ)
+extern "C" int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco_period, int chan_small, int chan_wide,
+                                            unsigned adv_q, unsigned TQ)
 {
     /* k_channelize_win<16, 26, true>: a thread's staged samples are 256 outputs = 16 frames apart, NOV = 2 */
-    if (chan_small) return M == 16 && p == 26 && !pair && nco_period && 32u % nco_period == 0 && 16u * adv_q < 2u * TQ;
-    if (chan_wide) return M == 256 && p == PW_P && !unfused && adv_q < 2 * TQ;         /* k_channelize_fused256<true>: NOV = 2 */
+    if (chan_small) return M == 16 && p == 26 && nco_period && 32u % nco_period == 0 && 16u * adv_q < 2u * TQ;
+    if (chan_wide) return M == 256 && p == PW_P && adv_q < 2 * TQ;                     /* k_channelize_fused256<true>: NOV = 2 */
     return 0;
 }
 

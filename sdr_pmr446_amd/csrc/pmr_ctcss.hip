@@ -5,7 +5,7 @@
 //            samples with the decision avg > 120 && max/avg > 10                  :366-409
 //
 // GPU formulation (everything per channel is linear, so time can be cut into pieces):
-//  * the low-pass branch is ONE FIR with taps delta[d-188] - h[d]: the audio FIR kernel (pmr_fir_mfma.hip /
+//  * the low-pass branch is ONE FIR with taps delta[d-188] - h[d]: the audio FIR kernel (pmr_fir_mfma4.hip /
 //    k_fir_pair) run a second time on the discriminator ring, writing a time-major ring (done by the host);
 //  * the dc-blocker v0 = x - a1 v1, y = v0 - v1 is a first-order linear scan, cut on the SAME segment grid as the Goertzel bank:
 //    zero-state aggregates of every (segment, channel) (k_ct_seg_agg), a workgroup per channel strings them together with a

@@ -49,6 +49,19 @@ extern "C" int pmr_debug_fe_stamps(void *dst, size_t bytes) { return (int)hipMem
 #define FE_STAMP_AT(i) do { } while (0)
 #endif
 
+// sample b of the caller's block in its own format (pmr_fe_params.in_fmt): the conversions of k_iq_convert (pmr_kernels.hip) /
+// pmr_io.c, operation for operation, so a block converted here equals the block converted first and fed as cf32
+static __device__ __forceinline__ cf fe_raw(const void *x, long b, int fmt)
+{
+    if (fmt == 0) return reinterpret_cast<const cf *>(x)[b];
+    if (fmt == 1) {
+        const unsigned w = reinterpret_cast<const unsigned *>(x)[b];
+        return cfm((float)(short)(w & 0xffffu) * (1.0f / 32768.0f), (float)(short)(w >> 16) * (1.0f / 32768.0f));
+    }
+    const unsigned w = reinterpret_cast<const unsigned short *>(x)[b];
+    return cfm(((float)(w & 0xffu) - 127.5f) * (1.0f / 127.5f), ((float)(w >> 8) - 127.5f) * (1.0f / 127.5f));
+}
+
 template <int MODE, int N3, int TAIL>
 __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 {
@@ -68,7 +81,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     FE_STAMP_AT(0);
-    const cf *__restrict__ x = (const cf *)p.x;
+    const cf *__restrict__ x = (const cf *)p.x;              // (cf32 view: only used when p.in_fmt == 0)
     const cf *__restrict__ hist = (const cf *)p.hist;
     const float lam = -p.dc_a1;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so give every XCD a
@@ -83,7 +96,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 
     // ---- phase A: raw tile -> LDS ----
     if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
-    const bool fast = b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
+    const bool fast = p.in_fmt == 0 && b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
     if (fast) {
         // wave-instruction i of wave w moves slots s0 .. s0 + 63, s0 = 512 w + 64 i (1 KiB).  fe_swz(s0 + lane) - s0 depends on
         // the parity of i only ((s0 >> 4) & 7 = 4 (i & 1)), so the source address is a UNIFORM base (scalar registers, immediate
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
         for (int i = 0; i < N0 / 2 / NT; i++)
             __builtin_amdgcn_global_load_lds((gptr_t *)(srcw + i * 1024 + ((i & 1) ? sw1 : sw0)), (lptr_t *)(ldsw + i * 64), 16, 0,
                                              FE_DMA_AUX);
-    } else {
+    } else if (p.in_fmt == 0) {
         // edge tiles (history before the block, zeros beyond it, or an unaligned block): plain loads into the same image
 #pragma unroll 4
         for (int i = tid; i < N0; i += NT) {
@@ -107,6 +120,45 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) w = hist[hi]; }
             else if (b < (long)p.n_in) w = x[b];
             buf[2 * fe_swz(i >> 1) + (i & 1)] = w;
+        }
+    } else {
+        // integer sample formats, converted on the way in (synchronous zero-copy calls: the block sits in pinned HOST memory, 2 or
+        // 4 bytes per sample cross the link instead of 8).  Four samples per thread and step: one 8- / 16-byte request where the
+        // group lies inside the block and is naturally aligned, else sample by sample
+        const int bps = p.in_fmt == 1 ? 4 : 2;
+#pragma unroll 2
+        for (int i4 = tid; i4 < N0 / 4; i4 += NT) {
+            const int i = 4 * i4;
+            const long b = b0 + i;
+            cf w[4];
+            const char *src = reinterpret_cast<const char *>(p.x) + b * bps;
+            if (b >= 0 && b + 4 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(src) & (uintptr_t)(4 * bps - 1)) == 0)) {
+                if (p.in_fmt == 1) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(src);
+                    const unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        w[k] = cfm((float)(short)(vv[k] & 0xffffu) * (1.0f / 32768.0f), (float)(short)(vv[k] >> 16) * (1.0f / 32768.0f));
+                } else {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                    const unsigned vv[2] = {v.x, v.y};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned h2 = (vv[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                        w[k] = cfm(((float)(h2 & 0xffu) - 127.5f) * (1.0f / 127.5f), ((float)(h2 >> 8) - 127.5f) * (1.0f / 127.5f));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long bk = b + k;
+                    w[k] = cfm(0.f, 0.f);
+                    if (bk < 0) { const long hi = (long)p.hcap + bk; if (hi >= 0) w[k] = hist[hi]; }
+                    else if (bk < (long)p.n_in) w[k] = fe_raw(p.x, bk, p.in_fmt);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) buf[2 * fe_swz((i + k) >> 1) + ((i + k) & 1)] = w[k];
         }
     }
 
@@ -274,7 +326,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
         cf *__restrict__ nh = (cf *)p.new_hist;
         for (int i = tid; i < p.hcap; i += NT) {
             const long sb = (long)i + (long)p.n_in - (long)p.hcap;      // block-relative index
-            nh[i] = sb < 0 ? hist[(long)i + p.n_in] : x[sb];
+            nh[i] = sb < 0 ? hist[(long)i + p.n_in] : fe_raw(p.x, sb, p.in_fmt);
         }
     }
 }
@@ -367,13 +419,23 @@ static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, 
 }
 
 /* the specialised kernels cover: N3 six-tap stages, then optionally (m = 5, m = 10); 256 x 16 tiles */
-static int fast_pattern(const pmr_fe_params *p, int *n3, int *tail)
+static int fast_pattern_m(const int *m, int h, int *n3, int *tail)
 {
     int k = 0;
-    while (k < p->h && p->m[k] == 3) k++;
+    while (k < h && m[k] == 3) k++;
     *n3 = k;
-    if (k == p->h) { *tail = 0; return k >= 1; }
-    if (k + 2 == p->h && p->m[k] == 5 && p->m[k + 1] == 10) { *tail = 1; return 1; }
+    if (k == h) { *tail = 0; return k >= 1; }
+    if (k + 2 == h && m[k] == 5 && m[k + 1] == 10) { *tail = 1; return 1; }
+    return 0;
+}
+static int fast_pattern(const pmr_fe_params *p, int *n3, int *tail) { return fast_pattern_m(p->m, p->h, n3, tail); }
+
+extern "C" int pmr_fe_fast_covers(int mode, const int *m, int h)
+{
+    int n3 = 0, tail = 0;
+    if (!fast_pattern_m(m, h, &n3, &tail)) return 0;
+    if (mode == FE_FULL) return tail && n3 <= 3;
+    if (mode == FE_L1) return !tail && n3 >= 2 && n3 <= 5;
     return 0;
 }
 

@@ -4,8 +4,8 @@
 //            PCM hand-off :903-906 / src/dsd_in.c:172-175; the complementary CTCSS low-pass branch delay188(x) - hp(x) :884-889.
 //
 // Why: demodulating ALL M channels makes this filter the FLOP hot spot of the back end -- 383 MACs per audio sample (gain and the
-// truncated de-emphasis response are folded into the taps, pmr_chain.c).  The direct form on the matrix pipe (pmr_fir_mfma4.hip,
-// pmr_fir_mfma.hip: exact k-ordered f32 chains) is bound by the f32 MFMA rate: 0.030 ms per cfg2 block at the 155 TFLOP/s peak,
+// truncated de-emphasis response are folded into the taps, pmr_chain.c).  The direct form on the matrix pipe (pmr_fir_mfma4.hip:
+// exact k-ordered f32 chains) is bound by the f32 MFMA rate: 0.030 ms per cfg2 block at the 155 TFLOP/s peak,
 // 0.055 measured -- a third of the back end's CU time, and the two streams of the chain time-slice the CUs.  The same LINEAR
 // filter through a 4096-point FFT costs ~50 vector instructions per output sample instead of 766 FLOP:
 //     y = IFFT( FFT(x block) . H ),   H = FFT(taps),   block = N samples, the last N - (ntaps-1) outputs of each are valid,

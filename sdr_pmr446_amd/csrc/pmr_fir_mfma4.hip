@@ -1,29 +1,24 @@
-// pmr_fir_mfma4.hip -- the audio FIR (reference src/sdr_pmr446.c:882-904: 377-tap CTCSS high-pass, gain, 50 us de-emphasis, PCM
-// hand-off; the complementary CTCSS low-pass branch :884-889; the optional FIR de-emphasis / low-pass passes :896,:901) on the
-// gfx950 matrix pipe with v_mfma_f32_16x16x4_f32, 16 channels x 128 frames per workgroup.
+// pmr_fir_mfma4.hip -- the DIRECT form of the audio FIR (reference src/sdr_pmr446.c:882-904: 377-tap CTCSS high-pass, gain, 50 us
+// de-emphasis, PCM hand-off; the complementary CTCSS low-pass branch :884-889; the optional FIR de-emphasis / low-pass passes
+// :896,:901) on the gfx950 matrix pipe with v_mfma_f32_16x16x4_f32, 16 channels x 128 frames per workgroup.
 //
-// Same formulation as pmr_fir_mfma.hip (banded Toeplitz x data, taps with gain and the truncated de-emphasis response folded in,
-// exact k-ordered f32 accumulation oldest sample first = liquid's order) -- the results are bit-identical to that kernel's.
-// What differs is the GRAIN.  With 32x32x2 tiles a wave's unit of work is 64 frames x 16 channels = 13.3k matrix-pipe cycles,
-// a cfg2 block has 5462 of them for 1024 SIMDs (5.3 each: some SIMDs run 6, the launch lasts as long as those), and a workgroup
-// needs 45 KB of LDS (three per CU).  Here:
+// Where it runs (round 4): small blocks (the reference's 100 000-sample calls), the open-channel gather, the follow-on FIR passes,
+// and everything under PMR_FIR=direct -- large blocks of the default chain take the overlap-save FFT form (pmr_fir_fft.hip), whose
+// results this kernel bounds in tests/test_gpu_fir_fft.py.
+//
+// Formulation: banded Toeplitz x data, taps with gain and the truncated de-emphasis response folded in, exact k-ordered f32
+// accumulation oldest sample first = liquid's firfilt order.
 //   * D = A B with the 16x16x4 shape: A[i][kappa] = g[i + (n-1) - kappa] (lane l: row l & 15, kappa = 4 s + (l >> 4)),
 //     B[kappa][j] = X[T - (n-1) + kappa][channel j] (lane l: 64 CONSECUTIVE floats of the time-major window per step: no bank
-//     conflicts, no padding).  The band needs n - 1 + 16 kappa per 16 frames: 398 -> 100 steps (the 32-row tiles need 414 -> 416);
+//     conflicts, no padding).  The band needs n - 1 + 16 kappa per 16 frames: 398 -> 100 steps;
 //   * a wave owns 32 frames: two accumulators (16 frames each) that share every A operand and alternate on the pipe (32-cycle
 //     issue, 40-cycle dependent latency);
-//   * a workgroup = 4 waves = 128 frames: 33 KB of LDS, four per CU, 2731 workgroups per cfg2 block: the dispatcher evens the
-//     load out (10.7 wave-units of 6.4k cycles per SIMD), and one workgroup's window staging hides under three others' MFMAs;
+//   * a workgroup = 4 waves = 128 frames: 33 KB of LDS, four per CU, 2731 workgroups per cfg2 block;
 //   * the epilogue goes through LDS so that PCM / audio leave as whole 16-byte pieces of a channel row (256 B per channel).
 // Measured on MI355X (round 3): the k loop alone reaches 140-150 TFLOP/s with 2-4 workgroups per CU (tools/exp/mfma_f32_rate.hip:
-// 90-96 % of the f32 MFMA peak, operands from LDS), the kernel 88 (cfg2: 0.053 ms; the 32x32x2 form 0.055): the rest is the
-// window traffic -- 2731 x 36 KB = 98 MB per cfg2 block, fetched by all the workgroups of a dispatch round at once.  Two forms
-// that cut it (a workgroup sliding the window over a run of 2-6 tiles with the next rows prefetched under the MFMAs; one
-// persistent workgroup per CU) were built and measured: equal or slower alone (0.053-0.071 ms) and slower in the chain, so they
-// are not in the tree.  In the chain this kernel wins where a block has few frames (cfg3 +3 %, the reference point: twice the
-// workgroups of the 256-frame form) and LOSES at cfg2 (-8 %: its short-lived workgroups get a smaller share of the CUs beside
-// the front end's tiles than the long-lived ones of the 256-frame form, and the back-end stream is the critical one there);
-// pmr_launch_fir_tm picks per plan.
+// 90-96 % of the f32 MFMA peak, operands from LDS), the kernel 88 (cfg2: 0.053 ms): the rest is the window traffic -- 2731 x 36 KB
+// = 98 MB per cfg2 block.  Round 2's 32x32x2 / 256-frame form (pmr_fir_mfma.hip, bit-identical results, the faster one in the
+// cfg2 chain of round 3) and forms that slid the window over several tiles were retired in round 4 with the FFT form's arrival.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

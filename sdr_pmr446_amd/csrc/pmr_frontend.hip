@@ -565,15 +565,16 @@ extern "C" int pmr_launch_fe_level2_fast(pmr_stream_t s, const pmr_fe_params *p,
 /* tile geometries: (threads, samples per thread).  4096-sample tiles as 256 x 16; 16384-sample tiles (cascades too deep
  * for those where the two-level split does not apply) as 1024 x 16.  The specialised kernels of pmr_fe_fast.hip take the
  * cascades they cover unless `generic` is set (PMR_FE_KERNEL=generic).                                               */
-extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt, int generic,
+extern "C" int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt,
                                    const pmr_launch_events *ev)
 {
     if (!ntiles) return 0;
     hipStream_t st = (hipStream_t)s;
-    if (!generic && nt == 256 && spt == 16 && (p->mode == FE_FULL || p->mode == FE_L1)) {
-        const int rc = pmr_launch_fe_fast(s, p, ntiles, ev);
+    if (nt == 256 && spt == 16 && (p->mode == FE_FULL || p->mode == FE_L1)) {
+        const int rc = pmr_launch_fe_fast(s, p, ntiles, ev);        /* the specialised kernels, where the cascade is one they cover */
         if (rc >= 0) return rc;
     }
+    if (p->in_fmt) return (int)hipErrorInvalidValue;                /* (only k_fe_fast converts integer samples as it loads) */
     if (p->mode == FE_L1 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L1>(st, p, ntiles, ev);
     if (p->mode == FE_L2 && nt == 256 && spt == 16) return launch_frontend_t<256, 16, FE_L2>(st, p, ntiles, ev);
     if (p->mode != FE_FULL) return (int)hipErrorInvalidValue;

@@ -14,36 +14,14 @@ extern "C" {
 
 typedef void *pmr_stream_t;     /* hipStream_t */
 
-/* A/B switches: read from the environment ONCE per handle by pmr_chain_create and handed to the launchers;
- * nothing on a launch path calls getenv.  All zero = the product. */
-enum { PMR_FIR_MFMA = 0, PMR_FIR_PAIR = 1, PMR_FIR_LDS = 2, PMR_FIR_TM = 3 };
+/* Environment switches: read ONCE per handle by pmr_chain_create; nothing on a launch path calls getenv.
+ * All zero = the product. */
 typedef struct {
-    int fe_staged;          /* PMR_FRONTEND=staged: one kernel per front-end stage                         */
-    int fe_generic;         /* PMR_FE_KERNEL=generic: run-time-parameterised k_frontend                     */
-    int fe_levels;          /* PMR_FE_LEVELS=1|2: force the one- / two-level front end (0 = automatic)      */
-    int l2_on_fe;           /* PMR_L2_STREAM=fe: level 2 on the front-end stream                            */
-    int chan_generic;       /* PMR_CHANNELIZER=generic: k_channelize for M = 16 too                         */
-    int chan_pair;          /* PMR_CHANNELIZER_SMALL=pair: two-frames-per-thread small-M channelizer        */
-    int chan_unfused;       /* PMR_CHAN_FUSED=0: M = 256 through k_pfb_wide + k_fft_disc instead of the fused kernel */
-    int chan_ft;            /* PMR_CHAN_FT=n: tile height of the generic channelizer (0 = automatic)        */
-    int fir_mode;           /* PMR_FIR=pair|lds|global: VALU versions of the audio FIR (PMR_FIR_*)          */
     int fir_direct;         /* PMR_FIR=direct: the direct (MFMA) form of the audio FIR for every block (default: FFT form for large blocks) */
-    int fir_mfma_global;    /* PMR_FIR_MFMA=global: MFMA FIR without the LDS sample window                  */
-    int fir_mfma32;         /* PMR_FIR_MFMA=32: the 32x32x2 / 256-frame-tile form of the MFMA FIR (A/B reference) */
-    int fir_mfma4;          /* PMR_FIR_MFMA=4: the 16x16x4 / 128-frame-tile form for every plan (default: by plan, pmr_launch_fir_tm) */
-    int fir_tpw;            /* PMR_FIR_TPW=1: one tile per workgroup in the MFMA FIR (default 2)            */
-    int fir_nodual;         /* PMR_FIR_DUAL=0: CTCSS low-pass branch in a FIR pass of its own                */
-    int no_overlap;         /* PMR_OVERLAP=0                                                                */
-    int be_prio;            /* PMR_STREAM_PRIO: unset = equal priorities, "1" = 1 back end high (round-1 default), "fe" = 2 front end high */
-    int host_gate;          /* default on; PMR_HOST_GATE=0: ring-reuse gating by a wait packet on the front-end stream */
-    int ct_no_async;        /* PMR_CT_STREAM=0: the CTCSS detector's kernels stay on the back-end stream (default: own stream, pipelined calls) */
-    unsigned zc_max_in;     /* PMR_ZEROCOPY_MAX=n: largest block (samples) a synchronous call reads in place from pinned host memory */
+    int no_overlap;         /* PMR_OVERLAP=0: single-stream calls (also pmr_chain_set_overlap)                */
     int no_zerocopy;        /* PMR_ZEROCOPY=0: synchronous host calls always go through the copy engines (H2D / D2H) */
-    int tf_on_be;           /* PMR_TILEFIX_STREAM: unset = by load (pmr_chain.c tilefix_on_backend), "be" = 1 back-end stream, "fe" = 2 front-end stream */
     int carry_inplace;      /* PMR_CARRY=inplace: one-level front end's dc carry by the read-modify-write pass over the whole block
-                               (k_fe_tilefix) instead of at the channelizer's loads                                     */
-    int fe_marker;          /* PMR_FE_EVENT=marker: "front end done" as a separate event-record packet (default: the last
-                               front-end launch's own completion signal) */
+                               (k_fe_tilefix) instead of at the channelizer's loads -- the form the at-load one must equal bit for bit */
 } pmr_switches;
 
 #define PMR_DC_TILE 4096u       /* raw samples per dc-block tile (256 threads x 16) */
@@ -122,26 +100,25 @@ typedef struct {
 
 /* does the channelizer this (M, p, nco_period, switches) selects apply pmr_carry_fix at load?  `adv_q` = decimated samples one
  * frame advances (upper bound), TQ as above */
-int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco_period, int chan_small, int chan_wide, int pair, int unfused,
+int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco_period, int chan_small, int chan_wide,
                                  unsigned adv_q, unsigned TQ);
 /* LDS table length (pmr_carry_fix.nv) for that kernel */
 unsigned pmr_channelize_carry_nv(unsigned M, unsigned adv_q, unsigned TQ);
 
 /* NCO shift + polyphase analysis bank + M-point FFT + discriminator (:808-821, :881), any power-of-two M */
-int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int ft_forced /*0 = automatic*/);
+int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out);
 int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, unsigned ntiles, unsigned M, unsigned ns,
                            float *rssi_db);
 
-/* wide banks (pmr_channelize_wide.hip, M = 64 / 256 / 1024 / 4096): filter-bank kernel parallel over channels, then radix-4
- * FFT + discriminator kernel parallel over frames; x_scratch holds (ns + 1) * M complex floats.  Same outputs. */
+/* wide banks (pmr_channelize_wide.hip): M = 256 in one fused kernel; M = 64 / 1024 / 4096: filter-bank kernel parallel over channels,
+ * then radix-4 FFT + discriminator kernel parallel over frames; x_scratch holds (ns + 1) * M complex floats.  Same outputs. */
 int pmr_channelize_wide_supported(unsigned M, unsigned p, unsigned nco_period);
-int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out,
-                               int unfused /*M = 256: separate filter-bank and FFT kernels instead of the fused one*/);
+int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params *p, void *x_scratch, unsigned *ntiles_out);
 
-/* small-M specialisation (pmr_channelize_small.hip): thread-per-frame-pair, FFT in registers.  n_valid = valid
- * samples in xr (zeros are read beyond).  Same outputs as pmr_launch_channelize.                       */
+/* the 16-channel, 26-tap bank of the PMR446 plan (pmr_channelize_small.hip): staged window, sliding-window bank, FFT in registers.
+ * Same outputs as pmr_launch_channelize. */
 int pmr_channelize_small_supported(unsigned M, unsigned p, unsigned nco_period);
-int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int pair /*two frames per thread*/);
+int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out);
 
 /* time-major real FIR with optional epilogue (:882-904).
  *  in        time-major, in[(t)*M + k], t = 0 first new frame (history at negative t)
@@ -159,13 +136,13 @@ int pmr_launch_channelize_small(pmr_stream_t s, const pmr_chan_params *p, unsign
  *  reference's block size): the RSSI finish of the block's channelizer (k_rssi_finish's arithmetic, one extra workgroup).  Taken by
  *  the 16x16x4 MFMA kernel on blocks of a few tiles; *job_done says whether it was (otherwise the caller launches k_rssi_finish). */
 typedef struct { const float *rssi_part; unsigned ntiles, M, ns; float *rssi_db; } pmr_rssi_job;
-int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                       const float *taps_pad, unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
                       float *out_tm, int16_t *pcm, float *audio, unsigned stride, const unsigned *chan_list, unsigned n_chan,
                       const pmr_rssi_job *job /*nullable*/, int *job_done /*nullable*/);
 /* audio FIR (-> pcm / audio) and a second tap set of the same length (-> time-major out2_tm) in ONE pass over the samples;
  * returns -1 when the MFMA kernel cannot take it (caller then runs two passes) */
-int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
+int pmr_launch_fir_dual(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns, unsigned M,
                         const float *taps_pad, const float *taps2_pad, unsigned ntaps, int16_t *pcm, float *audio, unsigned stride,
                         float *out2_tm, const unsigned *chan_list, unsigned n_chan);
 
@@ -189,13 +166,6 @@ int pmr_launch_fir_mfma4(pmr_stream_t s, const float *in, uint64_t row_mask, int
                          const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
                          const unsigned *chan_list, unsigned n_chan, const float *taps2_pad, float *out2_tm,
                          const pmr_rssi_job *job /*nullable*/, int *job_done /*nullable*/);
-/* the 32x32x2 form it replaced (PMR_FIR_MFMA=32: A/B reference) */
-int pmr_fir_mfma_supported(unsigned M, unsigned ntaps);
-int pmr_launch_fir_mfma(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
-                        unsigned M, const float *taps_pad, unsigned ntaps, float *out_tm, int16_t *pcm, float *audio,
-                        unsigned stride, const unsigned *chan_list /*nullable: enabled channels (device)*/, unsigned n_chan,
-                        const float *taps2_pad /*nullable: second tap set (same ntaps), -> out2_tm, same pass*/, float *out2_tm);
-
 /* ---- CTCSS branch (pmr_ctcss.hip) ---- */
 #define PMR_CT_TONES 38u
 #define PMR_CT_SEG 16u          /* time segments a Goertzel block is split into */
@@ -222,7 +192,10 @@ int pmr_launch_dsd_hb(pmr_stream_t s, const float *in, uint64_t in_mask, uint64_
 /* ---- fused front end (pmr_frontend.hip): dc-block + half-band cascade + arbitrary resampler in one pass ---- */
 #define PMR_FE_MAX_STAGES 16
 typedef struct {
-    const void *x;              /* new block [n_in] cf32                                             */
+    const void *x;              /* new block [n_in]: cf32, or the raw integer samples when in_fmt != 0 */
+    int in_fmt;                 /* 0 cf32; 1 interleaved int16 / 32768; 2 interleaved uint8, (x - 127.5) / 127.5 (include/pmr_io.h):
+                                   converted as the tile is loaded -- synchronous zero-copy calls on the receiver's own sample format
+                                   (k_fe_fast only: pmr_fe_fast_covers; same arithmetic as k_iq_convert)                            */
     const void *hist;           /* raw history: the hcap samples before the block                    */
     void *new_hist;             /* raw history for the NEXT call (other ping-pong buffer), written by tile 0 */
     void *out;                  /* resampled ring; output j of this block goes to out[(out_pos0 + j) & out_mask] */
@@ -275,13 +248,15 @@ typedef struct {
  * own on the stream, where hipEventRecord is a marker packet that costs ~3.6 us between two back-to-back kernels -- and
  * `start` a marker in front (start..stop = the kernel's own begin..end timestamps).  Both nullable hipEvent_t; ev may be NULL. */
 typedef struct { void *start, *stop; } pmr_launch_events;
-int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt, int generic,
+int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int nt, int spt,
                         const pmr_launch_events *ev);
 /* level 2 of the two-level front end: the specialised k_fe_level2 (m = 5, 10 + resampler, 2048-sample tiles) or the generic
  * k_frontend in mode 2 (4096-sample tiles) */
 int pmr_launch_frontend_l2(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int fast);
 /* specialised kernels of pmr_fe_fast.hip; return -1 when the cascade is not one they cover */
 int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev);
+/* does a specialised kernel exist for this cascade (mode 0: whole front end, 1: level 1; m[0..h): stages in execution order)? */
+int pmr_fe_fast_covers(int mode, const int *m, int h);
 /* tile carries of a level-1 launch (V[c], next call's dc state) + in-place dc fix of the ring samples [f->j0, f->ny) */
 int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f);
 /* one-level front end, carry applied at the channelizer's loads: tile carries + in-place correction of the block's tail [f->j0, f->ny) */

@@ -189,12 +189,6 @@ static __host__ __device__ inline unsigned chan_ft_auto(unsigned M, unsigned ns)
     if (want < 2u) want = 2u;
     return want < cap ? want : cap;
 }
-// the tile height is chosen on the host (`forced` = PMR_CHAN_FT, for experiments) and handed to the kernel
-static unsigned chan_ft(unsigned M, unsigned ns, int forced)
-{
-    if (forced >= 2) { unsigned cap = 8192u / M; if (cap < 2u) cap = 2u; return (unsigned)forced < cap ? (unsigned)forced : cap; }
-    return chan_ft_auto(M, ns);
-}
 
 template <int F, int P>
 static __device__ __forceinline__ void pfb_rows(const pmr_chan_params &q, unsigned log2M, cf *Xs, long long fbase,
@@ -350,174 +344,12 @@ __global__ void k_rssi_finish(const float *__restrict__ part, unsigned ntiles, u
     rssi_db[k] = 20.f * log10f(a / (float)ns);       // average_power(), :330-336
 }
 
-// ------------------------------------------------------------------------------------------------
-// Time-major real FIR, R outputs per thread, taps wave-uniform (scalar loads), optional epilogue:
-//   gain (:890) -> de-emphasis IIR (:898) -> int16 PCM (src/dsd_in.c:174) / float audio (:904)
-// lane <-> (channel k, time segment); y[t] = sum_d h[d] x[t-d], accumulated oldest sample first.
-// ------------------------------------------------------------------------------------------------
-#define RP (PMR_AUDIO_R + PMR_AUDIO_J)
 typedef float v2f __attribute__((ext_vector_type(2)));
-static_assert(RP % 2 == 0, "packed accumulators come in pairs");
-
-// Inner loop shared by the FIR kernels.  acc[i] <-> output t0 - J + i; step e brings input sample
-// s = t0 - J - (ntaps-1) + e, which meets output i with tap taps_q[(ntaps + RP - 2 - e) + i] (taps_q = h zero-padded
-// by RP-1 on both sides).  Four steps share ONE window of RP+3 wave-uniform taps (a few wide scalar loads instead
-// of one s_load per tap pair); every tap is then an SGPR operand of a plain v_fmac_f32.
-template <typename LoadX>
-static __device__ __forceinline__ void fir_accumulate(float (&acc)[RP], const float *__restrict__ taps_q,
-                                                      unsigned ntaps, LoadX loadx)
-{
-    const unsigned steps = ntaps + RP - 1;
-    const float *tq0 = taps_q + PMR_TAP_PAD + (ntaps - 1) - (RP - 1) + (RP - 1);
-    unsigned e = 0;
-    for (; e + 4 <= steps; e += 4) {
-        const float x0 = loadx(e), x1 = loadx(e + 1), x2 = loadx(e + 2), x3 = loadx(e + 3);
-        const float *tp = tq0 - e - 3;                // tap(e + u, i) = tp[3 - u + i]
-#pragma unroll
-        for (int i = 0; i < (int)RP; i++) {
-            float a = acc[i];
-            a = fmaf(tp[3 + i], x0, a);
-            a = fmaf(tp[2 + i], x1, a);
-            a = fmaf(tp[1 + i], x2, a);
-            a = fmaf(tp[i], x3, a);
-            acc[i] = a;
-        }
-    }
-    for (; e < steps; e++) {
-        const float x = loadx(e);
-        const float *tp = tq0 - e;
-#pragma unroll
-        for (int i = 0; i < (int)RP; i++) acc[i] = fmaf(tp[i], x, acc[i]);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_fir_tm(const float *__restrict__ in, unsigned long long row_mask,
-                                                long long row0, unsigned ns, unsigned M,
-                                                unsigned log2M, const float *__restrict__ taps_q,
-                                                unsigned ntaps, float gain, int iir, float b0, float b1, float a1,
-                                                float *__restrict__ out_tm, int16_t *__restrict__ pcm,
-                                                float *__restrict__ audio, unsigned stride)
-{
-    const unsigned gid = blockIdx.x * 256u + threadIdx.x;
-    const unsigned k = gid & (M - 1), seg = gid >> log2M;
-    const long t0 = (long)seg * PMR_AUDIO_R;
-    if (t0 >= (long)ns) return;
-    // acc[i] <-> output t0 - J + i.  Step e brings input sample s = t0 - J - (ntaps-1) + e, which meets output i
-    // with tap h[(ntaps-1) + i - e]; taps_q is that sequence zero-padded and stored so that the RP taps of one
-    // step are ASCENDING in i: tap(e, i) = taps_q[(ntaps + RP - 2 - e) + i].  Two adjacent accumulators share
-    // one v_pk_fma_f32 (x broadcast, tap pair from scalar registers).
-    float acc[RP];
-#pragma unroll
-    for (int i = 0; i < (int)RP; i++) acc[i] = 0.f;
-    const long long r0 = row0 + t0 - (long long)PMR_AUDIO_J - (long long)(ntaps - 1);
-    fir_accumulate(acc, taps_q, ntaps,
-                   [&](unsigned e) { return in[((unsigned long long)(r0 + e) & row_mask) * M + k]; });
-    float v1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < (int)RP; i++) {
-        float u = __fmul_rn(acc[i], gain);
-        float y = u;
-        if (iir) {
-            const float v0 = __fsub_rn(u, __fmul_rn(a1, v1));
-            y = __fadd_rn(__fmul_rn(b0, v0), __fmul_rn(b1, v1));
-            v1 = v0;
-        }
-        if (i >= (int)PMR_AUDIO_J) {
-            const long t = t0 + (i - (int)PMR_AUDIO_J);
-            if (t < (long)ns) {
-                if (out_tm) out_tm[((unsigned long long)(row0 + t) & row_mask) * M + k] = y;
-                if (audio) audio[(size_t)k * stride + t] = y;
-                if (pcm) {
-                    float s = y * 32767.0f;
-                    int16_t q;
-                    if (!(s == s)) q = 0;
-                    else if (s >= 32767.0f) q = 32767;
-                    else if (s <= -32768.0f) q = -32768;
-                    else q = (int16_t)s;                  // truncation toward zero
-                    pcm[(size_t)k * stride + t] = q;
-                }
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
-// LDS-tiled version of k_fir_tm: one workgroup = 16 channels x 512 output frames.  The 16-channel slab of the
-// time-major input (rows of 64 bytes) is staged once with 16-byte loads; each thread (channel k, 32-output
-// segment) then walks its inputs out of LDS while the tap pairs stay wave-uniform in SGPRs (v_pk_fma_f32).
-// LDS row r lives at r*16 + 16*(r>>5) floats: neighbouring 32-row segments land on opposite bank halves, so the
-// 32 lanes of one ds_read_b32 (16 channels x 2 segments) never collide.
-// ------------------------------------------------------------------------------------------------
-#define FL_SEGS 16
-#define FL_T (FL_SEGS * PMR_AUDIO_R)          /* 512 output frames per tile */
-
-__global__ __launch_bounds__(256) void k_fir_lds(const float *__restrict__ in, unsigned long long row_mask,
-                                                 long long row0, unsigned ns, unsigned M,
-                                                 const float *__restrict__ taps_q, unsigned ntaps, float gain,
-                                                 int iir, float b0, float b1, float a1, float *__restrict__ out_tm,
-                                                 int16_t *__restrict__ pcm, float *__restrict__ audio,
-                                                 unsigned stride)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_f[];
-    float *tile = reinterpret_cast<float *>(smem_f);
-    const int tid = threadIdx.x;
-    const unsigned groups = M >> 4;
-    const unsigned g = blockIdx.x % groups, tb = blockIdx.x / groups;
-    const long t0w = (long)tb * FL_T;                              // first output frame of the tile
-    const long r0 = t0w - (long)PMR_AUDIO_J - (long)(ntaps - 1);   // frame of tile row 0
-    const unsigned rows = FL_T + PMR_AUDIO_J + ntaps - 1;
-
-    // stage [rows][16] (frames >= ns read as zero; history lives at negative frames of `in`)
-    for (unsigned u = tid; u < rows * 4; u += 256) {
-        const unsigned r = u >> 2, q4 = (u & 3) * 4;
-        const long t = r0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < (long)ns)
-            v = *reinterpret_cast<const float4 *>(in + ((unsigned long long)(row0 + t) & row_mask) * M + g * 16 + q4);
-        *reinterpret_cast<float4 *>(tile + r * 16 + 16 * (r >> 5) + q4) = v;
-    }
-    __syncthreads();
-
-    const unsigned k = tid & 15, seg = tid >> 4;
-    const long t0 = t0w + (long)seg * PMR_AUDIO_R;
-    if (t0 >= (long)ns) return;
-    float acc[RP];
-#pragma unroll
-    for (int i = 0; i < (int)RP; i++) acc[i] = 0.f;
-    const float *px = tile + seg * (PMR_AUDIO_R * 16 + 16) + k;    // row seg*32 of the tile, column k
-    fir_accumulate(acc, taps_q, ntaps, [&](unsigned e) { return px[e * 16 + 16 * (e >> 5)]; });
-    const unsigned kk = g * 16 + k;
-    float v1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < (int)RP; i++) {
-        float u = __fmul_rn(acc[i], gain);
-        float y = u;
-        if (iir) {
-            const float v0 = __fsub_rn(u, __fmul_rn(a1, v1));
-            y = __fadd_rn(__fmul_rn(b0, v0), __fmul_rn(b1, v1));
-            v1 = v0;
-        }
-        if (i >= (int)PMR_AUDIO_J) {
-            const long t = t0 + (i - (int)PMR_AUDIO_J);
-            if (t < (long)ns) {
-                if (out_tm) out_tm[((unsigned long long)(row0 + t) & row_mask) * M + kk] = y;
-                if (audio) audio[(size_t)kk * stride + t] = y;
-                if (pcm) {
-                    float s = y * 32767.0f;
-                    int16_t q;
-                    if (!(s == s)) q = 0;
-                    else if (s >= 32767.0f) q = 32767;
-                    else if (s <= -32768.0f) q = -32768;
-                    else q = (int16_t)s;                  // truncation toward zero
-                    pcm[(size_t)kk * stride + t] = q;
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_fir_pair: the same FIR + epilogue, PACKED ACROSS TWO ADJACENT CHANNELS.  lane <-> (channel pair, 16-output
+// k_fir_pair: the direct-form audio FIR for channel counts the MFMA kernel does not take (M not a multiple of 16) -- time-major real
+// FIR y[t] = sum_d h[d] x[t-d], accumulated oldest sample first, + epilogue (gain :890, de-emphasis IIR :898, int16 PCM
+// src/dsd_in.c:174 / float audio :904), PACKED ACROSS TWO ADJACENT CHANNELS.  lane <-> (channel pair, 16-output
 // segment); accumulator i is the v2f (channel 2c, channel 2c+1) of output t0 - J + i, so one v_pk_fma_f32 per
 // (step, output) does two MACs with the tap broadcast from a single SGPR (no SGPR-pair alignment, no moves) and
 // the input pair is one 8-byte load from the time-major stream.  v_pk_fma_f32 sustains ~1.8x the FLOP rate of
@@ -736,9 +568,9 @@ extern "C" int pmr_launch_arb(pmr_stream_t s, const void *dec, void *out_ring, u
     return (int)hipGetLastError();
 }
 
-extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out, int ft_forced)
+extern "C" int pmr_launch_channelize(pmr_stream_t s, const pmr_chan_params *p, unsigned *ntiles_out)
 {
-    const unsigned ft = chan_ft(p->M, p->ns, ft_forced);
+    const unsigned ft = chan_ft_auto(p->M, p->ns);                      /* tile height: chosen on the host, handed to the kernel */
     const unsigned ntiles = (p->ns + ft - 2) / (ft - 1);
     if (ntiles_out) *ntiles_out = ntiles;
     if (!p->ns) return 0;
@@ -760,77 +592,32 @@ extern "C" int pmr_launch_rssi_finish(pmr_stream_t s, const float *rssi_part, un
     return (int)hipGetLastError();
 }
 
-/* Which MFMA form runs the audio FIR (both give the same bits).  The 16x16x4 / 128-frame-tile kernel (pmr_fir_mfma4.hip) unless
- * the plan is 16 channels with big blocks: there the 32x32x2 kernel's 256-frame, two-tiles-per-workgroup form is faster IN THE
- * CHAIN (cfg2: 376 vs 345 GS/s on one box; see the header of pmr_fir_mfma4.hip), while blocks of a few thousand frames (the
- * reference's 100 000-sample blocks: 1220) want the finer tiles (10 workgroups instead of 5).  PMR_FIR_MFMA=4 / =32 force one. */
-static bool fir_use_mfma4(const pmr_switches *sw, unsigned M, unsigned ntaps, unsigned ns, const unsigned *chan_list, unsigned n_chan,
-                          bool dual = false)
-{
-    if (!pmr_fir_mfma4_supported(M, ntaps) || sw->fir_mfma32) return false;
-    if (sw->fir_mfma4 || !pmr_fir_mfma_supported(M, ntaps)) return true;
-    /* open-channel mask: a workgroup takes 16 (channel, segment) units whatever their length, so few open channels want the SHORT
-     * segments -- twice the workgroups, half the serial work each (one open channel at cfg2: 171 workgroups instead of 86) */
-    if (chan_list && (unsigned long long)n_chan * ((ns + 255u) / 256u) < 16ull * 1024ull) return true;
-    /* two tap sets in one pass (CTCSS on): the 32x32x2 kernel then has registers for ONE tile per workgroup only and is the slower
-     * one in the chain too (cfg2, detector on, all channels: 254 vs 247 GS/s) */
-    if (dual) return true;
-    return !(M == 16 && ns >= 65536);
-}
-
-extern "C" int pmr_launch_fir_dual(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
+/* second tap set in the same pass (CTCSS low-pass branch): the MFMA kernel only; -1: caller runs two passes */
+extern "C" int pmr_launch_fir_dual(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0, unsigned ns,
                                    unsigned M, const float *taps_pad, const float *taps2_pad, unsigned ntaps, int16_t *pcm, float *audio,
                                    unsigned stride, float *out2_tm, const unsigned *chan_list, unsigned n_chan)
 {
-    if (sw->fir_mode != PMR_FIR_MFMA || sw->fir_mfma_global) return -1;
-    if (fir_use_mfma4(sw, M, ntaps, ns, chan_list, n_chan, true))
-        return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan, taps2_pad, out2_tm,
-                                    nullptr, nullptr);
-    if (!pmr_fir_mfma_supported(M, ntaps)) return -1;
-    if (!ns) return 0;
-    return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan,
-                               taps2_pad, out2_tm);
+    if (!pmr_fir_mfma4_supported(M, ntaps)) return -1;
+    return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, nullptr, pcm, audio, stride, chan_list, n_chan, taps2_pad, out2_tm,
+                                nullptr, nullptr);
 }
 
-extern "C" int pmr_launch_fir_tm(const pmr_switches *sw, pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
+extern "C" int pmr_launch_fir_tm(pmr_stream_t s, const float *in, uint64_t row_mask, int64_t row0,
                                  unsigned ns, unsigned M, const float *taps_pad, unsigned ntaps, float gain, int iir, float b0,
                                  float b1, float a1, float *out_tm, int16_t *pcm, float *audio, unsigned stride,
                                  const unsigned *chan_list, unsigned n_chan, const pmr_rssi_job *job, int *job_done)
 {
     if (job_done) *job_done = 0;
     if (!ns) return 0;
-    const int mode = sw->fir_mode;           /* PMR_FIR_MFMA (default where supported), _PAIR, _LDS, _TM */
-    if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && !sw->fir_mfma_global && fir_use_mfma4(sw, M, ntaps, ns, chan_list, n_chan))
+    /* the direct form: on the matrix pipe (pmr_fir_mfma4.hip) where M is a multiple of 16, else packed over channel pairs on the VALU */
+    if (gain == 1.0f && !iir && pmr_fir_mfma4_supported(M, ntaps))
         return pmr_launch_fir_mfma4(s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr,
                                     job, job_done);
-    if (mode == PMR_FIR_MFMA && gain == 1.0f && !iir && pmr_fir_mfma_supported(M, ntaps))
-        return pmr_launch_fir_mfma(sw, s, in, row_mask, row0, ns, M, taps_pad, ntaps, out_tm, pcm, audio, stride, chan_list, n_chan, nullptr, nullptr);
-    if ((mode == PMR_FIR_PAIR || mode == PMR_FIR_MFMA) && M >= 2) {
-        const unsigned segs = (ns + FP_R - 1) / FP_R;
-        const size_t threads = (size_t)segs * (M >> 1);
-        PMR_KLAUNCH(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, M,
-                           ilog2(M >> 1), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
-        return (int)hipGetLastError();
-    }
-    if (mode == PMR_FIR_LDS && M >= 16 && ntaps <= 512) {
-        const unsigned rows = FL_T + PMR_AUDIO_J + ntaps - 1;
-        const size_t lds = ((size_t)rows * 16 + 16 * ((rows >> 5) + 1)) * sizeof(float);
-        static pmr_attr_flags attr_set{0};
-        if (pmr_attr_needed(attr_set)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_lds),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
-        const unsigned tiles = (ns + FL_T - 1) / FL_T;
-        PMR_KLAUNCH(k_fir_lds, dim3(tiles * (M >> 4)), dim3(256), lds, (hipStream_t)s, in,
-                           (unsigned long long)row_mask, (long long)row0, ns, M, taps_pad,
-                           ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
-        return (int)hipGetLastError();
-    }
-    const unsigned segs = (ns + PMR_AUDIO_R - 1) / PMR_AUDIO_R;
-    const size_t threads = (size_t)segs * M;
-    PMR_KLAUNCH(k_fir_tm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
+    if (chan_list || M < 2) return (int)hipErrorInvalidValue;            /* (the open-channel list needs the MFMA kernel: pmr_chain_set_channel_mask) */
+    const unsigned segs = (ns + FP_R - 1) / FP_R;
+    const size_t threads = (size_t)segs * (M >> 1);
+    PMR_KLAUNCH(k_fir_pair, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, in,
                        (unsigned long long)row_mask, (long long)row0, ns, M,
-                       ilog2(M), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
+                       ilog2(M >> 1), taps_pad, ntaps, gain, iir, b0, b1, a1, out_tm, pcm, audio, stride);
     return (int)hipGetLastError();
 }

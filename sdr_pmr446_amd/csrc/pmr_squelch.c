@@ -11,13 +11,16 @@ void pmr_squelch_init(pmr_squelch *s)
     s->rssi = 0.0f;
 }
 
-/* :668-700 -- only mask-enabled channels take part; result is (max - mean of the dB values) */
-int pmr_find_max_rssi_channel(const float *rssi_db, unsigned M, uint64_t channel_mask, float *max_rssi)
+/* :668-700 -- only mask-enabled channels take part; result is (max - mean of the dB values).  The mask has the layout of
+ * pmr_chain_set_channel_mask (bit k & 63 of word k >> 6 enables channel k: the reference's uint64_t channel_mask, :18, :293-295,
+ * for any M; NULL = every channel enabled).  A mask shorter than M channels is an error: -1, no channel. */
+int pmr_find_max_rssi_channel(const float *rssi_db, unsigned M, const uint64_t *mask_words, unsigned n_words, float *max_rssi)
 {
     int max_i = -1, ch_en = 0;
     float rssi_max = 0.0f, rssi_avg = 0.0f;
+    if (mask_words && (uint64_t)n_words * 64 < M) return -1;
     for (unsigned i = 0; i < M; i++) {
-        const int enabled = i >= 64 ? 1 : (int)((channel_mask >> i) & 1u);   /* the reference has at most 64 channels (:18) */
+        const int enabled = mask_words ? (int)((mask_words[i >> 6] >> (i & 63)) & 1u) : 1;
         if (!enabled) continue;
         ++ch_en;
         const float rssi = rssi_db[i];
@@ -36,11 +39,11 @@ int pmr_find_max_rssi_channel(const float *rssi_db, unsigned M, uint64_t channel
 }
 
 /* :828-874.  Returns 1 when the active channel changed (tuned, hopped or detuned), 0 otherwise. */
-int pmr_squelch_update(pmr_squelch *s, const float *rssi_db, unsigned M, uint64_t channel_mask, float squelch_level,
-                       int lock_mode_max)
+int pmr_squelch_update(pmr_squelch *s, const float *rssi_db, unsigned M, const uint64_t *mask_words, unsigned n_words,
+                       float squelch_level, int lock_mode_max)
 {
     float max_rssi = s->rssi;
-    const int max_ch = pmr_find_max_rssi_channel(rssi_db, M, channel_mask, &max_rssi);
+    const int max_ch = pmr_find_max_rssi_channel(rssi_db, M, mask_words, n_words, &max_rssi);
     const int before = s->active_chan;
     s->rssi = max_rssi;
     if (s->state == PMR_SCANNING) {

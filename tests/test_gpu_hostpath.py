@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle
-from parity_util import CFG2, CFG5, CFG_REF, active_channels, pcm_diff
+from parity_util import CFG2, CFG3, CFG5, CFG_REF, active_channels, pcm_diff
 from sdr_pmr446_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -102,6 +102,60 @@ def test_integer_ingest_formats_are_converted_on_the_device(fmt):
     g.close()
 
 
+@pytest.mark.parametrize("cfg,fmt,sizes", [(CFG_REF, "cu8", [100000, 99999, 7, 0, 100000, 65537, 3]),
+                                           (CFG_REF, "cs16", [100000, 100001, 1, 99998]),
+                                           (CFG2, "cu8", [250000, 1 << 18, (1 << 18) + 1, 300001]),
+                                           (CFG3, "cs16", [1 << 18, 200003, 150001]),
+                                           (CFG5, "cu8", [1 << 18, 200003])],
+                         ids=["ref-point-cu8", "ref-point-cs16", "cfg2-cu8-around-threshold", "cfg3-cs16", "cfg5-cu8"])
+def test_sync_integer_formats_read_in_place_equal_the_converted_cf32_call(cfg, fmt, sizes):
+    """pmr_chain_process_block_fmt: the synchronous call on the receiver's own samples (the reference's radio is an RTL-SDR: uint8
+    pairs, README.md:12; SoapySDR widens them to the cf32 of readStream, src/shared.c:62).  Blocks of up to 2^18 samples in
+    pmr_host_alloc memory are read in place by the front end and converted as it loads them (2 / 4 bytes per sample on the host
+    link); larger or pageable blocks go through H2D + the conversion kernel.  Either way PCM and audio are BIT-IDENTICAL to the cf32
+    call on the host-converted samples -- ragged sizes, a view at an odd offset inside the pinned allocation (unaligned groups) and a
+    pageable copy included."""
+    from sdr_pmr446_amd import chain
+    fs, M = cfg
+    n = sum(sizes)
+    x = synth.synth_iq(n, fs, M, dev_hz=1500.0, channels=None if M <= 16 else list(range(0, M, M // 16)))
+    xi = np.empty(2 * n, np.float32); xi[0::2] = x.real; xi[1::2] = x.imag
+    if fmt == "cs16":
+        raw = np.clip(np.round(xi * 32768.0 * 1.5), -32768, 32767).astype(np.int16)
+        host = raw.astype(np.float32) * np.float32(1.0 / 32768.0)
+        code = chain.IQ_CS16
+    else:
+        raw = np.clip(np.round(xi * 127.5 * 1.5 + 127.5), 0, 255).astype(np.uint8)
+        host = (raw.astype(np.float32) - np.float32(127.5)) * np.float32(1.0 / 127.5)
+        code = chain.IQ_CU8
+    xc = (host[0::2] + 1j * host[1::2]).astype(np.complex64)
+    mb = max(sizes)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=mb)
+    ref, pos = [], 0
+    for s_ in sizes:
+        ref.append(g.process_block(xc[pos:pos + s_], want=("pcm", "audio")))
+        pos += s_
+    for variant in ("pinned", "pinned-odd-offset", "pageable"):
+        g.reset()
+        pin = g.pinned_array(2 * mb + 8, raw.dtype)
+        pos = 0
+        for k, s_ in enumerate(sizes):
+            blk = raw[2 * pos:2 * (pos + s_)]
+            if variant == "pageable":
+                src = blk
+            else:
+                off = 2 if variant == "pinned-odd-offset" else 0          # one complex sample in: groups of four no longer aligned
+                src = pin[off:off + 2 * s_]
+                src[:] = blk
+            r = g.process_block(src, want=("pcm", "audio"), fmt=code)
+            assert r["n_frames"] == ref[k]["n_frames"]
+            assert np.array_equal(r["pcm"], ref[k]["pcm"]), (variant, k)
+            assert np.array_equal(r["audio"], ref[k]["audio"]), (variant, k)
+            pos += s_
+    assert sum(r_["n_frames"] for r_ in ref) >= 5                  # (cfg5: 1024 channels, 12.5 kHz each: 460 000 samples are 5 frames)
+    g.close()
+
+
 @pytest.mark.parametrize("cfg,sizes", [(CFG_REF, [100000, 99999, 7, 0, 100000, 65537]), (CFG2, [250000, 1 << 18, (1 << 18) + 1, 300001]),
                                        (CFG5, [1 << 18, 200003])],
                          ids=["ref-point", "cfg2-around-threshold", "cfg5"])
@@ -192,7 +246,7 @@ def test_two_step_form_opens_the_squelch_on_the_same_block():
         blk = x[b * nb:(b + 1) * nb]
         ref = o.process_block(blk, want=("pcm",))["pcm"]
         c = g.channelize_block(blk, want=("rssi",))
-        if L.pmr_squelch_update(C.byref(st), c["rssi"].ctypes.data, M, (1 << 64) - 1, 18.0, 0):
+        if L.pmr_squelch_update(C.byref(st), c["rssi"].ctypes.data, M, None, 0, 18.0, 0):
             g.set_channel_mask([st.active_chan] if st.state == 1 else [])
             if st.state == 1 and opened_at is None:
                 opened_at = b

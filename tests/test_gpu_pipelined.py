@@ -111,13 +111,9 @@ CASES = [
     ({}, CFG3, RAGGED3, False),
     ({}, CFG5, RAGGED5, False),
     ({}, CFG2, RAGGED2, True),                         # CTCSS branch enabled (second FIR pass + detector kernels in the back end)
-    ({"PMR_L2_STREAM": "fe"}, CFG5, RAGGED5, False),
-    ({"PMR_FRONTEND": "staged"}, CFG2, RAGGED2, False),
-    ({"PMR_FE_EVENT": "marker"}, CFG2, RAGGED2, False),     # "front end done" as a record packet instead of the launch's own signal
-    ({"PMR_STREAM_PRIO": "fe"}, CFG3, RAGGED3, False),      # front-end stream at the higher priority
-    ({"PMR_TILEFIX_STREAM": "be"}, CFG2, RAGGED2, True),    # carry pass at the head of the back-end stream (CTCSS on)
-    ({"PMR_TILEFIX_STREAM": "be"}, CFG3, RAGGED3, False),
-    ({"PMR_HOST_GATE": "0"}, CFG5, RAGGED5, False),         # ring-reuse gating by a wait packet instead of the host
+    ({}, CFG3, RAGGED3, True),
+    ({"PMR_FIR": "direct"}, CFG2, RAGGED2, False),     # the direct MFMA form of the audio FIR on the big blocks (default: FFT form)
+    ({"PMR_CARRY": "inplace"}, CFG3, RAGGED3, False),  # dc carry by the in-place pass (what debug capture / waterfall calls fall back to)
 ]
 
 
@@ -160,7 +156,7 @@ print("frames", fresh.shape[1], "identical", bool(ok))
 sys.exit(0 if ok and fresh.shape[1] > 50 else 1)
 """
 
-RESET_CASES = [({}, CFG2, RAGGED2), ({"PMR_FRONTEND": "staged"}, CFG2, RAGGED2), ({}, CFG5, RAGGED5)]
+RESET_CASES = [({}, CFG2, RAGGED2), ({"PMR_CARRY": "inplace"}, CFG2, RAGGED2), ({}, CFG5, RAGGED5)]
 
 
 @pytest.mark.parametrize("env,cfg,sizes", RESET_CASES,

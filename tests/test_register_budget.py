@@ -1,6 +1,6 @@
 """The kernels' VGPR counts are part of the design: four front-end tiles (4 x 88 registers per SIMD) leave 160 for a back-end
-wave, so the 256-frame audio FIR must stay <= 160 and the front end <= 88 -- a build that crossed either line by five registers
-cost the cfg2 chain 8-10 % with no test failing (profiles/r03_ab_log.txt).  Cross-compiles the four units for
+wave, so every back-end kernel must stay <= 160 (the FFT audio FIR <= 128) and the front end <= 88 -- a build that crossed either line by five registers
+cost the cfg2 chain 8-10 % with no test failing (profiles/r03_ab_log.txt).  Cross-compiles the units for
 gfx950 (no GPU needed) and reads the counts from the code objects' metadata."""
 import os
 import re
@@ -18,7 +18,7 @@ BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, w
     ("pmr_fe_fast.hip", r"k_fe_fastILi0E", 88, "one-level front end: four tiles per SIMD + one 160-register back-end wave"),
     ("pmr_fe_fast.hip", r"k_fe_fastILi1E", 64, "level 1 of the two-level front end"),
     ("pmr_fe_fast.hip", r"k_fe_level2", 80, "level 2 runs beside four level-1 tiles"),
-    ("pmr_fir_mfma.hip", r"k_fir_mfma16ILb0ELi2ELb1ELb0ELb0E", 160, "256-frame audio FIR beside four front-end tiles (cfg2)"),
+    ("pmr_fir_fft.hip", r"k_fir_fftILi4ELb0E", 128, "FFT form of the audio FIR (1024 points): one-wave workgroups, four per SIMD, beside four front-end tiles"),
     ("pmr_fir_mfma4.hip", r"k_fir_mfma4ILb0ELb0ELb0E", 64, "128-frame audio FIR: four workgroups per CU"),
     ("pmr_channelize_small.hip", r"k_channelize_winILi16ELi26ELb1ELi16E", 88, "16-channel bank: a wave fits beside four front-end tiles with room to spare"),
     ("pmr_channelize_wide.hip", r"k_channelize_fused256ILb1E", 128, "256-channel bank: four waves per SIMD"),

@@ -9,9 +9,18 @@ from oracle import squelch as orc
 from sdr_pmr446_amd import chain
 
 
-@pytest.mark.parametrize("M,lock_max,mask", [(16, 0, 0xFFFF), (16, 1, 0xFFFF), (16, 1, 0x0FF3), (256, 0, 0xFFFFFFFFFFFFFFF0)])
+def _words(mask, M):
+    """Python int (bit k = channel k) -> the uint64 mask words of pmr_chain_set_channel_mask / pmr_squelch_update."""
+    n = (M + 63) // 64
+    return np.array([(mask >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(n)], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("M,lock_max,mask", [(16, 0, 0xFFFF), (16, 1, 0xFFFF), (16, 1, 0x0FF3), (256, 0, (1 << 256) - 1 - 0xF),
+                                             (256, 1, ((1 << 256) - 1) & ~(0xFF << 64) & ~(1 << 200)),     # channels >= 64 CAN be excluded
+                                             (1024, 0, sum(1 << k for k in range(0, 1024, 3)))])
 def test_squelch_state_machine_matches_reference_logic(M, lock_max, mask):
     L = chain.load()
+    mw = _words(mask, M)
     rng = np.random.default_rng(M + lock_max)
     s = chain.Squelch()
     L.pmr_squelch_init(C.byref(s))
@@ -21,8 +30,8 @@ def test_squelch_state_machine_matches_reference_logic(M, lock_max, mask):
     for step in range(400):
         rssi = (rng.standard_normal(M) * 2.0 - 30.0).astype(np.float32)
         if (step // 25) % 2 == 1:                       # a carrier comes and goes, sometimes hopping
-            rssi[(3 + step // 50) % M] += np.float32(rng.uniform(10.0, 40.0))
-        changed = L.pmr_squelch_update(C.byref(s), rssi.ctypes.data, M, mask, 18.0, lock_max)
+            rssi[(3 + 67 * (step // 50)) % M] += np.float32(rng.uniform(10.0, 40.0))     # (lands on masked-out channels too)
+        changed = L.pmr_squelch_update(C.byref(s), rssi.ctypes.data, M, mw.ctypes.data, len(mw), 18.0, lock_max)
         ochanged = o.update(rssi, mask, 18.0, lock_max)
         assert (s.state, s.active_chan, bool(changed)) == (o.state, o.active_chan, bool(ochanged)), step
         assert s.rssi == pytest.approx(float(o.rssi), abs=1e-4)
@@ -35,6 +44,14 @@ def test_find_max_respects_mask_and_all_disabled():
     L = chain.load()
     rssi = np.array([-10, -50, 5, -50], dtype=np.float32)
     mr = C.c_float(123.0)
-    assert L.pmr_find_max_rssi_channel(rssi.ctypes.data, 4, 0b1011, C.byref(mr)) == 0      # channel 2 masked out
+    m = np.array([0b1011], dtype=np.uint64)
+    assert L.pmr_find_max_rssi_channel(rssi.ctypes.data, 4, m.ctypes.data, 1, C.byref(mr)) == 0      # channel 2 masked out
     assert mr.value == pytest.approx(-10 - (-10 - 50 - 50) / 3.0, abs=1e-5)
-    assert L.pmr_find_max_rssi_channel(rssi.ctypes.data, 4, 0, C.byref(mr)) == -1
+    z = np.zeros(1, dtype=np.uint64)
+    assert L.pmr_find_max_rssi_channel(rssi.ctypes.data, 4, z.ctypes.data, 1, C.byref(mr)) == -1
+    assert L.pmr_find_max_rssi_channel(rssi.ctypes.data, 4, None, 0, C.byref(mr)) == 2                # NULL = every channel
+    # a channel beyond 64 excluded (round 3 treated every channel >= 64 as enabled), and a mask shorter than M refused
+    big = np.full(256, -40.0, dtype=np.float32); big[200] = 0.0; big[70] = -5.0
+    w = _words(((1 << 256) - 1) & ~(1 << 200), 256)
+    assert L.pmr_find_max_rssi_channel(big.ctypes.data, 256, w.ctypes.data, 4, C.byref(mr)) == 70
+    assert L.pmr_find_max_rssi_channel(big.ctypes.data, 256, w.ctypes.data, 3, C.byref(mr)) == -1
