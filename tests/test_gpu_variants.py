@@ -23,10 +23,11 @@ CASES = [
     # id, fs_in, M, extra cfg, splits, expected (fe, chan, fir) plan
     ("staged-front-end-h12-4ch", 4 * 12500.0 * 5120.0, 4, {}, [700000, 1, 499999, 650000], (0, 0, 0)),
     ("generic-tile-kernel-As80", 2.4e6, 16, dict(resamp_As=80.0), [150000, 1, 99999, 130000], (1, 1, 2)),
-    ("two-level-generic-As75-1024ch", 1.0e9, 1024, dict(resamp_As=75.0), [1 << 22, 3000000], (4, 3, 2)),
+    ("generic-tile-kernel-As75-1024ch", 1.0e9, 1024, dict(resamp_As=75.0), [1 << 22, 3000000], (1, 3, 2)),
+    ("two-level-generic-level1-256ch-1GSps", 1.0e9, 256, {}, [1 << 22, 3000001], (4, 2, 2)),     # six six-tap stages in level 1
     ("generic-bank-16ch-m9", 2.4e6, 16, dict(pfb_m=9), [150000, 1, 99999, 130000], (2, 0, 2)),
     ("generic-bank-32ch", 4.8e6, 32, {}, [300000, 3, 199999], (2, 0, 2)),
-    ("pair-fir-8ch", 1.2e6, 8, {}, [80000, 1, 49999, 65000], (2, 0, 0)),
+    ("pair-fir-4ch", 1.6e6, 4, {}, [1 << 17, 1, (1 << 17) - 1], (2, 0, 0)),
     ("wide-bank-64ch", 15.36e6, 64, {}, [1 << 20, 700001], (2, 3, 2)),
 ]
 
@@ -36,7 +37,7 @@ def test_fallback_plans_reached_by_legal_configurations_keep_parity(name, fs, M,
     from sdr_pmr446_amd import chain
     ks = None if M <= 64 else list(range(0, M, M // 16))
     n = sum(splits)
-    x = synth.synth_iq(n, fs, M, channels=ks, dev_hz=1500.0, dc_offset=0.003)
+    x = synth.synth_iq(n, fs, M, channels=ks, dev_hz=500.0 if M <= 8 else 1500.0, dc_offset=0.003)
     g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(splits), **extra)
     got_plan = (g.info(INFO_FE), g.info(INFO_CHAN), g.info(INFO_FIR))
     assert got_plan == plan, "this configuration no longer selects the fallback it is here for: %r" % (got_plan,)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Synchronous host call (pmr_chain_process_block_f32, pinned input, pcm + audio + rssi out) at the reference configuration:
-median latency per block size.  Run once as is and once with PMR_ZEROCOPY=0 (switches are read when the handle is created);
-PMR_ZEROCOPY_MAX=<samples> moves the size limit of the in-place path."""
+median latency per block size.  Run once as is and once with PMR_ZEROCOPY=0 (switches are read when the handle is created); blocks
+above 2^18 samples always go through the copy engines."""
 import os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,7 +13,7 @@ g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(sizes))
 S = g.max_frames
 pcm = np.zeros((M, S), np.int16); audio = np.zeros((M, S), np.float32); rssi = np.zeros(M, np.float32); ns = C.c_uint(0)
 pin = g.pinned_array(max(sizes)); pin[:] = x
-print("PMR_ZEROCOPY=%s PMR_ZEROCOPY_MAX=%s" % (os.environ.get("PMR_ZEROCOPY", "(default on)"), os.environ.get("PMR_ZEROCOPY_MAX", "(default 2^18)")))
+print("PMR_ZEROCOPY=%s" % os.environ.get("PMR_ZEROCOPY", "(default on)"))
 for n in sizes:
     def call():
         rc = g._L.pmr_chain_process_block_f32(g.h, pin.ctypes.data, n, pcm.ctypes.data, audio.ctypes.data, S, C.byref(ns), None, rssi.ctypes.data)
