@@ -288,13 +288,15 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
     prof = ch.profile()
     # the reference's own semantics (src/sdr_pmr446.c:876-877): one squelch-selected channel demodulated to audio
     from sdr_pmr446_amd import synth as _synth
-    one = _synth.signal_channels(M, fs)[0]
-    ch.set_channel_mask([one])
-    for _ in range(args.warmup):
-        step()
-    ch.synchronize()
-    dts1 = [multigpu.timed_region(run, dist, device_sync, sync_dev)[0] for _ in range(5)]
-    ch.set_channel_mask(None)
+    dts1 = []
+    if not args.no_one_open:
+        one = _synth.signal_channels(M, fs)[0]
+        ch.set_channel_mask([one])
+        for _ in range(args.warmup):
+            step()
+        ch.synchronize()
+        dts1 = [multigpu.timed_region(run, dist, device_sync, sync_dev)[0] for _ in range(5)]
+        ch.set_channel_mask(None)
 
     rec = None
     if rank == 0:
@@ -343,7 +345,7 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
                        "channels_demodulated": M,
                        "hbm_frac_of_peak_whole_chain": value * 1e6 * b_alg / 1e9 / world / HBM_PEAK_GBPS},
             "roofline": roof,
-            "one_open_channel": {"value": multigpu.aggregate_throughput(world, args.steps, block, statistics.median(dts1)) / 1e6,
+            "one_open_channel": None if not dts1 else {"value": multigpu.aggregate_throughput(world, args.steps, block, statistics.median(dts1)) / 1e6,
                                  "ms_per_step": statistics.median(dts1) / args.steps * 1e3, "open_channels": 1, "regions": len(dts1),
                                  "note": "reference semantics (src/sdr_pmr446.c:876-877): channelizer + discriminator for all %d "
                                          "channels, audio FIR / PCM for the one open channel (pmr_chain_set_channel_mask)" % M},
@@ -440,6 +442,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=4, help="distinct device-resident blocks the timed steps rotate through (a power "
                     "of two; 1 = one block re-read every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-open", action="store_true", help="skip the one-open-channel leg (profile runs: one kernel mix per trace)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs (falls back to gloo, and says so, if the "
                                                           "RCCL group does not come up); gloo lets two ranks share one GPU to "
                                                           "exercise the N > 1 code path on a 1-GPU box")
