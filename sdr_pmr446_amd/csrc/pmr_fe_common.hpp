@@ -26,7 +26,12 @@ static __device__ __forceinline__ cf cfma(float h, cf x, cf acc) { return __buil
 template <int CTRL, int ROW_MASK = 0xF>
 static __device__ __forceinline__ float dpp0(float src)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
+    // all rows enabled: bound_ctrl:1 makes the lanes without a source read 0 by themselves -- ONE v_mov_b32_dpp instead of a v_mov
+    // that zeroes the destination first plus the DPP move (the dc scan and the half-band halo are 34 such moves per thread and tile)
+    if constexpr (ROW_MASK == 0xF)
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), CTRL, 0xF, 0xF, true));
+    else
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, false));
 }
 template <int CTRL, int ROW_MASK = 0xF>
 static __device__ __forceinline__ cf dpp0c(cf v) { return cf{dpp0<CTRL, ROW_MASK>(v.x), dpp0<CTRL, ROW_MASK>(v.y)}; }
