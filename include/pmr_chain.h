@@ -55,8 +55,9 @@ enum {
     PMR_OK = 0,
     PMR_EINVAL = 1,      /* bad argument / configuration                  */
     PMR_ERANGE = 2,      /* n_in > max_block, or stride < frames produced */
-    PMR_EHIP = 3,        /* a HIP runtime call or kernel launch failed.  Inside a block this leaves the stream position undefined:
-                            the handle then refuses further blocks (PMR_EHIP) until pmr_chain_reset */
+    PMR_EHIP = 3,        /* a HIP runtime call or kernel launch failed.  ANY failure inside a block (after the plan checks, which
+                            return PMR_EINVAL / PMR_ERANGE with nothing advanced) leaves the stream position undefined: the handle
+                            then refuses further blocks (PMR_EHIP) until pmr_chain_reset */
     PMR_ENOMEM = 4
 };
 

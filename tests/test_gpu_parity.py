@@ -149,6 +149,36 @@ def test_errors_do_not_abort():
     assert out["n_frames"] == 0
 
 
+def test_capacity_errors_come_before_any_state_advances_and_leave_the_handle_usable():
+    """Argument / capacity errors are decided on the closed-form plan: an unknown sample format, a stride shorter than
+    the frames the block yields, and a CTCSS plan with more Goertzel blocks per call than the detector strings together are refused
+    with PMR_EINVAL / PMR_ERANGE -- not by a launch that fails mid-block -- and the stream continues as if the call had not been made."""
+    import ctypes as C
+    from sdr_pmr446_amd import chain
+    fs, M, n = 2.4e6, 16, 100000
+    x = synth.synth_iq(2 * n, fs, M, dev_hz=500.0)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n)
+    ref = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n)
+    a0 = g.process_block(x[:n])["pcm"]
+    S = g.max_frames
+    pcm = np.zeros((M, S), np.int16); ns = C.c_uint(0)
+    L = g._L
+    assert L.pmr_chain_process_block_fmt(g.h, x[n:].ctypes.data, 7, n, pcm.ctypes.data, None, S, C.byref(ns), None, None) == 1      # PMR_EINVAL
+    assert L.pmr_chain_process_block_fmt(g.h, x[n:].ctypes.data, 0, n, pcm.ctypes.data, None, 10, C.byref(ns), None, None) == 2     # PMR_ERANGE: stride
+    assert ns.value > 10                                                   # ... and it says how many frames the block would yield
+    assert L.pmr_chain_process_block_fmt(g.h, x[n:].ctypes.data, 0, n + 1, pcm.ctypes.data, None, S, C.byref(ns), None, None) == 2  # > max_block
+    a1 = g.process_block(x[n:])["pcm"]                                      # the stream position is where it was
+    b0 = ref.process_block(x[:n])["pcm"]; b1 = ref.process_block(x[n:])["pcm"]
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1)
+    g.close(); ref.close()
+    big = chain.PmrChain(fs_in=fs, num_channels=M, max_block=1 << 28)      # 1.4 M frames per call = 573 Goertzel blocks > 384
+    with pytest.raises(chain.PmrError, match="rc=2"):
+        big.ctcss_enable(True)
+    out = big.process_block(x[:n])                                          # the handle is still usable, detector off
+    assert out["n_frames"] > 500
+    big.close()
+
+
 def test_full_size_split_invariance_and_known_answer():
     """BASELINE-size block (2^24 samples, cfg2) generated in HBM: (a) one call vs 16 calls agree within 1 LSB,
     (b) the FM tone of every 'fm' channel has the analytic discriminator amplitude."""
