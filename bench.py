@@ -40,8 +40,9 @@ WORKLOADS = {
 HEADLINE = "cfg5"
 EVENT_EVERY = 8        # timed region: at least every 8th front-end launch carries start/stop events (fewer when that still gives ~24 samples)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-KERNEL_SYMBOLS = ("slot k_frontend = k_frontend_fast<MODE,N3,TAIL> (specialised cascades; MODE 1 = level 1 of the two-level "
-                  "front end) or k_frontend<NT,SPT,MODE> in a rocprofv3 trace; k_fir_tm<hp> = k_fir_fft<4, DUAL> (large blocks) / k_fir_mfma4<...>")
+KERNEL_SYMBOLS = ("profile slots name the kernels as a rocprofv3 trace does: k_fe_fast<MODE,N3,TAIL> = the specialised front end (MODE 1 = level 1 "
+                  "of the two-level form; k_frontend<NT,SPT,MODE> for cascades it does not cover); audio FIR <hp> = k_fir_fft<4, DUAL> on "
+                  "large blocks, k_fir_mfma4<...> otherwise")
 
 
 def _oracle_loop(fs, M, block_host, seconds_target, only_channel=-1):

@@ -34,10 +34,11 @@ typedef struct { float re, im; } cfl;
 enum { K_DC_AGG, K_DC_SCAN, K_DC_APPLY, K_HALFBAND, K_ARB, K_CHANNELIZE, K_RSSI, K_FIR_HP, K_FIR_DE, K_FIR_LP,
        K_FE, K_FE_TILES, K_CHANNELIZE_SMALL, K_FE_L2, K_CT_FIR, K_CT_DC, K_CT_GOERTZEL, K_FE_TILEFIX, K_SPGRAM, K_COUNT };
 static const char *k_names[K_COUNT] = { "k_dcblock<agg>", "k_dc_scan", "k_dcblock<apply>", "k_halfband", "k_arb",
-                                        "k_channelize", "k_rssi_finish", "k_fir_tm<hp>", "k_fir_tm<deemph>",
-                                        "k_fir_tm<lp>", "k_frontend", "k_fe_carry",
-                                        "k_channelize_small", "k_frontend<level2>", "k_fir_tm<ctcss_lp>",
-                                        "k_ct_dc_* (unused)", "k_ct_seg_agg+scan, k_ct_goertzel+final", "k_fe_tilefix", "k_spgram+finish" };
+                                        "k_channelize (fused256 / pfb_wide + fft_disc / generic)", "k_rssi_finish",
+                                        "audio FIR <hp> (k_fir_fft / k_fir_mfma4 / k_fir_pair)", "audio FIR <deemph>",
+                                        "audio FIR <lp>", "k_fe_fast (k_frontend)", "k_fe_carry",
+                                        "k_channelize_win", "k_fe_level2", "audio FIR <ctcss_lp>",
+                                        "(unused)", "k_ct_seg_agg + scan + goertzel + final", "k_fe_carry_tail / k_fe_tilefix", "k_spgram + finish" };
 
 #define ZC_MAX_IN  (1u << 18)            /* zero-copy synchronous calls: samples (above this a copy engine + HBM-speed kernels win) */
 #define ZC_MAX_OUT (1u << 20)            /* ... and bytes of [rssi | pcm | audio] */
