@@ -35,6 +35,7 @@ def gpu_required():
 # f4 (ingest / egress / waterfall); fallback kernels and the soak last.  First matching pattern wins; ties keep file order.
 _ORDER = [
     ("test_golden.py::test_hip_matches_golden", 0),
+    ("test_golden.py::test_hip_rssi", 20),                      # f1
     ("test_gpu_fullbank.py::test_every_channel_loaded", 1),
     ("test_gpu_pipelined.py::test_bench_path_unsynchronised_full_size_blocks", 2),
     ("test_gpu_carry.py::test_carry_at_load_equals_in_place_and_oracle", 3),

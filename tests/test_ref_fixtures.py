@@ -4,10 +4,11 @@ exists; only the resulting data is committed):
   tests/golden/ctcss_ref.npz   the CTCSS detector -- src/sdr_pmr446.c:338-409 (ctcss_detector_reset / _create / _analyze) and its
                                struct include/sdr_pmr446.h:42-52, cut out of the reference and compiled with gcc -- run on the
                                detector inputs of a tone-level sweep that straddles both decision thresholds (:403-404);
-  tests/golden/deemph_ref.npz  standard_deemph() of scripts/filter_des.py:31-44, imported and evaluated.
+  tests/golden/deemph_ref.npz  standard_deemph() of scripts/filter_des.py:31-44, imported and evaluated;
+  tests/golden/rssi_ref.npz    average_power() -- src/sdr_pmr446.c:330-336, cut out and compiled -- on channelizer output rows.
 
-They pin the two pieces of the oracle that are not restatements of liquid-dsp: orc_chain.c's detector (the thing the GPU
-detector is compared with) and the de-emphasis coefficients."""
+They pin the pieces of the oracle that are not restatements of liquid-dsp: orc_chain.c's detector (the thing the GPU detector is
+compared with), the de-emphasis coefficients and the RSSI arithmetic (what the GPU's rssi_db is compared with)."""
 import ctypes as C
 import os
 
@@ -100,3 +101,30 @@ def test_deemphasis_coefficients_are_the_design_scripts():
     de = np.zeros(n, dtype=np.float32)
     chain.load().pmr_cfg_design(C.byref(cfg), chain.DESIGN_DEEMPH, 0, de.ctypes.data, n)
     assert n == 3 and np.array_equal(de, np.array([b[0] / a[0], b[1] / a[0], a[1] / a[0]], dtype=np.float32))
+
+
+def test_oracle_rssi_equals_the_references_average_power_bit_for_bit():
+    """tests/golden/rssi_ref.npz: average_power() (src/sdr_pmr446.c:330-336, cut out of the reference and compiled) on the channelizer
+    output rows of a synthetic block -- the numbers find_max_rssi_channel (:668-700) compares.  The oracle chain, run on the same IQ,
+    must return the same tap-off and the same 16 dB values bit for bit; the reference's max - mean selection on them is what
+    oracle/squelch.py and the product's pmr_find_max_rssi_channel compute."""
+    from oracle import squelch as orc_sq
+    from sdr_pmr446_amd import chain, synth
+    g = np.load(os.path.join(GOLD, "rssi_ref.npz"))
+    fs, M, n = float(g["synth_fs"]), int(g["synth_M"]), int(g["synth_n"])
+    x = synth.synth_iq(n, fs, M, dev_hz=float(g["synth_dev_hz"]))
+    o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n)
+    r = o.process_block(x, want=("pcm", "chan", "rssi"))
+    o.close()
+    assert np.array_equal(r["chan"], g["chan"])
+    assert np.array_equal(np.asarray(r["rssi"], dtype=np.float32), g["rssi_db"])
+    ref = g["rssi_db"]
+    # :668-700 on the reference's numbers: max channel and (max - mean of the dB values), all channels enabled
+    want_i = int(np.argmax(ref))
+    want_v = np.float32(ref[want_i] - np.float32(np.float32(ref.sum(dtype=np.float32)) / np.float32(M)))
+    oi, ov = orc_sq.find_max_rssi_channel(ref, (1 << M) - 1)
+    assert oi == want_i and abs(float(ov) - float(want_v)) < 1e-4
+    L = chain.load(build_if_missing=True)
+    mr = C.c_float(0.0)
+    assert L.pmr_find_max_rssi_channel(np.ascontiguousarray(ref).ctypes.data, M, None, 0, C.byref(mr)) == want_i
+    assert abs(mr.value - float(ov)) < 1e-5

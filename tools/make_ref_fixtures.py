@@ -17,7 +17,10 @@ are data).  Two pieces of the hot path's neighbourhood are plain C / Python in t
  (ii) the de-emphasis coefficients (row a8): scripts/filter_des.py:31-44 standard_deemph() is imported (matplotlib on the Agg
       backend, its plots and prints swallowed) and evaluated: tests/golden/deemph_ref.npz {b, a, tau, fs}.
 
-    python3 tools/make_ref_fixtures.py            regenerate both fixtures
+ (iii) average_power (row f1): src/sdr_pmr446.c:330-336 cut out and compiled the same way, run on the channelizer output rows of a
+      synthetic block: tests/golden/rssi_ref.npz {chan, rssi_db}.
+
+    python3 tools/make_ref_fixtures.py            regenerate the fixtures
     python3 tools/make_ref_fixtures.py --build    only compile oracle/_ref/ctcss_ref (what __graft_entry__.build() calls)
 """
 import contextlib
@@ -151,6 +154,66 @@ def make_ctcss_fixture():
           (M, B, int(det[:, 1:].sum()), int((1 - det[:, 1:]).sum()), os.path.getsize(path)))
 
 
+RSSI_DRIVER = r"""
+/* driver (ours): [uint32 rows][uint32 len] then rows x len complex float32 on stdin -> one average_power() per row */
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+int main(void)
+{
+    uint32_t hdr[2];
+    if (fread(hdr, 4, 2, stdin) != 2) return 1;
+    complex float *row = malloc((size_t)hdr[1] * sizeof(*row));
+    for (uint32_t r = 0; r < hdr[0]; ++r) {
+        if (fread(row, sizeof(*row), hdr[1], stdin) != hdr[1]) return 2;
+        printf("%.9g\n", (double)average_power(row, hdr[1]));
+    }
+    return 0;
+}
+"""
+OUT_RSSI = os.path.join(ROOT, "oracle", "_ref", "rssi_ref")
+
+
+def build_rssi_ref():
+    """gcc the reference's average_power (src/sdr_pmr446.c:330-336, cut out at run time) + our driver -> oracle/_ref/rssi_ref"""
+    os.makedirs(os.path.dirname(OUT_RSSI), exist_ok=True)
+    body = _lines(REF_C, 330, 336)
+    assert body.lstrip().startswith("static float average_power") and "log10f" in body
+    src = "#include <complex.h>\n#include <math.h>\n#include <stddef.h>\n" + body + RSSI_DRIVER
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "rssi_ref.c")
+        with open(c, "w") as f:
+            f.write(src)
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-o", OUT_RSSI, c, "-lm"])
+    return OUT_RSSI
+
+
+def make_rssi_fixture():
+    """(iii) average_power (row f1, src/sdr_pmr446.c:330-336) on the channelizer output rows of a synthetic block: the numbers the
+    reference's find_max_rssi_channel (:668-700) compares.  tests/golden/rssi_ref.npz: chan [M][ns] complex64 (the oracle chain's
+    tap-off), rssi_db [M] as the REFERENCE's code computes them, synth parameters (the GPU test regenerates the IQ)."""
+    build_rssi_ref()
+    sys.path.insert(0, ROOT)
+    import oracle
+    from sdr_pmr446_amd import synth
+    fs, M, n = 2.4e6, 16, 100000
+    x = synth.synth_iq(n, fs, M, dev_hz=1500.0)
+    o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n)
+    r = o.process_block(x, want=("pcm", "chan", "rssi"))
+    o.close()
+    chan = np.ascontiguousarray(r["chan"], dtype=np.complex64)
+    hdr = np.array([chan.shape[0], chan.shape[1]], dtype=np.uint32).tobytes()
+    out = subprocess.run([OUT_RSSI], input=hdr + chan.tobytes(), capture_output=True, check=True).stdout
+    rssi = np.array([float(l) for l in out.decode().split()], dtype=np.float32)
+    assert rssi.shape == (M,)
+    path = os.path.join(ROOT, "tests", "golden", "rssi_ref.npz")
+    np.savez_compressed(path, chan=chan, rssi_db=rssi, oracle_rssi_db=np.asarray(r["rssi"], dtype=np.float32),
+                        synth_fs=fs, synth_M=M, synth_n=n, synth_dev_hz=1500.0,
+                        source=np.array("reference src/sdr_pmr446.c:330-336 average_power() compiled by tools/make_ref_fixtures.py"))
+    print("rssi_ref.npz: %d channels x %d frames, rssi %.2f .. %.2f dB, max |oracle - reference| = %.3g dB, %d bytes" %
+          (M, chan.shape[1], rssi.min(), rssi.max(), float(np.abs(rssi - r["rssi"]).max()), os.path.getsize(path)))
+
+
 def make_deemph_fixture():
     import importlib.util
     os.environ["MPLBACKEND"] = "Agg"
@@ -170,6 +233,8 @@ if __name__ == "__main__":
         raise SystemExit("this tool runs in the build container (needs %s)" % REF)
     if "--build" in sys.argv:
         print(build_ctcss_ref())
+        print(build_rssi_ref())
     else:
         make_ctcss_fixture()
         make_deemph_fixture()
+        make_rssi_fixture()
