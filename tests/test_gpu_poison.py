@@ -5,12 +5,15 @@ Round 3's red driver run was `k_ct_goertzel` reading LDS beyond its workgroup's 
 Under the poison mode every such read finds a NaN, on every box.  "The suite is green under poison" only means something if the
 poison really lands, so: (1) a probe kernel that copies its UNINITIALISED LDS out must read the pattern from every workgroup on
 every CU; (2) scratch allocations are 0xFF-filled; (3) the mode changes no result."""
+import os
+
 import numpy as np
 import pytest
 
 from parity_util import CFG2, CFG3
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("PMR_TEST_POISON", "1") == "0", reason="the poison mode was switched off for this run")]
 
 POISON = 0x7FA0DEAD
 
