@@ -84,6 +84,9 @@ template <int NOV>
 static __device__ __forceinline__ pmr_cfv pmr_carry_apply(const pmr_carry_fix &f, const pmr_carry_lds &t, pmr_carry_state &s,
                                                           pmr_cfv x, int dj, unsigned long long dph)
 {
+#ifdef PMR_CARRY_NOOP       /* timing experiment only (tools/variant_bench.sh): what would the chain gain if this cost nothing?  WRONG results */
+    return x;
+#endif
     const unsigned lo = (unsigned)s.ph;
     const int q = (int)__builtin_amdgcn_alignbit((unsigned)(s.ph >> 32), lo, 24);       // low 32 bits of ph >> 24
     int ql = q - s.qb;

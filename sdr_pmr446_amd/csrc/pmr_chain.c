@@ -123,6 +123,7 @@ struct pmr_chain_s {
     int chan_wide;                   /* wide-bank channelizer (pmr_channelize_wide.hip: filter bank + radix-4 FFT kernels) */
     cfl *d_chan_x;                   /* its scratch: polyphase bank outputs [chan_size + 1][M]         */
     int fe_on, fe_nt, fe_spt;        /* fused path selected; threads per tile workgroup, samples per thread */
+    unsigned fe_lds_pad;             /* pmr_fe_params.lds_pad of this plan (chain_init)                */
     int fe_fast_fmt;                 /* the plan's front-end kernel converts int16 / uint8 input as it loads (k_fe_fast, 256 x 16 tiles) */
     int cur_in_fmt;                  /* sample format of THIS call's d_iq (0 cf32): set by the synchronous zero-copy path of slot_submit */
     int fe_T_own, fe_Hh, fe_HhQ, fe_TQ, fe_hcap;
@@ -714,6 +715,12 @@ static int chain_init(pmr_chain q)
     q->chan_wide = !q->chan_small && pmr_channelize_wide_supported(M, p, d->nco_period);
     if (q->chan_wide && (rc = dev_alloc(q, (void **)&q->d_chan_x, ((size_t)q->chan_size + 2) * M * sizeof(cfl)))) return rc;
     q->l2_on_backend = 1;
+    /* 256-channel one-level plans (cfg3, every GPU of cfg4): 6.5 KB of unused LDS per front-end tile -- three 40 KB tiles per CU instead
+     * of four 33.6 KB ones, 40 KB of every CU left to the back end, whose 256-channel bank now takes 56 KB per workgroup (24 frames).
+     * Chain +3.3 / +2.4 / +1.6 % on three boxes (459.7 vs 445.5, 444.8 vs 434.8, 458.2 vs 451.0 GS/s; 5 KB of padding, which still
+     * lets four tiles in, measures the same); alone the kernel is 1.5 % slower.  The same padding COSTS cfg2 2.6 % and cfg5 2.3 %.
+     * profiles/r04_ab_log.txt r4r. */
+    q->fe_lds_pad = (q->fe_on && !q->fe_two && q->chan_wide && M == 256) ? 6656u : 0u;
     q->tf_on_backend = 0;
     q->cal_ok = 0;
     if (q->fe_on && !q->fe_two && q->d_fe_G12 && !q->sw.carry_inplace) {
@@ -1071,7 +1078,7 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     fe_carry_params(q, &t, slot, ntiles, c_end, off_end, pend, cur, nxt);
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
-    p.x = d_iq; p.in_fmt = q->cur_in_fmt;
+    p.x = d_iq; p.in_fmt = q->cur_in_fmt; p.lds_pad = q->fe_lds_pad;
     p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr; p.out_pos0 = q->xr_abs; p.out_mask = q->xr_mask;
     p.probeA = (void *)t.probeA; p.probeB = (void *)t.probeB; p.probeL = (void *)t.probeL; p.probeE = (void *)t.probeE;
     p.tile_j = (void *)t.tile_j;

@@ -27,7 +27,12 @@ typedef float cf __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ cf cfm(float r, float i) { return cf{r, i}; }
 static __device__ __forceinline__ cf cmul(cf a, cf w) { return __builtin_elementwise_fma(cf{a.x, a.x}, w, cf{a.y, a.y} * cf{-w.y, w.x}); }
 
+#ifndef PW_F
 #define PW_F 8          /* frames per (channel, group) work item of the filter bank */
+#endif
+#ifndef PW_FPW1024
+#define PW_FPW1024 2    /* rows of X per k_fft_disc workgroup at M = 1024 (the first is the previous frame, transformed again) */
+#endif
 #define PW_P 26         /* branch taps (2 m, m = 13: reference :437) */
 
 #ifndef PW_MINB
@@ -181,24 +186,31 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
 // FIX: the front end's dc carry is subtracted from the samples as they are loaded (pmr_carry_fix / pmr_carry_load.hpp).  A
 // thread's rows are 256 outputs apart = M * step / 2^24 ~ 307 decimated samples at cfg3, more than one front-end tile (217) and
 // less than two: NOV = 2 compare-and-subtract steps per row.
+// Frames per workgroup (round 4): 24 new frames (+ the previous one) for blocks of thousands of frames, 8 for short ones.  A thread
+// loads, corrects and mixes (G + 26) / G rows per frame: 4.25 at G = 8, 2.1 at G = 24.  Round 3 measured G = 16 10 % faster ALONE
+// and 4 % slower IN THE CHAIN (its 35 KB of LDS beside the direct audio FIR's 36 KB); with the FFT form of the FIR (8.7 KB) the
+// balance turned: cfg3 chain 430.8 / 431.7 (G = 8), 436.0 / 436.7 (12), 441.4 / 441.1 (16), 440.8 / 440.7 (20), 445.1 / 446.8 GS/s (24)
+// on one box (profiles/r04_ab_log.txt r4q).  Beyond 24 the accumulators no longer fit 128 VGPRs (spills).  RB = rows per load
+// batch (two batches in flight): sized so that nothing spills.
 #ifndef PF_G
-#define PF_G 8              /* new frames per workgroup.  16 is 10 % faster ALONE (0.031 vs 0.0345 ms at cfg3: 2.6 instead of 4.25 loads per
-                               sample) and 4 % slower IN THE CHAIN (380 vs 397 GS/s: 35 KB of LDS no longer fit beside four front-end tiles, the
-                               back-end stream becomes the critical one); 12: 391, 6: 391, 4: 367 (tools/variant_bench.sh, round 3) */
+#define PF_G 24
 #endif
 #ifndef PF_RB
-#define PF_RB 9             /* rows per load batch (two batches in flight) */
+#define PF_RB 3
 #endif
-template <bool FIX>
+#define PF_G_SMALL 8        /* blocks of < PF_SMALL_NS frames (the synchronous small-block calls): more, shorter workgroups */
+#define PF_RB_SMALL 9
+#define PF_SMALL_NS 2048u
+template <bool FIX, int G, int RBATCH>
 __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params q)
 {
-    constexpr int M = 256, NF = PF_G + 1, NROW = NF + PW_P - 1;             // frames per workgroup (first = previous); input rows
+    constexpr int M = 256, NF = G + 1, NROW = NF + PW_P - 1;                // frames per workgroup (first = previous); input rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *A = reinterpret_cast<cf *>(smem), *tw = A + NF * M;                 // [NF][M], [M/2]
     const int tid = threadIdx.x;
     const unsigned ns = q.ns;
     const unsigned wg = pmr_xcd_contiguous(blockIdx.x, gridDim.x);
-    const unsigned R0 = wg * PF_G;                                          // row R0 <-> frame frame0 - 1 + R0 (the previous frame)
+    const unsigned R0 = wg * G;                                             // row R0 <-> frame frame0 - 1 + R0 (the previous frame)
     if (tid < M / 2) tw[tid] = ((const cf *)q.fft_tw)[tid];
     pmr_carry_lds ct;
     if constexpr (FIX) {
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
         // rows in batches of RB, SOFTWARE-PIPELINED: batch b + 1 is requested before batch b is consumed, so only the first batch's
         // L2 / HBM latency is exposed (round 3 loaded, waited and computed batch by batch).  Measured neutral (26 us alone either
         // way, profiles/r04_ab_log.txt r4g: the bank phase is 19.5 of the kernel's 26 us, 6.6 of them the carry arithmetic)
-        constexpr int RB = PF_RB, NBATCH = (NROW + RB - 1) / RB;
+        constexpr int RB = RBATCH, NBATCH = (NROW + RB - 1) / RB;
         cf xq[2][RB];
         const auto request = [&](int b, cf (&dst)[RB]) {
 #pragma unroll
@@ -297,13 +309,13 @@ __global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params 
     }
     // ---- discriminator, tap-off, RSSI partial sums (k_fft_disc's epilogue) ----
     cf *__restrict__ chan_out = (cf *)q.chan_out;
-    const unsigned nnew = R0 >= ns ? 0u : min((unsigned)PF_G, ns - R0);
+    const unsigned nnew = R0 >= ns ? 0u : min((unsigned)G, ns - R0);
     {
         // thread = channel: the frame before is the previous iteration's `cu`; fixed trip count, so the eight arg() chains interleave
         const unsigned k = (unsigned)tid;
         cf pv = A[k];
 #pragma unroll
-        for (unsigned f = 0; f < (unsigned)PF_G; f++) {
+        for (unsigned f = 0; f < (unsigned)G; f++) {
             const cf cu = A[(f + 1) * M + k];
             if (f < nnew) {
                 const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
@@ -353,12 +365,19 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
     if (!p->ns) return 0;
     hipStream_t st = (hipStream_t)s;
     if (p->M == 256) {
-        const unsigned ntiles = (p->ns + PF_G - 1) / PF_G;
+        const bool small = p->ns < PF_SMALL_NS;
+        const unsigned G = small ? PF_G_SMALL : PF_G;
+        const unsigned ntiles = (p->ns + G - 1) / G;
         if (ntiles_out) *ntiles_out = ntiles;
         const bool fix = p->fix.V != nullptr;
-        const size_t lds = ((size_t)(PF_G + 1) * 256 + 128) * sizeof(cf) + (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
-        if (fix) PMR_KLAUNCH(k_channelize_fused256<true>, dim3(ntiles), dim3(256), lds, st, *p);
-        else PMR_KLAUNCH(k_channelize_fused256<false>, dim3(ntiles), dim3(256), lds, st, *p);
+        const size_t lds = ((size_t)(G + 1) * 256 + 128) * sizeof(cf) + (fix ? pmr_carry_lds_floats(p->fix) * sizeof(float) : 0);
+        if (small) {
+            if (fix) PMR_KLAUNCH((k_channelize_fused256<true, PF_G_SMALL, PF_RB_SMALL>), dim3(ntiles), dim3(256), lds, st, *p);
+            else PMR_KLAUNCH((k_channelize_fused256<false, PF_G_SMALL, PF_RB_SMALL>), dim3(ntiles), dim3(256), lds, st, *p);
+        } else {
+            if (fix) PMR_KLAUNCH((k_channelize_fused256<true, PF_G, PF_RB>), dim3(ntiles), dim3(256), lds, st, *p);
+            else PMR_KLAUNCH((k_channelize_fused256<false, PF_G, PF_RB>), dim3(ntiles), dim3(256), lds, st, *p);
+        }
         return (int)hipGetLastError();
     }
     if (p->fix.V) return (int)hipErrorInvalidValue;            /* the two-kernel form expects corrected samples */
@@ -371,7 +390,7 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
     if (rc) return rc;
     switch (p->M) {
     case 64:   return launch_fft_disc<64, 32>(st, p, (const cf *)x_scratch, ntiles_out);
-    case 1024: return launch_fft_disc<1024, 2>(st, p, (const cf *)x_scratch, ntiles_out);   /* (three rows per workgroup -- 25 % fewer
+    case 1024: return launch_fft_disc<1024, PW_FPW1024>(st, p, (const cf *)x_scratch, ntiles_out);   /* (three rows per workgroup -- 25 % fewer
                   transforms, half the workgroups -- measured neutral at cfg5, round 3) */
     case 4096: return launch_fft_disc<4096, 2>(st, p, (const cf *)x_scratch, ntiles_out);
     }
@@ -391,6 +410,6 @@ extern "C" int pmr_channelize_carry_at_load(unsigned M, unsigned p, unsigned nco
 extern "C" unsigned pmr_channelize_carry_nv(unsigned M, unsigned adv_q, unsigned TQ)
 {
     /* frames a workgroup stages: M = 16: up to 256 + 25 rows (k_channelize_win: 240 + 25); M = 256: 9 + 25 rows */
-    const unsigned rows = M == 16 ? 256u + 26u : (unsigned)(PF_G + 1 + PW_P);
+    const unsigned rows = M == 16 ? 256u + 26u : (unsigned)((PF_G > PF_G_SMALL ? PF_G : PF_G_SMALL) + 1 + PW_P);
     return (rows * adv_q) / TQ + 3u;
 }

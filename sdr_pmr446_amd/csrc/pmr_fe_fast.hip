@@ -46,7 +46,11 @@ __device__ unsigned long long fe_stamps[65536 * 8];
 #define FE_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) fe_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int pmr_debug_fe_stamps(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fe_stamps), bytes, 0, hipMemcpyDeviceToHost); }
 #else
+#if defined(FE_STOP)        /* timing experiment (tools/variant_kstats.sh): the kernel up to phase boundary FE_STOP; WRONG results */
+#define FE_STAMP_AT(i) do { if ((i) == FE_STOP && p.n_in != 0xffffffffu) return; } while (0)
+#else
 #define FE_STAMP_AT(i) do { } while (0)
+#endif
 #endif
 
 // sample b of the caller's block in its own format (pmr_fe_params.in_fmt): the conversions of k_iq_convert (pmr_kernels.hip) /
@@ -410,9 +414,9 @@ template <int MODE, int N3, int TAIL>
 static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
 #ifndef FE_EXTRA_LDS
-#define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup (8192 -> three tiles per CU instead of four) */
+#define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup on top of pmr_fe_params.lds_pad */
 #endif
-    const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS;
+    const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS + (MODE == FE_FULL ? p->lds_pad : 0u);
     auto kern = k_fe_fast<MODE, N3, TAIL>;
     PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p);
     return (int)hipGetLastError();

@@ -193,6 +193,8 @@ int pmr_launch_dsd_hb(pmr_stream_t s, const float *in, uint64_t in_mask, uint64_
 #define PMR_FE_MAX_STAGES 16
 typedef struct {
     const void *x;              /* new block [n_in]: cf32, or the raw integer samples when in_fmt != 0 */
+    unsigned lds_pad;           /* bytes of unused LDS added to every tile workgroup of the specialised kernels: shapes how front-end tiles
+                                   and the back end's workgroups share a CU (pmr_chain.c fe_init: 256-channel plans) */
     int in_fmt;                 /* 0 cf32; 1 interleaved int16 / 32768; 2 interleaved uint8, (x - 127.5) / 127.5 (include/pmr_io.h):
                                    converted as the tile is loaded -- synchronous zero-copy calls on the receiver's own sample format
                                    (k_fe_fast only: pmr_fe_fast_covers; same arithmetic as k_iq_convert)                            */

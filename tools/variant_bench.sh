@@ -2,8 +2,12 @@
 # usage (GPU box): bash tools/variant_bench.sh <workload> "<extra hipcc flags>" ... : rebuild the library with each flag set and bench
 W=$1; shift
 for F in "$@"; do
-  PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" python3 sdr_pmr446_amd/build.py --force > /dev/null 2>&1
   echo "== flags: $F"
+  # (a build that fails must not fall through to the previous flag set's library: round 4 lost four "baselines" to a -DX=1 that
+  #  collided with a variable named X.  Use -DPMR_BASELINE for "no change".)
+  if ! PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" python3 sdr_pmr446_amd/build.py --force > /tmp/variant_build.log 2>&1; then
+    echo "BUILD FAILED for flags: $F"; grep -m3 -E "error" /tmp/variant_build.log; continue
+  fi
   python3 bench.py --workload $W --also none --no-cpu-baseline --regions 5 --parity-blocks 0 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:

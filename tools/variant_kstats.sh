@@ -3,8 +3,12 @@
 # one bench run with blocks NOT pipelined (rocprofv3 kernel trace)
 W=$1; shift
 for F in "$@"; do
-  PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" python3 sdr_pmr446_amd/build.py --force > /dev/null 2>&1
   echo "== flags: $F"
+  # (a build that fails must not fall through to the previous flag set's library: round 4 lost four "baselines" to a -DX=1 that
+  #  collided with a variable named X.  Use -DPMR_BASELINE for "no change".)
+  if ! PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" python3 sdr_pmr446_amd/build.py --force > /tmp/variant_build.log 2>&1; then
+    echo "BUILD FAILED for flags: $F"; grep -m3 -E "error" /tmp/variant_build.log; continue
+  fi
   PMR_OVERLAP=0 bash tools/kstats.sh vk_tmp.txt --workload $W --also none --no-cpu-baseline --regions 2 --parity-blocks 0 --no-kernel-events
   head -6 gpurun_out/vk_tmp.txt
 done
