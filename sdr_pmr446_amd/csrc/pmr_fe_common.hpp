@@ -41,6 +41,23 @@ static __device__ __forceinline__ cf dpp0c(cf v) { return cf{dpp0<CTRL, ROW_MASK
 template <int G> static __device__ __forceinline__ int lidx(int e) { return e + e / G; }
 static __device__ __forceinline__ int lidx_rt(int e, int g_shift) { return e + (e >> g_shift); }
 
+/* experiment hooks (tools/variant_kstats.sh): FE_OUT_AND masks the output ring index (all tiles store into one small window: no
+ * HBM write traffic; WRONG results), FE_OUT_NT makes the 16-byte output stores non-temporal */
+#ifndef FE_OUT_AND
+#define FE_OUT_AND (~0ull)
+#endif
+typedef float fe_f4 __attribute__((ext_vector_type(4)));
+#if defined(FE_OUT_NT)
+#define FE_STORE4(ptr, val) do { const float4 v_ = (val); __builtin_nontemporal_store(fe_f4{v_.x, v_.y, v_.z, v_.w}, reinterpret_cast<fe_f4 *>(ptr)); } while (0)
+#elif defined(FE_OUT_SC)        /* write-through to system scope: nothing of the ring stays dirty in L2 for the end-of-kernel release */
+#define FE_STORE4(ptr, val) do { const float4 v_ = (val); const fe_f4 w_ = {v_.x, v_.y, v_.z, v_.w};                                \
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(ptr), "v"(w_) : "memory"); } while (0)
+#elif defined(FE_OUT_SKIP)      /* everything but the store itself (the condition is never true) */
+#define FE_STORE4(ptr, val) do { if (p.n_in == 0xfffffffeu) *reinterpret_cast<float4 *>(ptr) = (val); } while (0)
+#else
+#define FE_STORE4(ptr, val) (*reinterpret_cast<float4 *>(ptr) = (val))
+#endif
+
 #define FE_PAD 64      /* elements in front of the tile buffer; >= (4*10-2) * (1 + 1/2) */
 
 static constexpr int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -191,18 +208,18 @@ static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, cons
     };
     if (a.pairs && a.j0 + 1 < a.jb) {
         const cf y0 = resamp(a.j0, bk0), y1 = resamp(a.j0 + 1, bk1);
-        *reinterpret_cast<float4 *>(out + ((p.out_pos0 + a.j0) & p.out_mask)) = make_float4(y0.x, y0.y, y1.x, y1.y);
+        FE_STORE4(out + ((p.out_pos0 + a.j0) & (p.out_mask & FE_OUT_AND)), make_float4(y0.x, y0.y, y1.x, y1.y));
     } else if (a.j0 < a.jb) {
-        out[(p.out_pos0 + a.j0) & p.out_mask] = resamp(a.j0, bk0);
+        out[(p.out_pos0 + a.j0) & (p.out_mask & FE_OUT_AND)] = resamp(a.j0, bk0);
     }
     // rare leftovers, taps fetched on the spot: the odd head sample, and anything beyond 2 NT outputs per tile
     if (tid == 0 && a.jh > a.ja && a.ja < a.jb) {
         const unsigned long long ph = (unsigned long long)p.phi0 + a.ja * p.step;
-        out[(p.out_pos0 + a.ja) & p.out_mask] = resamp(a.ja, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
+        out[(p.out_pos0 + a.ja) & (p.out_mask & FE_OUT_AND)] = resamp(a.ja, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
     }
     for (unsigned long long j = (a.pairs ? a.jh + 2ull * NT : a.ja + NT) + tid; j < a.jb; j += NT) {
         const unsigned long long ph = (unsigned long long)p.phi0 + j * p.step;
-        out[(p.out_pos0 + j) & p.out_mask] = resamp(j, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
+        out[(p.out_pos0 + j) & (p.out_mask & FE_OUT_AND)] = resamp(j, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
     }
 }
 
