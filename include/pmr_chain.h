@@ -185,9 +185,7 @@ enum { PMR_INFO_NUM_STAGES = 0, PMR_INFO_M_STAGE = 1, PMR_INFO_ARB_STEP = 2, PMR
                                      2 specialised one-level (k_fe_fast), 3 two levels, specialised, 4 two levels, generic    */,
        PMR_INFO_CHAN_PLAN = 9     /* 0 generic k_channelize, 1 16-channel k_channelize_win, 2 fused 256-channel kernel,
                                      3 wide bank: k_pfb_wide + k_fft_disc                                                    */,
-       PMR_INFO_FIR_PLAN = 10     /* 0 k_fir_pair (VALU), 1 direct MFMA form only, 2 FFT form for large blocks + direct MFMA  */,
-       PMR_INFO_FE_TPW = 11       /* tiles a workgroup of the LAST block's front-end launch walked (k_fe_loop: blocks of thousands of
-                                     tiles); 0 = one tile per workgroup (k_fe_fast / k_frontend)                              */ };
+       PMR_INFO_FIR_PLAN = 10     /* 0 k_fir_pair (VALU), 1 direct MFMA form only, 2 FFT form for large blocks + direct MFMA  */ };
 enum { PMR_DESIGN_HALFBAND = 0, PMR_DESIGN_ARB = 1, PMR_DESIGN_PFB = 2,
        PMR_DESIGN_DEEMPH = 3 /* {b0, b1, a1} of the de-emphasis IIR, normalised by a0 (src/sdr_pmr446.c:462-463) */ };
 unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx);

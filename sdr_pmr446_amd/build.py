@@ -13,7 +13,7 @@ HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_fe_fast.hip", "pmr_ch
                "pmr_dsd_kernels.hip", "pmr_poison.hip"]
 EXTRA_HIP_FLAGS = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
 EXTRA_C_FLAGS = os.environ.get("PMR_CC_FLAGS", "").split()          # experiment builds only (tools/variant_bench.sh)
-HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_internal.h", "pmr_fe_common.hpp", "pmr_fe_phase_b.inc", "pmr_fe_tile.inc", "pmr_carry_load.hpp", os.path.join("..", "..", "include", "pmr_chain.h"),
+HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_internal.h", "pmr_fe_common.hpp", "pmr_carry_load.hpp", os.path.join("..", "..", "include", "pmr_chain.h"),
            os.path.join("..", "..", "include", "pmr_dsd.h"), os.path.join("..", "..", "include", "pmr_io.h"), os.path.join("..", "..", "include", "pmr_mem.h"),
            os.path.join("..", "data", "pmr446_taps.h")]
 

@@ -118,7 +118,6 @@ struct pmr_chain_s {
     unsigned hp_len_raw;             /* length of the un-folded high-pass table (377)                 */
 
     /* fused front end (pmr_frontend.hip): geometry, gain tables, raw history, dc probes */
-    unsigned fe_tpw_last;            /* tiles per workgroup of the last front-end launch (k_fe_loop), 0 = one tile per workgroup */
     pmr_switches sw;                 /* A/B switches, read once from the environment at create */
     int chan_small;                  /* small-M channelizer (pmr_channelize_small.hip) selected       */
     int chan_wide;                   /* wide-bank channelizer (pmr_channelize_wide.hip: filter bank + radix-4 FFT kernels) */
@@ -746,7 +745,6 @@ static void read_switches(pmr_switches *w)
 {
     memset(w, 0, sizeof(*w));
     w->fir_direct = env_is("PMR_FIR", "direct");
-    { const char *e = getenv("PMR_FE_TPW"); w->fe_tiles_per_wg = e ? atoi(e) : -1; }
     w->no_overlap = env_is("PMR_OVERLAP", "0");
     w->carry_inplace = env_is("PMR_CARRY", "inplace");
     w->no_zerocopy = env_is("PMR_ZEROCOPY", "0");
@@ -797,41 +795,11 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
      * serialise (cfg2 276 instead of 381 GS/s as bench.py's second workload) -- they apparently end up on one hardware queue.  With
      * normal / high that does not happen (profiles/r03_stream_priority.txt). */
     const int prio_base = (prio_hi <= 0 && 0 <= prio_lo) ? 0 : prio_lo;
-    int prio_be = prio_base, prio_fe = fe_high ? prio_hi : prio_base;
-#ifdef PMR_EXP_STREAMS
-    /* experiment build (tools/variant_bench.sh, PMR_CC_FLAGS=-DPMR_EXP_STREAMS): CU masks / priorities of the two streams from the
-     * environment.  PMR_X_BE_CUS = k: the back-end stream may use k CUs of every XCD (mask bit i <-> XCD i % 8, CU i / 8:
-     * tools/exp/cumask_probe.hip); PMR_X_FE_COMPL=1: the front-end stream gets the other 32 - k; PMR_X_FE_PRIO / PMR_X_BE_PRIO =
-     * hi | base | lo (a masked stream is created at the normal priority: HIP has no call that takes both). */
-    {
-        const char *e;
-        int be_cus = 0, fe_compl = 0;
-        if ((e = getenv("PMR_X_BE_CUS"))) be_cus = atoi(e);
-        if ((e = getenv("PMR_X_FE_COMPL"))) fe_compl = atoi(e);
-        if ((e = getenv("PMR_X_FE_PRIO"))) prio_fe = !strcmp(e, "hi") ? prio_hi : !strcmp(e, "lo") ? prio_lo : prio_base;
-        if ((e = getenv("PMR_X_BE_PRIO"))) prio_be = !strcmp(e, "hi") ? prio_hi : !strcmp(e, "lo") ? prio_lo : prio_base;
-        if (be_cus > 0 && be_cus < 32) {
-            uint32_t mb[8] = {0}, mf[8] = {0};
-            for (int i = 0; i < 256; i++) {
-                if (i < 8 * be_cus) mb[i / 32] |= 1u << (i % 32);
-                else mf[i / 32] |= 1u << (i % 32);
-            }
-            hipError_t e1 = hipExtStreamCreateWithCUMask(&q->stream, 8, mb);
-            hipError_t e2 = fe_compl ? hipExtStreamCreateWithCUMask(&q->stream_fe, 8, mf)
-                                     : hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_fe);
-            if (e1 != hipSuccess || e2 != hipSuccess) { fprintf(stderr, "PMR_EXP_STREAMS: masked stream creation failed\n"); pmr_design_free(&q->d); free(q); return NULL; }
-            fprintf(stderr, "PMR_EXP_STREAMS: back end on %d CUs per XCD, front end %s, fe prio %d\n", be_cus, fe_compl ? "on the rest" : "everywhere", prio_fe);
-            goto streams_made;
-        }
-    }
-#endif
+    const int prio_be = prio_base, prio_fe = fe_high ? prio_hi : prio_base;
     if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_be) != hipSuccess ||
         hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_fe) != hipSuccess) {
         pmr_design_free(&q->d); free(q); return NULL;
     }
-#ifdef PMR_EXP_STREAMS
-streams_made:
-#endif
     if (hipEventCreateWithFlags(&q->ev_switch, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&q->stream_h2d, hipStreamNonBlocking) != hipSuccess) { pmr_design_free(&q->d); free(q); return NULL; }
     if (hipStreamCreateWithPriority(&q->stream_ct, hipStreamNonBlocking, prio_base) != hipSuccess ||
@@ -1087,18 +1055,6 @@ static uint32_t step_rinv(uint32_t step)
     return r > 0xffffffffull ? 0xffffffffu : (uint32_t)r;
 }
 
-/* Tiles per workgroup of the specialised front end for a launch of `ntiles` tiles: k_fe_loop (pmr_fe_fast.hip) for launches that fill
- * the chip many times over, one tile per workgroup (k_fe_fast) otherwise -- small blocks want every tile on a CU of its own. */
-#define FE_LOOP_MIN_TILES 4096u
-#define FE_TPW_DEFAULT 1u
-static unsigned fe_tiles_per_wg(pmr_chain q, unsigned ntiles)
-{
-    const unsigned tpw = q->sw.fe_tiles_per_wg >= 0 ? (unsigned)q->sw.fe_tiles_per_wg : FE_TPW_DEFAULT;
-    /* the specialised kernels, cf32 input, a cascade that starts with a six-tap stage (pmr_launch_fe_fast) */
-    const int ok = tpw > 1 && q->fe_fast_fmt && q->cur_in_fmt == 0 && q->fe_m[0] == 3 && ntiles >= FE_LOOP_MIN_TILES;
-    return q->fe_tpw_last = ok ? tpw : 0u;
-}
-
 /* front end, fused: one pass over the raw block (pmr_fe_fast.hip / pmr_frontend.hip) */
 static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned *ny_out)
 {
@@ -1123,7 +1079,6 @@ static int frontend_fused(pmr_chain q, const void *d_iq, unsigned n_in, unsigned
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
     p.x = d_iq; p.in_fmt = q->cur_in_fmt; p.lds_pad = q->fe_lds_pad;
-    p.tiles_per_wg = fe_tiles_per_wg(q, ntiles);
     p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt]; p.out = q->d_xr; p.out_pos0 = q->xr_abs; p.out_mask = q->xr_mask;
     p.probeA = (void *)t.probeA; p.probeB = (void *)t.probeB; p.probeL = (void *)t.probeL; p.probeE = (void *)t.probeE;
     p.tile_j = (void *)t.tile_j;
@@ -1200,7 +1155,6 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     pmr_fe_params p;
     memset(&p, 0, sizeof(p));
     p.mode = 1;
-    p.tiles_per_wg = fe_tiles_per_wg(q, ntiles1);
     p.x = d_iq; p.in_fmt = q->cur_in_fmt; p.hist = q->d_fe_hist[cur]; p.new_hist = q->d_fe_hist[nxt];
     p.out = q->d_fe_ring1; p.out_pos0 = A; p.out_mask = q->ring1_mask;
     p.probeA = (void *)t.probeA; p.probeB = (void *)t.probeB; p.probeL = (void *)t.probeL; p.probeE = (void *)t.probeE;
@@ -1652,7 +1606,6 @@ static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_i
 {
     q->cur_single = single;
     q->rssi_job_pending = 0;
-    q->fe_tpw_last = 0;
     if (phase == 1 && !single) return fail(q, PMR_EINVAL, "two-step form is synchronous", hipSuccess);
     if (q->pend_audio) {
         /* a channelized block was never demodulated: filters that carry state of their own through the audio part (CTCSS
@@ -2273,7 +2226,6 @@ unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx)
         return q->fe_fast_fmt && q->fe2_fast ? 3 : 4;
     case PMR_INFO_CHAN_PLAN: return q->chan_small ? 1 : q->chan_wide ? (q->M == 256 ? 2 : 3) : 0;
     case PMR_INFO_FIR_PLAN: return !pmr_fir_mfma4_supported(q->M, q->hp_len) ? 0 : q->fft_ok ? 2 : 1;
-    case PMR_INFO_FE_TPW: return q->fe_tpw_last;
     default: return 0;
     }
 }

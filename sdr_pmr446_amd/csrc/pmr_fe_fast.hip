@@ -33,9 +33,6 @@ enum { FE_FULL = 0, FE_L1 = 1 };
                                level 2's ring reads or non-temporal PCM stores: neutral to slightly worse, not used) */
 #endif
 
-#ifndef FE_LOOP_MINB
-#define FE_LOOP_MINB 4      /* k_fe_loop's register cap: 4 -> <= 128 VGPRs (it takes 102 / 65), 5 -> <= 96 (two values spilled) */
-#endif
 
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
@@ -99,59 +96,242 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
         const int nt_all = gridDim.x, per = nt_all >> 3, main = per << 3;
         if (c < main) c = (c & 7) * per + (c >> 3);
     }
-#include "pmr_fe_tile.inc"
-}
+    const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // block-relative index of tile sample 0
 
-// ---------------------------------------------------------------------------------------------
-// k_fe_loop: the same tile (pmr_fe_tile.inc), several tiles per workgroup (tiles_per_wg: the grid is ntiles / tiles_per_wg workgroups).  Why: a tile's last act is a global store,
-// and a wave cannot retire before its stores are acknowledged -- behind the queue of tile DMAs that saturates the memory path that
-// takes about a microsecond, during which the tile's 33.6 KB of LDS and four wave slots wait for nothing.  Measured (round 4,
-// profiles/r04_ab_log.txt r4u): the level-1 kernel of cfg5 takes 96 us, 78 us with the ONE store instruction of a tile predicated
-// off (and 78 us with all arithmetic removed as well: that is its DMA rate); cfg2's kernel 119 -> 93-99 us.  In a loop the next
-// tile's DMA is requested right behind the stores and both complete under one wait; workgroup launch and retirement are paid
-// once per several tiles.  Same statements as k_fe_fast for every sample: bit-identical (tests/test_gpu_fe_loop.py).
-//   * the tile's parameters are read from the kernel-argument segment again in every trip (the empty asm hides the pointer's
-//     provenance): hoisted out of the loop, the ~100 scalars a tile uses (taps, powers of lambda, geometry) do not fit the scalar
-//     file and end up spilled to vector lanes -- round 2's persistent kernel carried 65 of those.
-// ---------------------------------------------------------------------------------------------
-template <int MODE, int N3, int TAIL>
-__global__ __launch_bounds__(256, FE_LOOP_MINB) void k_fe_loop(const pmr_fe_params p_arg, unsigned ntiles)
-{
-    static_assert(N3 >= 1 || (MODE == FE_FULL && TAIL == 1), "a cascade without six-tap stages is (m = 5, m = 10)");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = 256, SPT = 16, N0 = NT * SPT;
-    constexpr int H = N3 + 2 * TAIL;
-    constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;
-    constexpr int SCR = N3 == 0 ? N0 + N0 / 16 : N0;           // (LDS layout: k_fe_fast)
-    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
-    cf *wagg = buf + SCR;
-    cf *bnd = wagg + NT / 64;                                 // [4][10]
-
-    // trip i of workgroup w takes tile i * gridDim + w': the resident workgroups walk CONSECUTIVE tiles at any moment, like k_fe_fast's
-    // dispatch order (runs of tpw consecutive tiles per workgroup put the concurrent DMAs tpw * 31.5 KB apart -- the same few HBM
-    // channels: 90 -> 97 -> 130 us for tpw = 1, 4, 16 at cfg5); w' = the XCD-contiguous renumbering inside a row
-    int wg = blockIdx.x;
-    {
-        const int per = gridDim.x >> 3, main = per << 3;
-        if (wg < main) wg = (wg & 7) * per + (wg >> 3);
+    // ---- phase A: raw tile -> LDS ----
+    if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
+    const bool fast = p.in_fmt == 0 && b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
+    if (fast) {
+        // wave-instruction i of wave w moves slots s0 .. s0 + 63, s0 = 512 w + 64 i (1 KiB).  fe_swz(s0 + lane) - s0 depends on
+        // the parity of i only ((s0 >> 4) & 7 = 4 (i & 1)), so the source address is a UNIFORM base (scalar registers, immediate
+        // i * 1 KiB) plus one of two per-lane byte offsets, and the LDS base (M0) is scalar too: no per-instruction vector
+        // address arithmetic (it was ~5 VALU per DMA instruction)
+        const int ws = __builtin_amdgcn_readfirstlane(wave);
+        const char *srcw = reinterpret_cast<const char *>(x + b0) + (size_t)ws * (N0 / 8) * 16;
+        float4 *ldsw = reinterpret_cast<float4 *>(buf) + ws * (N0 / 8);
+        const unsigned sw0 = (unsigned)((lane & ~7) | ((lane & 7) ^ ((lane >> 4) & 7))) * 16u;
+        const unsigned sw1 = (unsigned)((lane & ~7) | ((lane & 7) ^ (((lane >> 4) + 4) & 7))) * 16u;
+#pragma unroll
+        for (int i = 0; i < N0 / 2 / NT; i++)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(srcw + i * 1024 + ((i & 1) ? sw1 : sw0)), (lptr_t *)(ldsw + i * 64), 16, 0,
+                                             FE_DMA_AUX);
+    } else if (p.in_fmt == 0) {
+        // edge tiles (history before the block, zeros beyond it, or an unaligned block): plain loads into the same image
+#pragma unroll 4
+        for (int i = tid; i < N0; i += NT) {
+            const long b = b0 + i;
+            cf w = cfm(0.f, 0.f);
+            if (b < 0) { const long hi = (long)p.hcap + b; if (hi >= 0) w = hist[hi]; }
+            else if (b < (long)p.n_in) w = x[b];
+            buf[2 * fe_swz(i >> 1) + (i & 1)] = w;
+        }
+    } else {
+        // integer sample formats, converted on the way in (synchronous zero-copy calls: the block sits in pinned HOST memory, 2 or
+        // 4 bytes per sample cross the link instead of 8).  Four samples per thread and step: one 8- / 16-byte request where the
+        // group lies inside the block and is naturally aligned, else sample by sample
+        const int bps = p.in_fmt == 1 ? 4 : 2;
+#pragma unroll 2
+        for (int i4 = tid; i4 < N0 / 4; i4 += NT) {
+            const int i = 4 * i4;
+            const long b = b0 + i;
+            cf w[4];
+            const char *src = reinterpret_cast<const char *>(p.x) + b * bps;
+            if (b >= 0 && b + 4 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(src) & (uintptr_t)(4 * bps - 1)) == 0)) {
+                if (p.in_fmt == 1) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(src);
+                    const unsigned vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        w[k] = cfm((float)(short)(vv[k] & 0xffffu) * (1.0f / 32768.0f), (float)(short)(vv[k] >> 16) * (1.0f / 32768.0f));
+                } else {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                    const unsigned vv[2] = {v.x, v.y};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const unsigned h2 = (vv[k >> 1] >> (16 * (k & 1))) & 0xffffu;
+                        w[k] = cfm(((float)(h2 & 0xffu) - 127.5f) * (1.0f / 127.5f), ((float)(h2 >> 8) - 127.5f) * (1.0f / 127.5f));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long bk = b + k;
+                    w[k] = cfm(0.f, 0.f);
+                    if (bk < 0) { const long hi = (long)p.hcap + bk; if (hi >= 0) w[k] = hist[hi]; }
+                    else if (bk < (long)p.n_in) w[k] = fe_raw(p.x, bk, p.in_fmt);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) buf[2 * fe_swz((i + k) >> 1) + ((i + k) & 1)] = w[k];
+        }
     }
-    const int c_first = wg, c_step = (int)gridDim.x;
-#pragma nounroll
-    for (int c = c_first; c < (int)ntiles; c += c_step) {
-        const __attribute__((address_space(4))) pmr_fe_params *pk =
-            (const __attribute__((address_space(4))) pmr_fe_params *)__builtin_amdgcn_kernarg_segment_ptr();   // (p_arg is the first argument)
-        asm volatile("" : "+s"(pk));
-        const pmr_fe_params &p = *(const pmr_fe_params *)pk;
-        // ... and so is everything derived from the thread index (LDS addresses of every phase, swizzles, DMA offsets): kept live
-        // across the loop they cost ~50 VGPRs, and the register count decides what shares a SIMD with these waves
-        int tid_ = threadIdx.x;
-        asm volatile("" : "+v"(tid_));
-        const int tid = tid_, lane = tid & 63, wave = tid >> 6;
-        const cf *__restrict__ x = (const cf *)p.x;
-        const cf *__restrict__ hist = (const cf *)p.hist;
-        const float lam = -p.dc_a1;
-        if (c != c_first) __syncthreads();                    // the previous tile's output phase has read its last stage out of this buffer
-#include "pmr_fe_tile.inc"
+
+    // ---- everything that comes from tables, requested while the tile streams in ----
+    const unsigned long long qa = (unsigned long long)c * p.TQ;
+    fe_arb_plan ap;
+    float bk0[14], bk1[14];
+    if constexpr (MODE == FE_FULL) {
+        ap = fe_arb_prepare<NT>(p, qa, tid);
+        if (p.tile_j && tid == 0) { ((unsigned long long *)p.tile_j)[2 * c] = ap.ja; ((unsigned long long *)p.tile_j)[2 * c + 1] = ap.jb; }
+#pragma unroll
+        for (int k = 0; k < 14; k++) { bk0[k] = ap.b0p[k]; bk1[k] = ap.b1p[k]; }
+    }
+    const float lp = p.lam_lane_pow[lane], l15 = p.lam_lane_pow[(lane & 15) + 1], l31 = p.lam_lane_pow[(lane & 31) + 1];
+    __syncthreads();                                       // (the compiler drains the DMA before the barrier)
+    FE_STAMP_AT(1);
+    // (a wave-local wait instead -- each wave's DMA fetches exactly the chunks its own threads read back -- was measured: neutral
+    //  in all three plans, round 3; and a build of this kernel with 101 instead of 88 VGPRs cost the cfg2 chain 10 %: the audio
+    //  FIR's and the channelizer's waves no longer fit beside four of these tiles on a SIMD, so keep an eye on the register count)
+
+    cf xs[SPT];
+    {
+        const float4 *rb = reinterpret_cast<const float4 *>(buf) + 8 * tid;
+        const int sw = (tid >> 1) & 7;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float4 v = rb[j ^ sw];
+            xs[2 * j] = cfm(v.x, v.y); xs[2 * j + 1] = cfm(v.z, v.w);
+        }
+    }
+
+    // ---- phase B: dc blocker (:795) from ZERO state + first (six-tap) stage straight from registers ----
+    {
+        cf yb[SPT];
+        cf v = cfm(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < SPT; j++) v = cfma(lam, v, xs[j]);             // v0 = x - a1 v1
+        // inclusive decayed scan across the wave (DPP): inc_l = sum_{s<=l} lambda^(SPT (l-s)) agg_s
+        v = cfma(p.lam_pow16[0], dpp0c<0x111>(v), v);                      // row_shr:1
+        v = cfma(p.lam_pow16[1], dpp0c<0x112>(v), v);                      // row_shr:2
+        v = cfma(p.lam_pow16[2], dpp0c<0x114>(v), v);                      // row_shr:4
+        v = cfma(p.lam_pow16[3], dpp0c<0x118>(v), v);                      // row_shr:8
+        v = cfma(l15, dpp0c<0x142, 0xA>(v), v);                            // row_bcast:15 -> rows 1, 3
+        v = cfma(l31, dpp0c<0x143, 0xC>(v), v);                            // row_bcast:31 -> rows 2, 3
+        if (lane == 63) wagg[wave] = v;
+        const cf ex = dpp0c<0x138>(v);                                     // wave_shr:1 (lane 0 <- 0)
+        __syncthreads();                                                   // also: every thread holds its raw samples
+        // v (local) at the end of the previous wave: Horner over the aggregates of the waves before this one.  Branch-free (the
+        // three reads issued together, each step selected by the wave index): as a loop over `wave` it compiled to an exec-masked
+        // loop with one dependent LDS read per trip -- ~400 cycles for wave 3, which the whole tile waits for at the next barrier
+        cf cw = cfm(0.f, 0.f);
+        {
+            const cf a0 = wagg[0], a1 = wagg[1], a2 = wagg[2];
+            const cf c1 = cfma(p.lam_wave, cw, a0);
+            cw = wave > 0 ? c1 : cw;
+            const cf c2 = cfma(p.lam_wave, cw, a1);
+            cw = wave > 1 ? c2 : cw;
+            const cf c3 = cfma(p.lam_wave, cw, a2);
+            cw = wave > 2 ? c3 : cw;
+        }
+        cf v1 = cfma(lp, cw, ex);
+        // stray probes (block start - 1 in tile 0, block end in the last tile) sit at arbitrary offsets
+        const int pL = (c == 0) ? p.Hh + p.pend - 1 : -1;
+        const int pE = (c == p.c_end) ? p.off_end : -1;
+        const cf v1s = v1;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const cf v0 = cfma(lam, v1, xs[j]);
+            yb[j] = csub(v0, v1);                                          // y = v0 - v1
+            v1 = v0;
+        }
+        if (pL >= 0 || pE >= 0) {
+            // only the block's first and last tile get here (uniform branch): the one thread that owns a stray probe runs its
+            // recurrence again.  Inside the loop above the test was an exec-mask branch per sample -- sixteen taken branches in
+            // the middle of the kernel's longest dependent chain, in every tile
+            if ((pL >= 0 && pL / SPT == tid) || (pE >= 0 && pE / SPT == tid)) {
+                cf u = v1s;
+#pragma unroll
+                for (int j = 0; j < SPT; j++) {
+                    u = cfma(lam, u, xs[j]);
+                    if (SPT * tid + j == pL) ((cf *)p.probeL)[0] = u;
+                    if (SPT * tid + j == pE) ((cf *)p.probeE)[0] = u;
+                }
+            }
+        }
+        if (tid == p.Hh / SPT - 1) ((cf *)p.probeA)[c] = v1;      // local v at tile offset Hh-1
+        if (tid == NT - 1) ((cf *)p.probeB)[c] = v1;              // local v at tile offset N0-1
+        if constexpr (N3 == 0) {
+            // no six-tap stage: dc-blocked samples -> LDS, layout L(16) (the raw tile is dead: every thread holds its samples)
+            cf *o = buf + tid * 17;
+#pragma unroll
+            for (int i = 0; i < SPT; i++) o[i] = yb[i];
+        } else {
+        // halo of stage 0: the previous thread's yb[6..15] (lane 0: previous wave's lane 63, through LDS)
+        cf W[26];
+#pragma unroll
+        for (int i = 0; i < 10; i++) W[i] = dpp0c<0x138>(yb[6 + i]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) W[10 + i] = yb[i];
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) bnd[wave * 10 + i] = yb[6 + i];
+        }
+        __syncthreads();
+        if (lane == 0 && wave > 0) {
+#pragma unroll
+            for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * 10 + i];
+        }
+        // z1[8 tid + q] = W[2q + 5] + sum_j h1[j] W[2q + 2j]   (window offset 0 <-> sample 16 tid - 10)
+        const float scale0 = H == 1 ? p.zeta : 1.0f;
+        cf *o = buf + tid * 9;                             // z1 in layout L(8), region R0 (over the raw tile)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            cf a = cfm(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 6; j++) a = cfma(p.taps_k[j], W[2 * q + 2 * j], a);
+            o[q] = cadd_scale(W[2 * q + 5], a, scale0);
+        }
+    }
+        }
+    __syncthreads();
+    FE_STAMP_AT(2);
+
+    // ---- phase C: remaining stages, ping-pong R0 <-> R1; stage e (execution index) has 2048 >> e outputs ----
+    cf *R0 = buf, *R1 = buf + R1_OFF;
+#define FE_STAGE(E, MM, TOFF) do { constexpr int NOUT = (N0 / 2) >> (E); constexpr int PP = NOUT >= NT ? NOUT / NT : 1;          \
+        hb_stage_pp<PP, MM>(((E) & 1) ? R0 : R1, ((E) & 1) ? R1 : R0, tid, NOUT / PP, p.taps_k + (TOFF),                         \
+                            (E) == H - 1 ? p.zeta : 1.0f); } while (0)
+    // six-tap stages 1 .. N3-1 (taps at 6 e), then the m = 5 and m = 10 stages
+    if constexpr (N3 >= 2) FE_STAGE(1, 3, 6);
+    if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
+    if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
+    if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
+    if constexpr (TAIL && N3 == 0) hb_stage_ip<8, 5>(buf, tid, NT, p.taps_k, 1.0f);            // 2048 outputs, L(16) -> L(8), in place
+    else if constexpr (TAIL) FE_STAGE(N3, 5, 6 * N3);
+    if constexpr (TAIL) FE_STAGE(N3 + 1, 10, 6 * N3 + 10);
+#undef FE_STAGE
+    constexpr int NLAST = (N0 / 2) >> (H - 1);
+    constexpr int PLAST = H == 1 ? 8 : (NLAST >= NT ? NLAST / NT : 1);
+    constexpr int GS = PLAST >= 8 ? 3 : (PLAST == 4 ? 2 : 1);                   // final layout L(1 << GS)
+    const cf *fin = ((H - 1) & 1) ? R1 : R0;                                      // stage e writes R1 when e is odd
+    FE_STAMP_AT(3);
+
+    if constexpr (MODE == FE_L1) {
+        // pairs of adjacent samples per lane through 16-byte stores (8-byte stores run at ~0.6x the rate); pairs start at
+        // even ring positions, so they are aligned and never straddle the ring end
+        cf *__restrict__ out = (cf *)p.out;
+        const int nown = (int)((qa + p.TQ <= p.Q) ? p.TQ : (p.Q > qa ? p.Q - qa : 0));   // samples this tile stores
+        const auto ld = [&](int i) { return fin[(p.HhQ + i) + ((p.HhQ + i) >> GS)]; };
+        const int head = (int)((p.out_pos0 + qa) & 1ull) && nown > 0;
+        if (head && tid == 0) out[(p.out_pos0 + qa) & (p.out_mask & FE_OUT_AND)] = ld(0);
+        const int npair = (nown - head) >> 1;
+        for (int t = tid; t < npair; t += NT) {
+            const int i = head + 2 * t;
+            const cf a = ld(i), b = ld(i + 1);
+            FE_STORE4(out + ((p.out_pos0 + qa + i) & (p.out_mask & FE_OUT_AND)), make_float4(a.x, a.y, b.x, b.y));
+        }
+        if (((nown - head) & 1) && tid == 0) out[(p.out_pos0 + qa + nown - 1) & (p.out_mask & FE_OUT_AND)] = ld(nown - 1);
+    } else {
+        fe_arb_store<NT, GS>(p, ap, qa, fin, bk0, bk1, tid);
+    }
+    FE_STAMP_AT(4);
+    // ---- raw history for the next call (last hcap samples of old history || block), by tile 0 ----
+    if (c == 0 && p.new_hist) {
+        cf *__restrict__ nh = (cf *)p.new_hist;
+        for (int i = tid; i < p.hcap; i += NT) {
+            const long sb = (long)i + (long)p.n_in - (long)p.hcap;      // block-relative index
+            nh[i] = sb < 0 ? hist[(long)i + p.n_in] : fe_raw(p.x, sb, p.in_fmt);
+        }
     }
 }
 
@@ -230,37 +410,15 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
 }
 
 // ---------------------------------------------------------------------------------------------
-#ifndef FE_EXTRA_LDS
-#define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup on top of pmr_fe_params.lds_pad */
-#endif
 template <int MODE, int N3, int TAIL>
 static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
+#ifndef FE_EXTRA_LDS
+#define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup on top of pmr_fe_params.lds_pad */
+#endif
     const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS + (MODE == FE_FULL ? p->lds_pad : 0u);
     auto kern = k_fe_fast<MODE, N3, TAIL>;
-#ifdef FE_ANYORDER      /* experiment: AQL packet without the barrier bit -- this launch's workgroups may start under the previous one's tail */
-    hipExtLaunchKernelGGL(kern, dim3(ntiles), dim3(256), (unsigned)lds, st, ev ? (hipEvent_t)ev->start : nullptr,
-                          ev ? (hipEvent_t)ev->stop : nullptr, hipExtAnyOrderLaunch, *p);
-#else
     PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p);
-#endif
-    return (int)hipGetLastError();
-}
-
-
-template <int MODE, int N3, int TAIL>
-static int launch_loop(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
-{
-    const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS + (MODE == FE_FULL ? p->lds_pad : 0u);
-    /* the grid is a whole number of "rounds" of the 4 x 256 workgroups the chip holds at a time: with any other count the last round
-     * runs on a mostly empty chip (tpw = 16 as ceil(17007 / 16) = 1063 workgroups took 127 us: 1024 workgroups walk 16 tiles, then 39
-     * walk 16 more) */
-    const unsigned slots = 4u * 256u;
-    unsigned rounds = (ntiles + (p->tiles_per_wg * slots) / 2) / (p->tiles_per_wg * slots);
-    if (rounds < 1) rounds = 1;
-    const unsigned nwg = rounds * slots < ntiles ? rounds * slots : ntiles;
-    auto kern = k_fe_loop<MODE, N3, TAIL>;
-    PMR_LAUNCH_EV(kern, dim3(nwg), dim3(256), lds, st, ev, *p, ntiles);
     return (int)hipGetLastError();
 }
 
@@ -290,19 +448,6 @@ extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsign
     hipStream_t st = (hipStream_t)s;
     int n3 = 0, tail = 0;
     if (!p->taps_valid || !fast_pattern(p, &n3, &tail)) return -1;
-    if (p->tiles_per_wg > 1 && p->in_fmt == 0 && n3 >= 1) {    /* blocks of thousands of tiles: a workgroup walks tiles_per_wg of them */
-        if (p->mode == FE_FULL && tail) {
-            if (n3 == 1) return launch_loop<FE_FULL, 1, 1>(st, p, ntiles, ev);
-            if (n3 == 2) return launch_loop<FE_FULL, 2, 1>(st, p, ntiles, ev);
-            if (n3 == 3) return launch_loop<FE_FULL, 3, 1>(st, p, ntiles, ev);
-        }
-        if (p->mode == FE_L1 && !tail) {
-            if (n3 == 2) return launch_loop<FE_L1, 2, 0>(st, p, ntiles, ev);
-            if (n3 == 3) return launch_loop<FE_L1, 3, 0>(st, p, ntiles, ev);
-            if (n3 == 4) return launch_loop<FE_L1, 4, 0>(st, p, ntiles, ev);
-            if (n3 == 5) return launch_loop<FE_L1, 5, 0>(st, p, ntiles, ev);
-        }
-    }
     if (p->mode == FE_FULL && tail) {
         if (n3 == 0) return launch_fast<FE_FULL, 0, 1>(st, p, ntiles, ev);
         if (n3 == 1) return launch_fast<FE_FULL, 1, 1>(st, p, ntiles, ev);

@@ -17,7 +17,6 @@ typedef void *pmr_stream_t;     /* hipStream_t */
 /* Environment switches: read ONCE per handle by pmr_chain_create; nothing on a launch path calls getenv.
  * All zero = the product. */
 typedef struct {
-    int fe_tiles_per_wg;    /* PMR_FE_TPW=<n>: tiles a workgroup of the specialised front end walks on big blocks (k_fe_loop); unset = plan default, 1 = k_fe_fast */
     int fir_direct;         /* PMR_FIR=direct: the direct (MFMA) form of the audio FIR for every block (default: FFT form for large blocks) */
     int no_overlap;         /* PMR_OVERLAP=0: single-stream calls (also pmr_chain_set_overlap)                */
     int no_zerocopy;        /* PMR_ZEROCOPY=0: synchronous host calls always go through the copy engines (H2D / D2H) */
@@ -196,8 +195,6 @@ typedef struct {
     const void *x;              /* new block [n_in]: cf32, or the raw integer samples when in_fmt != 0 */
     unsigned lds_pad;           /* bytes of unused LDS added to every tile workgroup of the specialised kernels: shapes how front-end tiles
                                    and the back end's workgroups share a CU (pmr_chain.c fe_init: 256-channel plans) */
-    unsigned tiles_per_wg;      /* > 1: k_fe_loop, a workgroup walks this many consecutive tiles (blocks of thousands of tiles: a tile's store
-                                   acknowledgement and the workgroup turn-over overlap the next tile's DMA); 0 / 1: one tile per workgroup, k_fe_fast */
     int in_fmt;                 /* 0 cf32; 1 interleaved int16 / 32768; 2 interleaved uint8, (x - 127.5) / 127.5 (include/pmr_io.h):
                                    converted as the tile is loaded -- synchronous zero-copy calls on the receiver's own sample format
                                    (k_fe_fast only: pmr_fe_fast_covers; same arithmetic as k_iq_convert)                            */
