@@ -80,10 +80,13 @@ def init_dist(backend, device=None, nccl_timeout_s=120):
         return Dist(dist, None, "gloo", None)
     ok, note, grp = 1, None, None
     try:
-        grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=nccl_timeout_s))
-        t = torch.ones(1, dtype=torch.float64, device=device)
-        dist.all_reduce(t, group=grp)
-        torch.cuda.synchronize(device)
+        # (RCCL prints its version banner on the C stdout when the first communicator comes up -- rank 0's stdout carries ONE JSON
+        #  line: profiles/r04_bench_2rank_nccl_fallback.json of round 4 had five banner lines in front of it)
+        with _stdout_to_stderr():
+            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=nccl_timeout_s))
+            t = torch.ones(1, dtype=torch.float64, device=device)
+            dist.all_reduce(t, group=grp)
+            torch.cuda.synchronize(device)
         if int(t.item()) != world:
             raise RuntimeError("all_reduce returned %r" % t.item())
     except Exception as e:                                   # reported in the record, never swallowed
