@@ -198,11 +198,14 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
 #ifndef PF_RB
 #define PF_RB 3
 #endif
+#ifndef PF_MINB
+#define PF_MINB 4          /* workgroups per CU the register budget allows for (4 -> <= 128 VGPRs) */
+#endif
 #define PF_G_SMALL 8        /* blocks of < PF_SMALL_NS frames (the synchronous small-block calls): more, shorter workgroups */
 #define PF_RB_SMALL 9
 #define PF_SMALL_NS 2048u
 template <bool FIX, int G, int RBATCH>
-__global__ __launch_bounds__(256, 4) void k_channelize_fused256(pmr_chan_params q)
+__global__ __launch_bounds__(256, PF_MINB) void k_channelize_fused256(pmr_chan_params q)
 {
     constexpr int M = 256, NF = G + 1, NROW = NF + PW_P - 1;                // frames per workgroup (first = previous); input rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -375,6 +378,13 @@ extern "C" int pmr_launch_channelize_wide(pmr_stream_t s, const pmr_chan_params 
             if (fix) PMR_KLAUNCH((k_channelize_fused256<true, PF_G_SMALL, PF_RB_SMALL>), dim3(ntiles), dim3(256), lds, st, *p);
             else PMR_KLAUNCH((k_channelize_fused256<false, PF_G_SMALL, PF_RB_SMALL>), dim3(ntiles), dim3(256), lds, st, *p);
         } else {
+            if (lds > 64 * 1024) {                              /* (more than 30 frames per workgroup) */
+                static pmr_attr_flags attr_set{0};
+                if (pmr_attr_needed(attr_set)) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_channelize_fused256<true, PF_G, PF_RB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_channelize_fused256<false, PF_G, PF_RB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                }
+            }
             if (fix) PMR_KLAUNCH((k_channelize_fused256<true, PF_G, PF_RB>), dim3(ntiles), dim3(256), lds, st, *p);
             else PMR_KLAUNCH((k_channelize_fused256<false, PF_G, PF_RB>), dim3(ntiles), dim3(256), lds, st, *p);
         }
