@@ -14,7 +14,7 @@ typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 4) void k_tile(const char *__restrict__ x, char *__restrict__ out, int chain, int MODE /*run-time: every mode runs the same code*/)
+__global__ __launch_bounds__(256, 4) void k_tile(const char *__restrict__ x, char *__restrict__ out, int chain, int MODE /*run-time: every mode runs the same code*/, unsigned wmask)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int c = blockIdx.x;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 4) void k_tile(const char *__restrict__ x, cha
         __builtin_amdgcn_global_load_lds((gptr_t *)(src + i * 1024 + lane * 16), (lptr_t *)(dst + i * 1024), 16, 0, 2);
     __syncthreads();
     float4 v = reinterpret_cast<float4 *>(smem)[tid];
-    char *o = out + (MODE == 2 ? (size_t)(c & 1) * 2048 : (size_t)c * 2048);
+    char *o = out + (MODE == 2 ? (size_t)(c & wmask) * 2048 : (size_t)c * 2048);       // mode 2: a window of (wmask + 1) x 2 KB
     if (MODE == 3 && tid < 128) reinterpret_cast<float4 *>(o)[tid] = v;
     // dependent chain: ~chain x 8 cycles per wave (a v_fma per step), with a barrier every 64 steps like the cascade's stages
     float a = v.x;
@@ -71,9 +71,14 @@ int main()
                             "scalar stores + s_dcache_wb", "vector store + s_waitcnt vmcnt(0) at the end"};
     for (int chain : {0, 64, 128, 256}) {
         printf("-- dependent ALU chain of %d steps per wave\n", chain);
-#define RUN(M) { double ms = timeit([&] { hipLaunchKernelGGL(k_tile, dim3(ntiles), dim3(256), 33600, 0, x, out, chain, M); }); \
+#define RUN(M) { double ms = timeit([&] { hipLaunchKernelGGL(k_tile, dim3(ntiles), dim3(256), 33600, 0, x, out, chain, M, 1u); }); \
                  printf("   mode %d %-46s %7.4f ms  %6.0f GB/s read\n", M, names[M], ms, bytes / ms / 1e6); }
         RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5)
+    }
+    printf("-- mode 2 by window size (no ALU chain): where does the write stream start to cost?\n");
+    for (unsigned wm : {1u, 127u, 1023u, 2047u, 4095u, 8191u, 16383u}) {
+        double ms = timeit([&] { hipLaunchKernelGGL(k_tile, dim3(ntiles), dim3(256), 33600, 0, x, out, 0, 2, wm); });
+        printf("   window %8.2f MB   %7.4f ms\n", (wm + 1) * 2048 / 1048576.0, ms);
     }
     return 0;
 }
