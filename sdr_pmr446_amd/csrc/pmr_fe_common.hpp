@@ -110,6 +110,23 @@ static __device__ __forceinline__ void hb_stage_pp(const cf *__restrict__ src, c
     __syncthreads();
 }
 
+// a stage with ONE output per thread whose result stays in a register (the level-1 kernel's last stage: its outputs go straight to
+// the ring, no LDS round trip): hb_stage_pp<1, MM>'s window and accumulation order
+template <int MM>
+static __device__ __forceinline__ cf hb_stage_out1(const cf *__restrict__ src, int tid, const float *h1, float scale)
+{
+    constexpr int NE = 2 * MM, G = 2;
+    const cf *w = src + tid * (G + 1);
+    cf we[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) we[i] = w[loff<G>(2 * i - (4 * MM - 2))];
+    const cf wd = w[loff<G>(1 - 2 * MM)];
+    cf a = cfm(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 2 * MM; j++) a = cfma(h1[j], we[j], a);
+    return cadd_scale(wd, a, scale);
+}
+
 // the same stage IN PLACE: read window -> barrier -> write over the input -> barrier.  Two barriers instead of one, half the LDS
 // (a level-2 tile then fits beside four level-1 tiles on a CU).
 template <int P, int MM>

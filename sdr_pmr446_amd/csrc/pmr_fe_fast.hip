@@ -294,7 +294,16 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     // six-tap stages 1 .. N3-1 (taps at 6 e), then the m = 5 and m = 10 stages
     if constexpr (N3 >= 2) FE_STAGE(1, 3, 6);
     if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
-    if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
+    // level 1 with four six-tap stages (cfg5, dsd_in): the last stage has one output per thread -- it stays in a register and goes
+    // straight to the ring (below): one LDS write, one barrier and two LDS reads less at the end of the tile's life
+#ifdef FE_LAST_LDS        /* A/B hook: the last stage through LDS like the others */
+    constexpr bool LAST_IN_REG = false;
+#else
+    constexpr bool LAST_IN_REG = MODE == FE_L1 && N3 == 4;
+#endif
+    cf ylast = cfm(0.f, 0.f);
+    if constexpr (LAST_IN_REG) ylast = hb_stage_out1<3>(R0, tid, p.taps_k + 18, p.zeta);
+    else if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
     if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
     if constexpr (TAIL && N3 == 0) hb_stage_ip<8, 5>(buf, tid, NT, p.taps_k, 1.0f);            // 2048 outputs, L(16) -> L(8), in place
     else if constexpr (TAIL) FE_STAGE(N3, 5, 6 * N3);
@@ -306,7 +315,25 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     const cf *fin = ((H - 1) & 1) ? R1 : R0;                                      // stage e writes R1 when e is odd
     FE_STAMP_AT(3);
 
-    if constexpr (MODE == FE_L1) {
+    if constexpr (LAST_IN_REG) {
+        // thread t holds output t of the last stage; outputs HhQ .. HhQ + nown - 1 are the tile's own.  A lane at an even ring position
+        // stores its sample and its right neighbour's (DPP wave_shl:1) as 16 bytes; lane 63 of a wave, the tile's last sample and the
+        // odd head sample go alone, and so does lane 0 when its left partner sits in the previous wave
+        cf *__restrict__ out = (cf *)p.out;
+        const int nown = (int)((qa + p.TQ <= p.Q) ? p.TQ : (p.Q > qa ? p.Q - qa : 0));   // samples this tile stores
+        const cf ynext = dpp0c<0x130>(ylast);                                            // wave_shl:1 (lane 63 <- 0)
+        const int i = tid - p.HhQ;
+        if (i >= 0 && i < nown) {
+            const unsigned long long r = p.out_pos0 + qa + (unsigned)i;
+            cf *o = out + (r & (p.out_mask & FE_OUT_AND));
+            if (!(r & 1ull)) {
+                if (i + 1 < nown && lane != 63) FE_STORE4(o, make_float4(ylast.x, ylast.y, ynext.x, ynext.y));
+                else *o = ylast;
+            } else if (i == 0 || lane == 0) {
+                *o = ylast;
+            }
+        }
+    } else if constexpr (MODE == FE_L1) {
         // pairs of adjacent samples per lane through 16-byte stores (8-byte stores run at ~0.6x the rate); pairs start at
         // even ring positions, so they are aligned and never straddle the ring end
         cf *__restrict__ out = (cf *)p.out;
