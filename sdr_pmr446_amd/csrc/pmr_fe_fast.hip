@@ -43,7 +43,9 @@ static __device__ __forceinline__ int fe_swz(int g) { return (g & ~7) | ((g & 7)
 #ifdef FE_STAMP
 // diagnostic build (tools/fe_phase_times.py): s_memtime at the phase boundaries of every tile, thread 0 -> fe_stamps[tile][8]
 __device__ unsigned long long fe_stamps[65536 * 8];
-#define FE_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) fe_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FE_STAMP_AT(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) { fe_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();      \
+        if ((i) == 0) fe_stamps[blockIdx.x * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 32) |                 \
+                                                      __builtin_amdgcn_s_getreg(4 | (31 << 11)); /* XCC_ID, HW_ID: which CU ran the tile */ } } while (0)
 extern "C" int pmr_debug_fe_stamps(void *dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(fe_stamps), bytes, 0, hipMemcpyDeviceToHost); }
 #else
 #if defined(FE_STOP)        /* timing experiment (tools/variant_kstats.sh): the kernel up to phase boundary FE_STOP; WRONG results */

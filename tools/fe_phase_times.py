@@ -35,3 +35,23 @@ print("%d tiles" % len(st))
 for i, nm in enumerate(names):
     print("  %-26s mean %7.0f  median %7.0f  p90 %7.0f cycles  (%4.1f %% of the lifetime)" % (nm, ph[:, i].mean(), np.median(ph[:, i]), np.percentile(ph[:, i], 90), 100 * ph[:, i].mean() / life.mean()))
 print("  %-26s mean %7.0f  median %7.0f  p90 %7.0f cycles" % ("tile lifetime", life.mean(), np.median(life), np.percentile(life, 90)))
+
+# ---- slot turn-over: which CU ran each tile (XCC_ID / HW_ID stamped at the start), how many tiles a CU holds over time, and how long a
+# slot stays empty between a tile's last stamp (stores issued) and the start of the next tile on that CU
+hw = st[:, 5]
+cu_key = ((hw >> 32) & 15) * 4096 + ((hw >> 13) & 7) * 256 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15)       # xcc, se, sh, cu
+turn, alive_frac = [], []
+for k in np.unique(cu_key):
+    m = cu_key == k
+    s0, e0 = np.sort(st[m, 0]), np.sort(st[m, 4])
+    if len(s0) < 12:
+        continue
+    # the i-th end frees a slot that the (i + 4)-th start takes (four tiles per CU): greedy pairing in time order
+    for i in range(len(e0) - 4):
+        turn.append(s0[i + 4] - e0[i])
+    span = e0[-1] - s0[0]
+    alive_frac.append((st[m, 4] - st[m, 0]).sum() / max(1, span))
+turn = np.array(turn, np.float64)
+print("  %d CUs; tiles alive per CU (stamped lifetimes / span): mean %.2f" % (len(alive_frac), np.mean(alive_frac)))
+print("  slot turn-over (a tile's last stamp -> start of the tile that takes its slot): mean %.0f  median %.0f  p90 %.0f cycles = %.1f %% of a lifetime"
+      % (turn.mean(), np.median(turn), np.percentile(turn, 90), 100 * turn.mean() / life.mean()))
