@@ -185,8 +185,8 @@ static __device__ __forceinline__ fe_jrange fe_tile_outputs(const pmr_fe_params 
 // rounded up to an even ring position; the odd head sample, if any, is thread 0's extra job): one 16-byte store per thread
 // instead of two 8-byte ones -- only when the tile has more outputs than threads, otherwise one output per thread is the
 // shorter phase.  fe_arb_prefetch requests the polyphase taps (two rows of the bank) long before fe_arb_store uses them.
-struct fe_arb_plan { unsigned long long ja, jb, jh, j0; bool pairs; const float *b0p, *b1p; };
-template <int NT>
+struct fe_arb_plan { unsigned long long ja, jb, jh, j0; bool pairs; int npts; bool head_owned; const float *b0p, *b1p; };
+template <int NT, bool HEAD_LAST = false>
 static __device__ __forceinline__ fe_arb_plan fe_arb_prepare(const pmr_fe_params &p, unsigned long long qa, int tid)
 {
     fe_arb_plan a;
@@ -195,10 +195,16 @@ static __device__ __forceinline__ fe_arb_plan fe_arb_prepare(const pmr_fe_params
     a.pairs = a.jb - a.ja > (unsigned long long)NT;
     a.jh = a.pairs ? a.ja + ((p.out_pos0 + a.ja) & 1ull) : a.ja;
     a.j0 = a.pairs ? a.jh + 2ull * tid : a.ja + tid;
-    const unsigned long long j1 = a.pairs ? a.j0 + 1 : a.jb;
+    a.npts = a.pairs ? (a.j0 + 1 < a.jb ? 2 : (a.j0 < a.jb ? 1 : 0)) : (a.j0 < a.jb ? 1 : 0);
+    // the odd head sample of a pairs tile (half of them have one) belongs to the LAST thread when that thread has no pair of its own
+    // (tiles of up to 2 NT - 2 outputs): its taps are then requested here, long before fe_arb_store -- as thread 0's extra job with
+    // taps fetched on the spot it was a dependent global load at the very end of the tile's life, in every second tile
+    // (HEAD_LAST: the one-level kernels, cfg2 chain +0.4 %; level 2 keeps thread 0's extra job -- there it measured -0.4 % at cfg5, r4ac)
+    a.head_owned = HEAD_LAST && a.pairs && a.jh > a.ja && a.jh + 2ull * (NT - 1) >= a.jb;          // (wave-uniform)
+    if (a.head_owned && tid == NT - 1) { a.j0 = a.ja; a.npts = 1; }
     const unsigned ph0 = p.phi0 + (unsigned)a.j0 * p.step, ph1 = ph0 + p.step;      // low 32 bits are all the bank index needs
-    a.b0p = p.arb_bank + (a.j0 < a.jb ? (ph0 & 0xffffffu) >> 16 : 0u) * 14u;
-    a.b1p = p.arb_bank + (j1 < a.jb ? (ph1 & 0xffffffu) >> 16 : 0u) * 14u;
+    a.b0p = p.arb_bank + (a.npts >= 1 ? (ph0 & 0xffffffu) >> 16 : 0u) * 14u;
+    a.b1p = p.arb_bank + (a.npts >= 2 ? (ph1 & 0xffffffu) >> 16 : 0u) * 14u;
     return a;
 }
 
@@ -223,14 +229,15 @@ static __device__ __forceinline__ void fe_arb_store(const pmr_fe_params &p, cons
         for (int k = 0; k < 14; k++) y = cfma(bk[k], bg[k & (NG - 1)][k + (k >> GS)], y);
         return y;
     };
-    if (a.pairs && a.j0 + 1 < a.jb) {
+    if (a.npts == 2) {
         const cf y0 = resamp(a.j0, bk0), y1 = resamp(a.j0 + 1, bk1);
         FE_STORE4(out + ((p.out_pos0 + a.j0) & (p.out_mask & FE_OUT_AND)), make_float4(y0.x, y0.y, y1.x, y1.y));
-    } else if (a.j0 < a.jb) {
+    } else if (a.npts == 1) {
         out[(p.out_pos0 + a.j0) & (p.out_mask & FE_OUT_AND)] = resamp(a.j0, bk0);
     }
-    // rare leftovers, taps fetched on the spot: the odd head sample, and anything beyond 2 NT outputs per tile
-    if (tid == 0 && a.jh > a.ja && a.ja < a.jb) {
+    // rare leftovers, taps fetched on the spot: the odd head sample of a tile whose last thread is busy, and anything beyond 2 NT
+    // outputs per tile
+    if (tid == 0 && a.jh > a.ja && a.ja < a.jb && !a.head_owned) {
         const unsigned long long ph = (unsigned long long)p.phi0 + a.ja * p.step;
         out[(p.out_pos0 + a.ja) & (p.out_mask & FE_OUT_AND)] = resamp(a.ja, p.arb_bank + ((unsigned)(ph & 0xffffffu) >> 16) * 14u);
     }

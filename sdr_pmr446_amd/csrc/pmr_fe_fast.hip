@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
     fe_arb_plan ap;
     float bk0[14], bk1[14];
     if constexpr (MODE == FE_FULL) {
-        ap = fe_arb_prepare<NT>(p, qa, tid);
+        ap = fe_arb_prepare<NT, true>(p, qa, tid);
         if (p.tile_j && tid == 0) { ((unsigned long long *)p.tile_j)[2 * c] = ap.ja; ((unsigned long long *)p.tile_j)[2 * c + 1] = ap.jb; }
 #pragma unroll
         for (int k = 0; k < 14; k++) { bk0[k] = ap.b0p[k]; bk1[k] = ap.b1p[k]; }

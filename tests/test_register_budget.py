@@ -15,7 +15,8 @@ CSRC = os.path.join(ROOT, "sdr_pmr446_amd", "csrc")
 HIPCC = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
 
 BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, why)
-    ("pmr_fe_fast.hip", r"k_fe_fastILi0E", 88, "one-level front end: four tiles per SIMD + one 160-register back-end wave"),
+    ("pmr_fe_fast.hip", r"k_fe_fastILi0ELi[1-9]E", 88, "one-level front end: four tiles per SIMD + one 160-register back-end wave"),
+    ("pmr_fe_fast.hip", r"k_fe_fastILi0ELi0E", 96, "one-level front end of the reference's own 1.024 MS/s plan (small blocks: its back end is the 64- / 84-register small-block kernels)"),
     ("pmr_fe_fast.hip", r"k_fe_fastILi1E", 64, "level 1 of the two-level front end"),
     ("pmr_fe_fast.hip", r"k_fe_level2", 80, "level 2 runs beside four level-1 tiles"),
     ("pmr_fir_fft.hip", r"k_fir_fftILi4ELb0E", 128, "FFT form of the audio FIR (1024 points): one-wave workgroups, four per SIMD, beside four front-end tiles"),
