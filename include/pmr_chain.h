@@ -65,6 +65,13 @@ void      pmr_chain_default_cfg(pmr_chain_cfg *cfg);       /* the reference's op
 pmr_chain pmr_chain_create(const pmr_chain_cfg *cfg);      /* NULL on failure (incl. no HIP device)      */
 int       pmr_chain_reset(pmr_chain q);                    /* all carried state to zero (stream restart) */
 int       pmr_chain_destroy(pmr_chain q);
+/* Why the last pmr_chain_create of THIS thread returned NULL ("" after a success): no handle exists to ask. */
+const char *pmr_chain_create_error(void);
+/* Restart the stream AT sample index n_raw: all carried state zero, counters (resampler phase, ring / NCO / frame positions, the
+ * CTCSS detector's block grid) as after n_raw zero samples -- the reference's loop never ends (:788) and its counters pass 2^32
+ * within seconds at the larger configurations; pmr_chain_position reports where the stream stands (any pointer may be NULL). */
+int       pmr_chain_seek(pmr_chain q, uint64_t n_raw);
+void      pmr_chain_position(pmr_chain q, uint64_t *n_raw, uint64_t *n_resampled, uint64_t *n_frames);
 unsigned  pmr_chain_max_frames(pmr_chain q);               /* SDR_CHANNEL_BUF_SIZE rule, :730-736        */
 unsigned  pmr_chain_num_channels(pmr_chain q);
 const char *pmr_chain_last_error(pmr_chain q);
@@ -201,7 +208,7 @@ int pmr_chain_debug_read(pmr_chain q, int what, void *host_buf, size_t cap_bytes
  * on bytes it did not write fails on every box.  Results are unchanged by it (tests/conftest.py runs the -m gpu tier under it);
  * costs ~25 us per launch. */
 int pmr_debug_poison(int on);
-/* the checker's checker: n_wg workgroups copy the first `words` (<= 16384) 32-bit words of their UNINITIALISED dynamic LDS to
+/* the checker's checker: n_wg workgroups copy the first `words` (<= 40960: the whole 160 KiB of a CU) 32-bit words of their UNINITIALISED dynamic LDS to
  * d_out[n_wg][words] (device pointer) and the call waits for them; with the poison mode on every word reads 0x7FA0DEAD */
 int pmr_debug_lds_probe(void *d_out, unsigned words, unsigned n_wg);
 

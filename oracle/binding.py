@@ -64,6 +64,8 @@ def lib():
         L.orc_chain_create.argtypes = [C.POINTER(OrcCfg)]
         L.orc_chain_create.restype = C.c_void_p
         L.orc_chain_reset.argtypes = [C.c_void_p]
+        L.orc_chain_seek.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_chain_seek.restype = C.c_int
         L.orc_chain_destroy.argtypes = [C.c_void_p]
         L.orc_chain_reset_channel.argtypes = [C.c_void_p, C.c_uint]
         L.orc_chain_max_frames.argtypes = [C.c_void_p]
@@ -169,6 +171,12 @@ class OracleChain:
 
     def reset(self):
         lib().orc_chain_reset(self.h)
+
+    def seek(self, n_raw):
+        """The state after n_raw zero samples, without running them (orc_chain_seek)."""
+        rc = lib().orc_chain_seek(self.h, int(n_raw))
+        if rc:
+            raise RuntimeError("orc_chain_seek rc=%d" % rc)
 
     def reset_channel(self, k):
         lib().orc_chain_reset_channel(self.h, k)

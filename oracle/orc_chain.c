@@ -208,6 +208,45 @@ int orc_chain_reset(orc_chain *q)
     return 0;
 }
 
+/* TEST HOOK (no counterpart in the reference, whose loop simply runs on, src/sdr_pmr446.c:788): the state after `n_raw` ZERO input
+ * samples, reached without running them.  A linear chain fed zeros stays at zero state (dc blockers, half-band / polyphase / FIR
+ * windows, delay line; freqdem yields arg(0) = 0; the Goertzel sums stay 0 and every completed block reports power 0, leaving
+ * max_power_index where it was: 0), so only the COUNTERS differ from a fresh chain, object by object:
+ *   msresamp_crcf   buffer_index = n_raw mod 2^h (staged zeros);
+ *   resamp_crcf     phase after Q = n_raw >> h pushes: ny outputs while phase <= 0xffffff, minus 2^24 per push (orc_resamp_crcf_execute);
+ *   cbuffercf       the remainder ny mod M (:804: frames of M) holds zeros;
+ *   nco_crcf        one step per sample of every consumed frame (:808-812): theta = frames * M * d_theta mod 2^32;
+ *   ctcss detector  samp_processed = frames mod CTCSS_BLOCK_SIZE (:379-381), per demodulated channel.
+ * tests/test_seek.py checks this against really feeding the zeros. */
+int orc_chain_seek(orc_chain *q, uint64_t n_raw)
+{
+    if (!q) return 1;
+    orc_chain_reset(q);
+    orc_msresamp_crcf *r = q->resampler;
+    const unsigned h = r->num_halfband_stages;
+    const uint64_t Q = n_raw >> h;
+    r->buffer_index = (unsigned)(n_raw & ((1ull << h) - 1ull));
+    memset(r->buffer, 0, (size_t)(4 + (1u << h)) * sizeof(cf32));
+    /* outputs j = 0, 1, ... at phase j * step; push i (0-based) emits those with (i << 24) <= j * step <= (i << 24) + 0xffffff */
+    const unsigned __int128 span = (unsigned __int128)Q << 24;
+    const uint32_t step = r->arbitrary->step;
+    const uint64_t ny = Q ? (uint64_t)((span + step - 1u) / step) : 0;
+    r->arbitrary->phase = (uint32_t)((unsigned __int128)ny * step - span);
+    const uint64_t frames = ny / q->M;
+    const unsigned left = (unsigned)(ny - frames * q->M);
+    if (left) {
+        cf32 *z = (cf32 *)calloc(left, sizeof(cf32));
+        if (!z) return 1;
+        const int rc = orc_cbuffercf_write(q->resamp_ring, z, left);
+        free(z);
+        if (rc) return 2;
+    }
+    q->nco.theta = (uint32_t)(frames * q->M * (uint64_t)q->nco.d_theta);
+    const unsigned blk = q->cfg.ctcss_block ? q->cfg.ctcss_block : 2441;
+    for (unsigned i = 0; i < q->M; i++) q->ch[i].ctcss.samp_processed = (unsigned)(frames % blk);
+    return 0;
+}
+
 /* what the reference does to its single demodulator when the squelch detunes, src/sdr_pmr446.c:866-867 */
 int orc_chain_reset_channel(orc_chain *q, unsigned channel)
 {

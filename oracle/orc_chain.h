@@ -77,6 +77,7 @@ typedef struct {
 void       orc_chain_default_cfg(orc_chain_cfg *cfg);
 orc_chain *orc_chain_create(const orc_chain_cfg *cfg);
 int        orc_chain_reset(orc_chain *q);
+int        orc_chain_seek(orc_chain *q, uint64_t n_raw);               /* test hook: the state after n_raw zero samples */
 unsigned   orc_ctcss_detector_run(const float *xs, unsigned nx, double audio_rate, unsigned block, orc_ctcss_event *ev, unsigned cap,
                                   float *powers /*nullable [cap][38]*/);
 void       orc_deemph_iir_coefs(float b[2], float a[2]);

@@ -62,18 +62,25 @@ def build(force=False, verbose=False):
 
 
 EXAMPLE = os.path.join(HERE, "pmr446_file")
+EXAMPLE_THREADS = os.path.join(HERE, "pmr446_threads")
 
 
-def build_example(verbose=False):
-    """examples/pmr446_file.c: headless file -> WAV / s16 harness, linked against the in-tree library."""
+def _build_c_example(src, exe, extra, verbose):
     root = os.path.dirname(HERE)
     cmd = ["gcc", "-std=gnu11", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(root, "include"),
-           os.path.join(root, "examples", "pmr446_file.c"), "-o", EXAMPLE, "-L" + HERE, "-lpmr446_hip",
-           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
+           os.path.join(root, "examples", src), "-o", exe, "-L" + HERE, "-lpmr446_hip",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ROCM, "lib")] + extra
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return EXAMPLE
+    return exe
+
+
+def build_example(verbose=False):
+    """examples/pmr446_file.c: headless file -> WAV / s16 harness (SURVEY f4), linked against the in-tree library;
+    examples/pmr446_threads.c: one pthread per handle (the deployment model of include/pmr_chain.h), self-checking."""
+    _build_c_example("pmr446_threads.c", EXAMPLE_THREADS, ["-lpthread"], verbose)
+    return _build_c_example("pmr446_file.c", EXAMPLE, [], verbose)
 
 
 if __name__ == "__main__":

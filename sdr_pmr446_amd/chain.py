@@ -18,7 +18,7 @@ DEBUG_RESAMPLED, DEBUG_FM, DEBUG_CTCSS_LP = range(3)
 
 #: every symbol include/pmr_chain.h declares
 ABI_SYMBOLS = [
-    "pmr_chain_default_cfg", "pmr_chain_create", "pmr_chain_reset", "pmr_chain_destroy", "pmr_chain_max_frames",
+    "pmr_chain_default_cfg", "pmr_chain_create", "pmr_chain_create_error", "pmr_chain_seek", "pmr_chain_position", "pmr_chain_reset", "pmr_chain_destroy", "pmr_chain_max_frames",
     "pmr_chain_num_channels", "pmr_chain_last_error", "pmr_chain_process_block", "pmr_chain_process_block_f32", "pmr_chain_process_block_fmt",
     "pmr_chain_process_block_device", "pmr_chain_synchronize", "pmr_chain_set_overlap", "pmr_chain_stream", "pmr_chain_profile_enable",
     "pmr_chain_profile_reset", "pmr_chain_profile_count", "pmr_chain_profile_name", "pmr_chain_profile_get",
@@ -129,6 +129,12 @@ def load(build_if_missing=True):
         getattr(L, name).restype = u
     L.pmr_chain_last_error.argtypes = [vp]
     L.pmr_chain_last_error.restype = C.c_char_p
+    L.pmr_chain_create_error.argtypes = []
+    L.pmr_chain_create_error.restype = C.c_char_p
+    L.pmr_chain_seek.argtypes = [vp, C.c_uint64]
+    L.pmr_chain_seek.restype = i
+    L.pmr_chain_position.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pmr_chain_position.restype = None
     L.pmr_chain_stream.argtypes = [vp]
     L.pmr_chain_stream.restype = vp
     L.pmr_chain_process_block.argtypes = [vp, vp, u, vp, u, C.POINTER(u), vp, vp]
@@ -407,7 +413,7 @@ class PmrChain:
         self._L = L
         self.h = L.pmr_chain_create(C.byref(cfg))
         if not self.h:
-            raise PmrError("pmr_chain_create failed (no HIP device, or invalid configuration)")
+            raise PmrError("pmr_chain_create failed: %s" % (L.pmr_chain_create_error().decode() or "no HIP device, or invalid configuration"))
         self.M = L.pmr_chain_num_channels(self.h)
         self.max_frames = L.pmr_chain_max_frames(self.h)
 
@@ -418,6 +424,16 @@ class PmrChain:
 
     def reset(self):
         self._check(self._L.pmr_chain_reset(self.h))
+
+    def seek(self, n_raw):
+        """pmr_chain_seek: zero state at stream position n_raw (as after n_raw zero samples)."""
+        self._check(self._L.pmr_chain_seek(self.h, int(n_raw)))
+
+    def position(self):
+        """(raw samples consumed, resampled samples produced, frames channelized) since reset / seek."""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._L.pmr_chain_position(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     def close(self):
         if getattr(self, "h", None):

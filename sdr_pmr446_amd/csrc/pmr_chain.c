@@ -75,6 +75,7 @@ struct pmr_chain_s {
      * detector waits for -- behind them on the back-end stream, the next block's carry / channelizer / FIR waited too */
     hipStream_t stream_ct; hipEvent_t ev_ct[PIPE_DEPTH], ev_ctlp; int ct_ev_used[PIPE_DEPTH], ct_async_last; unsigned ct_last_par, cur_par; int cur_single;
     int overlap;                     /* two-stream pipelining enabled (PMR_OVERLAP=0 disables)                     */
+    int fe_prio_high;                /* the front-end stream was created at high priority (two-level plan + FFT form of the audio FIR) */
     uint64_t n_calls;
     unsigned M, res_size, chan_size;
     char err[256];
@@ -271,15 +272,20 @@ static int fir_fft_init(pmr_chain q, const float *g, unsigned n)
  * direct MFMA form and its RSSI rider.  Transform size: 1024 points -- one-wave workgroups with 8.7 KB of LDS that fit beside the
  * front end's tiles.  The 4096-point form does 0.7x the arithmetic (92 % instead of 63 % of a block is output) and is the faster
  * kernel alone at cfg3, but in the chain it measured 4 % slower at cfg2 and equal at cfg3 (profiles/r04_ab_log.txt): it is
- * compiled in and selected from FF_N4096_MIN_NS frames per call on (tools/variant_bench.sh builds; default: never).
+ * compiled in and selected by PMR_FIR=fft4096 only (a run-time switch, read at create: tests/test_gpu_fir_fft.py runs both sizes;
+ * round 4's compile-time threshold lived in this C file, where the tools' -D flags for hipcc never reached it).
  * Returns -1 (direct), 0 (1024 points) or 1 (4096 points). */
-#ifndef FF_N4096_MIN_NS
-#define FF_N4096_MIN_NS 0xffffffffu
-#endif
 static int fir_fft_pick(const struct pmr_chain_s *q, unsigned ns, unsigned nchan)
 {
     if (!q->fft_ok || (unsigned long long)ns * nchan < (1ull << 17)) return -1;
-    return ns >= FF_N4096_MIN_NS ? 1 : 0;
+    const int which = q->sw.fir_fft4096 ? 1 : 0;
+    /* the kernel indexes the discriminator ring and its grid with 32-bit arithmetic (pmr_launch_fir_fft re-checks the same limits):
+     * a plan beyond them takes the direct form HERE, before anything is launched -- a launch-time refusal would come in the middle
+     * of a block and fault the handle on every large block */
+    const unsigned long long N = pmr_fir_fft_size(which), L = N - (q->hp_len - 1u);
+    if ((q->fm_mask + 1ull) * q->M > 0xffffffffull || (unsigned long long)ns + N > 0x7fffffffull) return -1;
+    if (((unsigned long long)ns + L - 1ull) / L * ((nchan + 1ull) / 2ull) > 0x7fffffffull) return -1;
+    return which;
 }
 
 /* ---- profiling helpers: HIP events on the chain's stream around every launch ---- */
@@ -745,6 +751,7 @@ static void read_switches(pmr_switches *w)
 {
     memset(w, 0, sizeof(*w));
     w->fir_direct = env_is("PMR_FIR", "direct");
+    w->fir_fft4096 = env_is("PMR_FIR", "fft4096");
     w->no_overlap = env_is("PMR_OVERLAP", "0");
     w->carry_inplace = env_is("PMR_CARRY", "inplace");
     w->no_zerocopy = env_is("PMR_ZEROCOPY", "0");
@@ -754,72 +761,98 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only);
 pmr_chain pmr_chain_create(const pmr_chain_cfg *cfg) { return chain_create(cfg, 0); }
 pmr_chain pmr_chain_create_frontend(const pmr_chain_cfg *cfg) { return chain_create(cfg, 1); }
 
+static __thread char g_create_err[256];
+static void create_error(const char *what) { snprintf(g_create_err, sizeof(g_create_err), "%s", what); }
+
 static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
 {
-    if (!cfg) return NULL;
+    g_create_err[0] = 0;
+    if (!cfg) { create_error("null configuration"); return NULL; }
     if (cfg->num_channels < 2 && !frontend_only) {
         fprintf(stderr, "pmr_chain_create: invalid configuration\n");
+        create_error("invalid configuration: num_channels < 2");
         return NULL;
     }
     pmr_chain q = (pmr_chain)calloc(1, sizeof(*q));
-    if (!q) return NULL;
+    if (!q) { create_error("out of memory"); return NULL; }
     q->cfg = *cfg;
     read_switches(&q->sw);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         fprintf(stderr, "pmr_chain_create: no HIP device (this library has no CPU path)\n");
+        create_error("no HIP device (this library has no CPU path)");
         free(q); return NULL;
     }
     if (cfg->device >= 0) {
-        if (cfg->device >= ndev || hipSetDevice(cfg->device) != hipSuccess) { free(q); return NULL; }
+        if (cfg->device >= ndev) {
+            snprintf(g_create_err, sizeof(g_create_err), "device ordinal %d does not exist (%d HIP device%s visible)", cfg->device, ndev, ndev == 1 ? "" : "s");
+            free(q); return NULL;
+        }
+        if (hipSetDevice(cfg->device) != hipSuccess) { create_error("hipSetDevice failed"); free(q); return NULL; }
         q->device = cfg->device;
-    } else if (hipGetDevice(&q->device) != hipSuccess) { free(q); return NULL; }
+    } else if (cfg->device != -1) {
+        snprintf(g_create_err, sizeof(g_create_err), "device ordinal %d: -1 (the calling thread's current device) or 0 .. %d", cfg->device, ndev - 1);
+        free(q); return NULL;
+    } else if (hipGetDevice(&q->device) != hipSuccess) { create_error("hipGetDevice failed"); free(q); return NULL; }
     if (cfg->max_block == 0 ||
         pmr_design_build(&q->d, cfg->fs_in, cfg->num_channels, cfg->channel_width_hz, cfg->dcblock_alpha,
                          cfg->resamp_As, cfg->pfb_m, cfg->pfb_As, cfg->fm_kf)) {
         fprintf(stderr, "pmr_chain_create: invalid configuration\n");
+        create_error("invalid configuration");
         pmr_design_free(&q->d); free(q); return NULL;
     }
     q->M = cfg->num_channels;
     pmr_design_buffer_sizes(&q->d, cfg->max_block, &q->res_size, &q->chan_size);
     /* Stream priorities (A/B history: profiles/r03_stream_priority.txt, r03_ab_log.txt r43-r46, r04_ab_log.txt r4d / r4e).  Equal for
      * one-level plans: the back-end stream is critical at cfg2 (front end high: -9 %), cfg3 is indifferent.  Two-level plans put the
-     * FRONT-END stream high (cfg5 +1.5-2 % on three boxes); round 3 had to give that up because the direct audio FIR's 36 KB of LDS
-     * did not fit beside four level-1 tiles and starved (541 -> 495 GS/s in steady state) -- the FFT form's one-wave, 8.7 KB
-     * workgroups do. */
+     * FRONT-END stream high (cfg5 +1.5-2 % on three boxes) -- but only when the audio FIR of large blocks is the FFT form, whose
+     * one-wave, 8.7 KB workgroups fit beside four level-1 tiles: round 3's direct form (36 KB of LDS per workgroup) starved behind a
+     * high-priority front end (541 -> 495 GS/s in steady state, bimodal regions).  Which form runs is only known once chain_init has
+     * made the plan (fe_two really selected, fft_ok: not PMR_FIR=direct, not deemph_fir / lowpass, <= 512 taps), so the front-end
+     * stream is created AFTER it; chain_init itself queues on q->stream only. */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);       /* numerically lower = higher priority */
-    const int fe_high = fe_wants_two_levels(&q->d);
     /* The base priority is NORMAL (0), not the range's least (1 on ROCm 7.2, what rounds 1-2 used for both streams): a process that
      * had held a handle with a high-priority stream and then created a handle with two LEAST-priority streams saw those two
      * serialise (cfg2 276 instead of 381 GS/s as bench.py's second workload) -- they apparently end up on one hardware queue.  With
      * normal / high that does not happen (profiles/r03_stream_priority.txt). */
     const int prio_base = (prio_hi <= 0 && 0 <= prio_lo) ? 0 : prio_lo;
-    const int prio_be = prio_base, prio_fe = fe_high ? prio_hi : prio_base;
-    if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_be) != hipSuccess ||
-        hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, prio_fe) != hipSuccess) {
+    if (hipStreamCreateWithPriority(&q->stream, hipStreamNonBlocking, prio_base) != hipSuccess) {
+        create_error("hipStreamCreateWithPriority failed");
         pmr_design_free(&q->d); free(q); return NULL;
     }
     if (hipEventCreateWithFlags(&q->ev_switch, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&q->stream_h2d, hipStreamNonBlocking) != hipSuccess) { pmr_design_free(&q->d); free(q); return NULL; }
+        hipStreamCreateWithFlags(&q->stream_h2d, hipStreamNonBlocking) != hipSuccess) { create_error("stream / event creation failed"); pmr_chain_destroy(q); return NULL; }
     if (hipStreamCreateWithPriority(&q->stream_ct, hipStreamNonBlocking, prio_base) != hipSuccess ||
-        hipEventCreateWithFlags(&q->ev_ctlp, hipEventDisableTiming) != hipSuccess) { pmr_design_free(&q->d); free(q); return NULL; }
-    q->sfe = q->stream_fe;
+        hipEventCreateWithFlags(&q->ev_ctlp, hipEventDisableTiming) != hipSuccess) { create_error("stream / event creation failed"); pmr_chain_destroy(q); return NULL; }
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
         if (hipEventCreateWithFlags(&q->ev_fe[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q->ev_ct[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&q->ev_be[i], hipEventDisableTiming) != hipSuccess) {
-            pmr_design_free(&q->d); free(q); return NULL;
+            create_error("event creation failed");
+            pmr_chain_destroy(q); return NULL;
         }
     }
     q->overlap = !q->sw.no_overlap;
     if (chain_init(q) != PMR_OK) {
         fprintf(stderr, "pmr_chain_create: %s\n", q->err);
+        create_error(q->err);
         pmr_chain_destroy(q);
         return NULL;
     }
+    q->fe_prio_high = q->fe_on && q->fe_two && q->fft_ok;
+    if (hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, q->fe_prio_high ? prio_hi : prio_base) != hipSuccess) {
+        create_error("hipStreamCreateWithPriority failed");
+        pmr_chain_destroy(q);
+        return NULL;
+    }
+    q->sfe = q->stream_fe;
     return q;
 }
+
+/* Why the last pmr_chain_create / pmr_chain_create_frontend of THIS thread returned NULL ("" after a success): the handle that would
+ * carry pmr_chain_last_error does not exist then. */
+const char *pmr_chain_create_error(void) { return g_create_err; }
 
 int pmr_chain_destroy(pmr_chain q)
 {
@@ -912,6 +945,34 @@ int pmr_chain_reset(pmr_chain q)
     for (unsigned i = 0; i < PIPE_DEPTH; i++) q->slot[i].used = 0;
     HIPCHK(hipStreamSynchronize(q->stream), "reset sync");
     return PMR_OK;
+}
+
+/* Stream position n_raw with every filter state zero -- exactly the state after n_raw ZERO samples (a linear chain fed zeros stays
+ * at zero; the discriminator's arg(0) = 0): reset, then the closed-form counters of plan_core taken over the whole prefix in one
+ * step.  Everything else that depends on the position is derived from them when a block is planned: the front end's pending raw
+ * samples (n_raw mod 2^h), the resampler phase, the ring positions (absolute indices), the NCO phase (xr index mod 2M), the frame
+ * remainder (xr_abs - frames_done M) and the detector's 2441-frame grid (frames_done).  The reference's loop never ends
+ * (src/sdr_pmr446.c:788): at cfg5 n_raw passes 2^32 after 4.3 s -- this is how tests put a handle there without streaming to it. */
+int pmr_chain_seek(pmr_chain q, uint64_t n_raw)
+{
+    if (!q) return PMR_EINVAL;
+    if (n_raw >> 62) return fail(q, PMR_ERANGE, "seek position", hipSuccess);
+    int rc = pmr_chain_reset(q);
+    if (rc) return rc;
+    const unsigned __int128 span = (unsigned __int128)(n_raw >> q->d.num_stages) << 24;
+    const uint64_t ny = (uint64_t)((span + q->d.arb_step - 1u) / q->d.arb_step);      /* phase 0 at the origin: plan_core */
+    q->n_raw = n_raw;
+    q->arb_phase = (uint32_t)((unsigned __int128)ny * q->d.arb_step - span);
+    q->xr_abs = ny;
+    q->frames_done = ny / q->M;
+    return PMR_OK;
+}
+
+void pmr_chain_position(pmr_chain q, uint64_t *n_raw, uint64_t *n_resampled, uint64_t *n_frames)
+{
+    if (n_raw) *n_raw = q ? q->n_raw : 0;
+    if (n_resampled) *n_resampled = q ? q->xr_abs : 0;
+    if (n_frames) *n_frames = q ? q->frames_done : 0;
 }
 
 unsigned pmr_chain_max_frames(pmr_chain q) { return q ? q->chan_size : 0; }
@@ -2099,7 +2160,10 @@ static hipError_t ct_restart_channel(pmr_chain q, unsigned k)
     hipError_t e = hipSuccess;
     for (int b = 0; b < 2 && e == hipSuccess; b++)
         e = hipMemset((char *)q->d_ct_carry[b] + (size_t)k * PMR_CT_TONES * 2 * sizeof(float), 0, (size_t)PMR_CT_TONES * 2 * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(q->d_ct_restart + k, q->frames_done % PMR_CT_BLOCK ? 1 : 0, 1);
+    /* "restarted in mid-block" is relative to where the detector runs NEXT: in the two-step form (channelize -> mask / reset ->
+     * demodulate) frames_done has already advanced past the pending block, whose audio part starts at pend_audio_frame0 */
+    const uint64_t next_frame = q->pend_audio ? (uint64_t)q->pend_audio_frame0 : q->frames_done;
+    if (e == hipSuccess) e = hipMemset(q->d_ct_restart + k, next_frame % PMR_CT_BLOCK ? 1 : 0, 1);
     return e;
 }
 

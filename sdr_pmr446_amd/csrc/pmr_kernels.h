@@ -18,6 +18,8 @@ typedef void *pmr_stream_t;     /* hipStream_t */
  * All zero = the product. */
 typedef struct {
     int fir_direct;         /* PMR_FIR=direct: the direct (MFMA) form of the audio FIR for every block (default: FFT form for large blocks) */
+    int fir_fft4096;        /* PMR_FIR=fft4096: the FFT form's 4096-point kernels (256 threads, 35 / 71 KB of LDS) wherever the FFT form runs
+                               -- the variant that lost its A/B in the chain (r04_ab_log.txt) but is compiled in: tests run it */
     int no_overlap;         /* PMR_OVERLAP=0: single-stream calls (also pmr_chain_set_overlap)                */
     int no_zerocopy;        /* PMR_ZEROCOPY=0: synchronous host calls always go through the copy engines (H2D / D2H) */
     int carry_inplace;      /* PMR_CARRY=inplace: one-level front end's dc carry by the read-modify-write pass over the whole block

@@ -15,23 +15,32 @@
 // A kernel whose result depends on bytes it did not write then fails deterministically, on every box.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "pmr_kernels.h"
 
 #define PMR_POISON_WORD 0x7FA0DEADu
 
-static int g_poison = -1;                                          // -1: not read yet (environment PMR_DEBUG_POISON)
+// process-wide, read by every launch of every handle's thread: an atomic (two threads that find it unread both read the environment
+// and store the same value)
+static std::atomic<int> g_poison{-1};                              // -1: not read yet (environment PMR_DEBUG_POISON)
 
 extern "C" int pmr_debug_poison_enabled(void)
 {
-    if (g_poison < 0) { const char *e = getenv("PMR_DEBUG_POISON"); g_poison = (e && e[0] && e[0] != '0') ? 1 : 0; }
-    return g_poison;
+    int v = g_poison.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("PMR_DEBUG_POISON");
+        v = (e && e[0] && e[0] != '0') ? 1 : 0;
+        int expect = -1;
+        if (!g_poison.compare_exchange_strong(expect, v, std::memory_order_relaxed)) v = expect;   // pmr_debug_poison() got there first
+    }
+    return v;
 }
 
 extern "C" int pmr_debug_poison(int on)
 {
     const int was = pmr_debug_poison_enabled();
-    g_poison = on ? 1 : 0;
+    g_poison.store(on ? 1 : 0, std::memory_order_relaxed);
     return was;
 }
 
@@ -49,23 +58,31 @@ __global__ __launch_bounds__(1024) void k_poison_lds(unsigned words, unsigned wo
     if (pz[(threadIdx.x * 61u) % words] != word) __builtin_trap();
 }
 
+// The whole 160 KiB of a gfx950 CU's LDS is requested EXPLICITLY, whatever hipDeviceAttributeMaxSharedMemoryPerBlock reports (other
+// gfx9 parts say 64 KiB: two 64 KiB workgroups per CU would leave 32 KiB of every CU unpoisoned and the one-per-CU placement
+// argument above would not hold).  A runtime that does not grant it makes the launch FAIL (and with it every test of the tier):
+// the mode never degrades silently.  The per-device "limit raised" flags are an atomic word (pmr_attr_flags), like every other
+// launcher's: handles on different devices may be driven from different threads.
+#define PMR_POISON_LDS_BYTES (160 * 1024)
 extern "C" int pmr_debug_poison_lds(pmr_stream_t s)
 {
-    static int dev_cus[64], dev_lds[64];
+    static pmr_attr_flags raised;
+    static std::atomic<int> dev_cus[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
-    if (!dev_cus[dev]) {
-        int cus = 0, lds = 0;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
-        if (cus <= 0) cus = 256;
-        if (lds <= 0 || lds > 160 * 1024) lds = 160 * 1024;        // gfx950: 160 KiB per CU, all of it allocatable by one workgroup
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        dev_cus[dev] = cus; dev_lds[dev] = lds;
+    if (pmr_attr_needed(raised)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_poison_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 PMR_POISON_LDS_BYTES);
+        if (e != hipSuccess) { raised.fetch_and(~(1ull << dev), std::memory_order_relaxed); return (int)e; }
     }
-    const int lds = dev_lds[dev], per_cu = (160 * 1024) / lds;      // 1 on gfx950
-    hipLaunchKernelGGL(k_poison_lds, dim3((unsigned)(dev_cus[dev] * (per_cu > 0 ? per_cu : 1))), dim3(1024), (size_t)lds, (hipStream_t)s,
-                       (unsigned)lds / 4u, PMR_POISON_WORD);
+    int cus = dev_cus[dev].load(std::memory_order_relaxed);
+    if (!cus) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cus <= 0) cus = 256;
+        dev_cus[dev].store(cus, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(k_poison_lds, dim3((unsigned)cus), dim3(1024), (size_t)PMR_POISON_LDS_BYTES, (hipStream_t)s,
+                       (unsigned)PMR_POISON_LDS_BYTES / 4u, PMR_POISON_WORD);
     return (int)hipGetLastError();
 }
 
@@ -80,7 +97,15 @@ __global__ __launch_bounds__(256) void k_lds_probe(unsigned *__restrict__ out, u
 
 extern "C" int pmr_debug_lds_probe(void *d_out, unsigned words, unsigned n_wg)
 {
-    if (!d_out || !words || words > 16384u || !n_wg) return (int)hipErrorInvalidValue;
+    if (!d_out || !words || words > PMR_POISON_LDS_BYTES / 4u || !n_wg) return (int)hipErrorInvalidValue;
+    if (words > 16384u) {                                            // beyond the default 64 KiB dynamic-LDS limit
+        static pmr_attr_flags once;
+        if (pmr_attr_needed(once)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lds_probe), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     PMR_POISON_LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
     PMR_KLAUNCH(k_lds_probe, dim3(n_wg), dim3(256), (size_t)words * 4u, (hipStream_t)0, (unsigned *)d_out, words);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();

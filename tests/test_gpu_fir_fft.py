@@ -17,15 +17,16 @@ from sdr_pmr446_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _chain(direct, **kw):
+def _chain(form, **kw):
+    """form: None = the product's choice (1024-point FFT form on large blocks), "direct", "fft4096" (PMR_FIR, read once at create)."""
     from sdr_pmr446_amd import chain
     old = os.environ.get("PMR_FIR")
-    if direct:
-        os.environ["PMR_FIR"] = "direct"
+    if form:
+        os.environ["PMR_FIR"] = form
     try:
-        return chain.PmrChain(**kw)                            # the switches are read once, at create
+        return chain.PmrChain(**kw)
     finally:
-        if direct:
+        if form:
             if old is None:
                 os.environ.pop("PMR_FIR", None)
             else:
@@ -52,26 +53,31 @@ def _run(c, x, splits, want):
 
 
 CASES = [
-    # (fs, M), splits, synthesised channels, open channels (None = all)
-    (CFG2, [1 << 21, (1 << 20) + 12345, 786433], None, None),                   # 4096-point blocks, ragged calls
-    (CFG2, [1 << 22], None, [3, 9, 14]),                                        # open-channel list, odd count (last pair = one channel)
-    (CFG2, [(1 << 22) + 999], None, [5]),                                       # reference semantics: one open channel
-    (CFG3, [1 << 23, (1 << 22) + 77], None, None),                              # 1024-point blocks (1706 frames per call)
-    (CFG3, [1 << 25], None, None),                                              # 4096-point blocks at 256 channels
-    (CFG5, [1 << 24, 1 << 24], None, None),                                     # the headline plan: 209 frames per call, one short block
+    # (fs, M), splits, synthesised channels, open channels (None = all), form under test
+    (CFG2, [1 << 21, (1 << 20) + 12345, 786433], None, None, None),             # ragged calls
+    (CFG2, [1 << 22], None, [3, 9, 14], None),                                  # open-channel list, odd count (last pair = one channel)
+    (CFG2, [(1 << 22) + 999], None, [5], None),                                 # reference semantics: one open channel
+    (CFG3, [1 << 23, (1 << 22) + 77], None, None, None),                        # 1706 frames per call
+    (CFG3, [1 << 25], None, None, None),                                        # one large call at 256 channels
+    (CFG5, [1 << 24, 1 << 24], None, None, None),                               # the headline plan: 209 frames per call, one short block
+    # the 4096-point kernels (PMR_FIR=fft4096: 256 threads, 35 KB of LDS; no plan selects them, tests keep them honest)
+    (CFG2, [1 << 21, (1 << 20) + 12345, 786433], None, None, "fft4096"),
+    (CFG2, [(1 << 22) + 999], None, [5, 12, 13], "fft4096"),
+    (CFG3, [1 << 24], None, None, "fft4096"),
 ]
-IDS = ["cfg2-ragged", "cfg2-three-open", "cfg2-one-open", "cfg3-1024pt", "cfg3-4096pt", "cfg5"]
+IDS = ["cfg2-ragged", "cfg2-three-open", "cfg2-one-open", "cfg3-two-calls", "cfg3-one-call", "cfg5",
+       "cfg2-ragged-4096pt", "cfg2-three-open-4096pt", "cfg3-4096pt"]
 
 
-@pytest.mark.parametrize("cfg,splits,ks,open_ch", CASES, ids=IDS)
-def test_fft_form_equals_direct_form_and_oracle(cfg, splits, ks, open_ch):
+@pytest.mark.parametrize("cfg,splits,ks,open_ch,form", CASES, ids=IDS)
+def test_fft_form_equals_direct_form_and_oracle(cfg, splits, ks, open_ch, form):
     fs, M = cfg
     n = sum(splits)
     x = _synth(n, fs, M, dev_hz=1500.0)
     mb = max(splits)
     res = []
-    for direct in (False, True):
-        g = _chain(direct, fs_in=fs, num_channels=M, max_block=mb)
+    for f in (form, "direct"):
+        g = _chain(f, fs_in=fs, num_channels=M, max_block=mb)
         if open_ch is not None:
             g.set_channel_mask(open_ch)
         res.append(_run(g, x, splits, ("pcm", "audio")))
@@ -94,16 +100,17 @@ def test_fft_form_equals_direct_form_and_oracle(cfg, splits, ks, open_ch):
         assert np.abs(fft["pcm"][chans].astype(np.int32) - po[chans].astype(np.int32)).max() <= 1
 
 
-@pytest.mark.parametrize("open_ch", [None, [2, 5, 11]], ids=["all", "three-open"])
-def test_fft_form_with_the_ctcss_branch_as_second_product(open_ch):
+@pytest.mark.parametrize("open_ch,form", [(None, None), ([2, 5, 11], None), (None, "fft4096"), ([2, 5, 11], "fft4096")],
+                         ids=["all", "three-open", "all-4096pt", "three-open-4096pt"])
+def test_fft_form_with_the_ctcss_branch_as_second_product(open_ch, form):
     """Detector on: the low-pass branch delay188(x) - hp(x) (:884-889) leaves the same forward transform as a second product.
     Branch samples against the direct DUAL pass and the oracle; the detector's events on top of it against the oracle's."""
     fs, M = CFG2
     splits = [(1 << 21) + 4321, 1 << 21]
     x = _synth(sum(splits), fs, M, dev_hz=1500.0, ctcss_dev_hz=700.0)
     res = []
-    for direct in (False, True):
-        g = _chain(direct, fs_in=fs, num_channels=M, max_block=max(splits))
+    for f in (form, "direct"):
+        g = _chain(f, fs_in=fs, num_channels=M, max_block=max(splits))
         if open_ch is not None:
             g.set_channel_mask(open_ch)
         res.append(_run(g, x, splits, ("pcm", "ctcss_lp", "ctcss")))

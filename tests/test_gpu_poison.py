@@ -22,7 +22,9 @@ def test_every_workgroup_on_every_cu_starts_on_poisoned_lds():
     from sdr_pmr446_amd import chain
     L = chain.load()
     assert L.pmr_debug_poison(1) == 1, "conftest switches the mode on for every -m gpu test"
-    for words, n_wg in [(8192, 1024), (16384, 512), (2048, 4096)]:      # 32 KB x 5 per CU, 64 KB x 2 per CU, 8 KB x 20 per CU
+    # 32 KB x 5 per CU, 64 KB x 2 per CU, 8 KB x 20 per CU, and the WHOLE 160 KB of every CU (one workgroup each, two rounds): a poison
+    # kernel that was granted less than 160 KB per workgroup would leave the top of every CU's LDS as it was
+    for words, n_wg in [(8192, 1024), (16384, 512), (2048, 4096), (40960, 512)]:
         out = chain.DeviceBuffer(words * n_wg * 4)
         assert L.pmr_debug_lds_probe(out.ptr, words, n_wg) == 0
         got = out.download(np.uint32, words * n_wg)

@@ -141,3 +141,20 @@ def test_scan_mode_follows_the_squelch(tmp_path):
     frames = [ch.process_block(x[i:i + nb], want=("pcm",))["n_frames"] for i in range(0, len(x), nb)]
     assert rate == 12500 and len(data) == sum(frames[3:8])
     assert np.abs(data[2000:]).max() > 0.05                              # audible audio while the carrier is there
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads,blocks", [(2, 12), (3, 9)])
+def test_one_pthread_per_handle_equals_the_streams_run_serially(threads, blocks):
+    """examples/pmr446_threads.c: the threading model include/pmr_chain.h promises ("one thread per handle; handles are
+    independent" -- the reference is a threaded C program, src/sdr_pmr446.c:520-544, 788-931), from C.  N pthreads, each with its
+    own handle on the same device, ragged blocks (0, 1, 7 samples among them), host calls and un-synchronised device calls, one
+    stream with the CTCSS detector, channel-mask changes and channel resets between blocks: PCM and CTCSS events byte for byte
+    what the same streams give when run one after the other.  Runs under the poison mode (inherited through the environment)."""
+    from sdr_pmr446_amd import build
+    build.build_example()
+    r = subprocess.run([build.EXAMPLE_THREADS, str(threads), str(blocks)], capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("stream ")]
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+    assert len(lines) == threads and all(l.endswith(": identical") for l in lines), r.stdout
+    assert "CTCSS + mask changes" in lines[1] and " 0 CTCSS events" not in lines[1], lines[1]

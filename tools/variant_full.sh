@@ -4,7 +4,10 @@
 W=$1; shift
 for F in "$@"; do
   echo "== flags: $F"
-  if ! PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" python3 sdr_pmr446_amd/build.py --force > /tmp/variant_build.log 2>&1; then
+  # the -D flags reach BOTH compilers (hipcc for the kernels, gcc for the host C: a macro that lives in pmr_chain.c was silently
+  # ignored in round 4 -- ADVICE r04); other flags are hipcc's only
+  CCF=$(for t in $F; do case $t in -D*) echo -n "$t ";; esac; done)
+  if ! PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" PMR_CC_FLAGS="$CCF" python3 sdr_pmr446_amd/build.py --force > /tmp/variant_build.log 2>&1; then
     echo "BUILD FAILED for flags: $F"; grep -m3 -E "error" /tmp/variant_build.log; continue
   fi
   python3 bench.py --workload $W --also none --no-cpu-baseline --regions 5 --parity-blocks 0 2>&1 | python3 -c "
