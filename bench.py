@@ -133,15 +133,20 @@ def cpu_baseline(fs, M, seconds_target=8.0, multi=True):
 
 def load_measured_traffic(workload, block):
     """HBM bytes per launch of the roofline kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE), if they were taken for this workload/block."""
+    (FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE), if they were taken for this workload/block -- and whether they were
+    taken with THESE kernels: the entry carries the sha256 of the kernel sources it was measured on (tools/collect_profiles.sh);
+    a different tree keeps the number and marks it stale.  Returns (bytes or None, stale flag or None, round tag or None)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
         e = t.get("%s/k_frontend/%d" % (workload, block))
-        return e["hbm_bytes_per_launch"] if e else None
+        if not e:
+            return None, None, None
+        from sdr_pmr446_amd import build as _b
+        return e["hbm_bytes_per_launch"], e.get("kernel_sources_sha256") != _b.kernel_sources_sha256(), e.get("round")
     except Exception:
-        return None
+        return None, None, None
 
 
 def parity_check(ch, fs, M, iq, block, pcm_bufs, S, nblk, rot=1):
@@ -299,6 +304,16 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
         dts1 = [multigpu.timed_region(run, dist, device_sync, sync_dev)[0] for _ in range(5)]
         ch.set_channel_mask(None)
 
+    # Every rank checks ITS stream on ITS device against the oracle (un-synchronised pipelined calls on the bench blocks): N = 1 the
+    # whole rotation, N > 1 one 2^26-sample block per rank (~2 s of one host core each, the ranks run in parallel on their
+    # NUMA-local cores); the verdicts are AND-reduced over the gloo group.  Without this an 8-GPU run would return eight throughput
+    # numbers and no evidence that device ordinals 1-7 compute the right thing (per-device hipSetDevice, table uploads, streams).
+    par = None
+    if args.parity_blocks > 0:
+        par = parity_check(ch, fs, M, iq, block, pcm_bufs, S, nchk if world == 1 else 1, rot)
+        par["device"] = local_rank
+        par_all = multigpu.reduce_parity(dist, rank, world, par)
+        par.update(par_all)
     rec = None
     if rank == 0:
         r = M * 12500.0 / fs
@@ -311,8 +326,11 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
             avg_s = ms / n * 1e-3
             launches_per_step = n / (args.steps * len(dts))
             achieved = b_alg * block / avg_s / 1e9
+            traffic, stale, tround = load_measured_traffic(name, block)
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": load_measured_traffic(name, block),
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_stale": stale,
+                    "traffic_source": None if traffic is None else "profiles/traffic.json (%s PMC passes: not measured in this run; "
+                                      "traffic_stale = the kernel sources differ from the ones the passes ran on)" % tround,
                     "avg_kernel_ms": ms / n, "launches_timed": n, "launches_per_step": launches_per_step,
                     "events": "start/stop events carried by every %d-th launch of the kernel inside the timed regions" % event_every,
                     "algorithmic_bytes_per_sample": b_alg, "algorithmic_bytes_per_launch": b_alg * block,
@@ -351,9 +369,9 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
                                  "note": "reference semantics (src/sdr_pmr446.c:876-877): channelizer + discriminator for all %d "
                                          "channels, audio FIR / PCM for the one open channel (pmr_chain_set_channel_mask)" % M},
         }
-        if world == 1 and args.parity_blocks > 0:
-            rec["parity_checked"] = parity_check(ch, fs, M, iq, block, pcm_bufs, S, nchk, rot)
-        if headline and args.host_io and world == 1:
+        if par is not None:
+            rec["parity_checked"] = par
+        if headline and not args.no_host_io and world == 1:
             rec["host_io"] = host_io(ch, iq, block, M, S)
         if world == 1 and not args.no_cpu_baseline:
             # headline: ~16 s incl. one stream per core; sub-records: the single-core and one-channel figures only (~6 s each)
@@ -362,6 +380,8 @@ def measure(name, args, rank, local_rank, world, dist, dev, headline):
     iq.free()
     for b in pcm_bufs:
         b.free()
+    if rec is None and par is not None:
+        rec = {"parity_checked": {"all_ok": par["all_ok"]}}          # ranks > 0: only what decides the exit code
     return rec
 
 
@@ -449,8 +469,9 @@ def main():
                                                           "exercise the N > 1 code path on a 1-GPU box")
     ap.add_argument("--force-rccl", action="store_true", help="TEST ONLY: try the RCCL group even when ranks share a device (it must "
                     "fail there and the ranks must agree to fall back to gloo: the failure path of multigpu.init_dist, exercised on a 1-GPU box)")
-    ap.add_argument("--host-io", action="store_true",
-                    help="also time the host-buffer entry point (H2D of the IQ + D2H of the PCM inside the call)")
+    ap.add_argument("--host-io", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--no-host-io", action="store_true",
+                    help="skip the PCIe-inclusive leg of the headline (host-buffer entry points on 2^22-sample calls, ~1 s)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-kernel HIP events in the timed region")
     ap.add_argument("--ctcss", action="store_true", help="run with the CTCSS detector enabled (SURVEY s8 row f2) -- an A/B aid, "
                                                          "not the headline workload (the one_open_channel sub-record then is "
@@ -495,6 +516,8 @@ def main():
         r = measure(w, args, rank, local_rank, world, dist, dev, headline=False)
         if r is not None:
             subs[w] = r
+    # a parity failure on ANY rank fails the job (every rank knows: the verdicts were all-reduced), after the line is out
+    parity_ok = all((r or {}).get("parity_checked", {}).get("all_ok", True) for r in [head] + list(subs.values()))
     if rank == 0:
         out = {"metric": "complex-IQ Msamples/s through full channelize+demod chain", "value": head["value"],
                "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -503,8 +526,8 @@ def main():
         if world > 1:
             out["dist"] = {"backend": args.dist_backend, "backend_used": dist.backend_used, "fallback_reason": dist.note,
                            "devices_visible": ndev, "rank0_affinity": affinity,
-                           "use": "start/stop barrier and MAX of the elapsed time only: one independent IQ stream per rank, no "
-                                  "data-path collective"}
+                           "use": "start/stop barrier and MAX of the elapsed time only (+ the AND of the ranks' parity verdicts): one "
+                                  "independent IQ stream per rank, no data-path collective"}
         for k in ("timed_regions", "config", "roofline", "one_open_channel", "parity_checked", "host_io", "cpu_baseline"):
             if k in head:
                 out[k] = head[k]
@@ -513,6 +536,9 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy()
+    if not parity_ok:
+        sys.stderr.write("bench.py: PARITY FAILED on at least one rank (parity_checked.per_rank)\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

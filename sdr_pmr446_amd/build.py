@@ -18,6 +18,20 @@ HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_internal.h", "pmr_fe_common.hpp
            os.path.join("..", "data", "pmr446_taps.h")]
 
 
+def kernel_sources_sha256():
+    """sha256 over the kernel sources (csrc/*.hip, *.hpp and the kernels' shared header), names and contents in sorted order: what
+    ties a committed PMC measurement (profiles/traffic.json) to the kernels it was taken with -- bench.py marks roofline.traffic
+    stale when the tree's hash differs from the entry's."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp")) or f == "pmr_kernels.h":
+            h.update(f.encode() + b"\0")
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -84,4 +98,7 @@ def build_example(verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--kernel-hash" in sys.argv:
+        print(kernel_sources_sha256())
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -12,7 +12,8 @@
 
 extern "C" void *pmr_device_alloc(size_t bytes, int device)
 {
-    if (device >= 0 && hipSetDevice(device) != hipSuccess) return NULL;
+    if (device < -1) return NULL;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return NULL; }    /* (the error is reported, not left sticky) */
     void *p = NULL;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return NULL;
     /* zero-filled; 0xFF bytes in the test-only poison mode (an output row the library was to write and did not then shows) */

@@ -279,3 +279,39 @@ def test_reopened_channels_restart_and_events_follow_the_mask_of_their_block():
         assert np.all(e3["index"][c, 1:] == c % 38) and np.all(e3["detected"][c, 1:] == 1), c
     assert np.all(np.isfinite(e3["max_power"])) and np.all(np.isfinite(e3["avg_power"]))
     assert r1["n_frames"] > N
+
+
+@pytest.mark.parametrize("first_frames,expect_first", [(2441, "decision"), (2441 // 2 + 1, "none")],
+                         ids=["audio-part-starts-on-the-grid", "audio-part-starts-in-mid-block"])
+def test_two_step_mask_change_restarts_relative_to_the_pending_audio_part(first_frames, expect_first):
+    """in the two-step form (pmr_chain_channelize_block -> set_channel_mask -> pmr_chain_demodulate_block, the squelch
+    order of the reference, src/sdr_pmr446.c:828-877) the frame counter has already advanced past the pending block when the mask
+    opens a channel, but the detector runs NEXT at the pending block's first frame: "restarted in mid-block" must be judged there.
+    Pending part starting ON the 2441-frame grid: the channel sees the whole Goertzel block -> a real decision (the old code
+    reported {-1, 0, 0, 0}); starting in mid-block: that block is incomplete for the channel -> no decision (the old code reported
+    a decision over a partial block whenever the advanced counter happened to sit on the grid)."""
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    N, k = 2441, 5
+    fm_ch = [c for c in active_channels(M) if synth.channel_kind(c) == "fm" and c != k]
+    c = fm_ch[0]
+    second_frames = 2 * N - first_frames if expect_first == "none" else N + N // 2
+    n1, n2 = first_frames * 192, second_frames * 192           # cfg2: exactly 192 raw samples per frame
+    x = synth.synth_iq(n1 + n2, fs, M, dev_hz=1500.0, ctcss_dev_hz=700.0)
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max(n1, n2))
+    g.ctcss_enable(True)
+    g.set_channel_mask([k])
+    assert g.process_block(x[:n1], want=("pcm",))["n_frames"] == first_frames
+    assert g.channelize_block(x[n1:], want=("rssi",))["n_frames"] == second_frames
+    g.set_channel_mask([k, c])                                 # the squelch opens channel c on THIS block, before its audio part
+    g.demodulate_block(want=("pcm",))
+    ev = g.ctcss_read()
+    g.close()
+    if expect_first == "decision":
+        assert ev.shape[1] == 1                                # frames [N, 2N) complete; [2N, 2.5N) in progress
+        assert ev["index"][c, 0] == c % 38 and ev["detected"][c, 0] == 1, ev[c]
+    else:
+        assert ev.shape[1] == 2                                # [0, N) completed by the pending part (channel c joined at N / 2), [N, 2N)
+        assert ev["index"][c, 0] == -1 and ev["detected"][c, 0] == 0, ev[c]
+        assert ev["index"][c, 1] == c % 38 and ev["detected"][c, 1] == 1, ev[c]
+    assert np.all(ev["index"][k] == k % 38) and np.all(ev["detected"][k] == 1)

@@ -65,6 +65,58 @@ def test_two_ranks_two_streams_max_time():
     assert f0 == f1 and thr0 == thr1 == pytest.approx(2 * 3 * 50000 / dt0)
 
 
+def _parity_worker(rank, world, port, q, fail_rank):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import oracle
+    from sdr_pmr446_amd import multigpu, synth
+    dist = multigpu.init_dist("gloo")
+    fs, M, n = 2.4e6, 16, 60000
+    x = synth.synth_iq(n, fs, M, stream_id=multigpu.stream_id_for_rank(rank), dev_hz=500.0)
+    ref = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n).process_block(x)["pcm"].astype(np.int32)
+    got = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n).process_block(x)["pcm"].astype(np.int32)   # stands in for the GPU chain
+    if rank == fail_rank:
+        got[3, 100] += 5                                     # this rank's "device" computed something else
+    d = int(np.abs(got - ref).max())
+    rec = {"ok": d <= 1, "max_abs_pcm_diff_lsb": d, "frames_checked": int(got.shape[1]), "channels_checked": M, "device": rank}
+    q.put((rank, multigpu.reduce_parity(dist, rank, world, rec)))
+    dist.destroy()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1], ids=["all-ranks-agree", "rank-1-fails"])
+def test_every_rank_learns_every_ranks_parity_verdict(fail_rank):
+    """bench.py at world > 1: each rank checks ITS stream on ITS device against the oracle and the verdicts are
+    reduced over the gloo group -- one failing rank must fail the record on EVERY rank (and with it the job's exit code)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_parity_worker, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]                                  # the same record on both ranks
+    r = res[0]
+    assert r["ranks"] == 2 and [e["rank"] for e in r["per_rank"]] == [0, 1] and [e["device"] for e in r["per_rank"]] == [0, 1]
+    assert all(e["frames_checked"] > 200 and e["channels_checked"] == 16 for e in r["per_rank"])
+    if fail_rank < 0:
+        assert r["all_ok"] and r["worst_lsb"] == 0 and all(e["ok"] for e in r["per_rank"])
+    else:
+        assert not r["all_ok"] and r["worst_lsb"] == 5
+        assert [e["ok"] for e in r["per_rank"]] == [True, False] and r["per_rank"][1]["max_abs_pcm_diff_lsb"] == 5
+
+
+def test_reduce_parity_single_process():
+    from sdr_pmr446_amd import multigpu
+    r = multigpu.reduce_parity(None, 0, 1, {"ok": True, "max_abs_pcm_diff_lsb": 1, "frames_checked": 10, "channels_checked": 4, "device": 0})
+    assert r == {"ranks": 1, "all_ok": True, "worst_lsb": 1,
+                 "per_rank": [{"rank": 0, "device": 0, "ok": True, "max_abs_pcm_diff_lsb": 1, "frames_checked": 10, "channels_checked": 4}]}
+    r = multigpu.reduce_parity(None, 0, 1, {"ok": False, "error": "oracle died"})
+    assert not r["all_ok"] and r["worst_lsb"] is None
+
+
 def test_single_process_defaults():
     from sdr_pmr446_amd import multigpu
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -119,7 +171,7 @@ def test_bench_gpus_2_launches_itself():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if torch.cuda.is_available():
-        pytest.skip("GPU box: covered by profiles/r03_bench_2rank_1gpu.json")
+        pytest.skip("GPU box: covered by profiles/r05_bench_2rank_1gpu.json")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2"],
                        env=env, capture_output=True, text=True, timeout=300)

@@ -6,8 +6,11 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
+# the kernels these counters belong to (profiles/traffic.json carries the hash; bench.py marks roofline.traffic stale when the
+# tree it runs from has other kernel sources)
+python3 $R/sdr_pmr446_amd/build.py --kernel-hash > $O/kernel_sources.sha256
 cd /tmp && export TMPDIR=/tmp
-[ -n "$SKIP_BENCH" ] || python3 $R/bench.py --host-io 2>/dev/null | grep '^{' > $O/bench.json
+[ -n "$SKIP_BENCH" ] || python3 $R/bench.py 2>/dev/null | grep '^{' > $O/bench.json
 B="--also none --regions 2 --steps 50 --warmup 2 --no-cpu-baseline --no-kernel-events --parity-blocks 0 --no-one-open"
 for W in ${WORKLOADS:-cfg5 cfg3 cfg2}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 $R/bench.py --workload $W $B > /dev/null 2>&1

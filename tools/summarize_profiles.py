@@ -28,6 +28,8 @@ if os.path.exists(src) and os.path.getsize(src):
     json.dump(d, open(os.path.join(O, "%s_bench.json" % tag), "w"), indent=1)
     print("bench: %s %.1f GS/s frac %.3f" % (d["config"]["workload"][:4], d["value"] / 1e3, d["roofline"]["frac"]))
 
+hp = os.path.join(P, "kernel_sources.sha256")
+KHASH = open(hp).read().strip() if os.path.exists(hp) else None
 tj = os.path.join(O, "traffic.json")
 traffic = json.load(open(tj)) if os.path.exists(tj) else {}
 for w in ("cfg5", "cfg3", "cfg2"):
@@ -75,6 +77,7 @@ for w in ("cfg5", "cfg3", "cfg2"):
             traffic["%s/k_frontend/%d" % (w, BLOCK)] = {
                 "FETCH_SIZE_KB": e["FETCH_SIZE_KB"], "WRITE_SIZE_KB": e["WRITE_SIZE_KB"],
                 "hbm_bytes_per_launch": e["hbm_bytes_per_launch"], "kernel": fe[0], "round": tag,
+                "kernel_sources_sha256": KHASH,
                 "chain_hbm_bytes_per_block": chain_bytes, "chain_over_algorithmic": chain_bytes / alg,
                 "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); FETCH_SIZE doubled per "
                         "MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for 16-B/lane streams); algorithmic bytes per "
