@@ -43,36 +43,52 @@ def _stale():
     return False
 
 
+def build_variant(name, hip_flags="", c_flags=None, verbose=False):
+    """Another BUILD of the library for same-box A/B runs (tools/ab_libs.py, PMR_LIBRARY): build_ab/<name>/libpmr446_hip.so, compiled
+    with extra -D flags (they reach hipcc AND gcc unless c_flags is given), objects beside it.  Not part of the product."""
+    out = os.path.join(os.path.dirname(HERE), "build_ab", name)
+    os.makedirs(out, exist_ok=True)
+    if c_flags is None:
+        c_flags = " ".join(t for t in hip_flags.split() if t.startswith("-D"))
+    lib = os.path.join(out, "libpmr446_hip.so")
+    _compile(lib, out, ["-fno-slp-vectorize"] + hip_flags.split(), c_flags.split(), verbose)
+    return lib
+
+
 def build(force=False, verbose=False):
     """Compile for gfx950 (cross-compiles without a GPU).  Returns the library path."""
     if not force and not _stale():
         return LIB
+    _compile(LIB, CSRC, EXTRA_HIP_FLAGS, EXTRA_C_FLAGS, verbose)
+    build_example(verbose)
+    return LIB
+
+
+def _compile(lib, objdir, hip_flags, c_flags, verbose):
     hipcc = os.path.join(ROCM, "bin", "hipcc")
     objs = []
     for f in C_SOURCES:
-        o = os.path.join(CSRC, f[:-2] + ".o")
+        o = os.path.join(objdir, f[:-2] + ".o")
         cmd = ["gcc", "-std=gnu11", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
-               "-I" + os.path.join(ROCM, "include")] + EXTRA_C_FLAGS + ["-c", os.path.join(CSRC, f), "-o", o]
+               "-I" + os.path.join(ROCM, "include")] + c_flags + ["-c", os.path.join(CSRC, f), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(o)
     for f in HIP_SOURCES:
-        o = os.path.join(CSRC, f[:-4] + ".o")
+        o = os.path.join(objdir, f[:-4] + ".o")
         # -fno-slp-vectorize: keep f32 FMAs as v_fma/v_fmac; hipcc otherwise SLP-packs adjacent ones into
         # v_pk_fma_f32, which is slower than two plain FMAs on gfx950 (measured on k_fir_*; MI355X_MICROARCH.md)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-parameter"] + \
-              EXTRA_HIP_FLAGS + ["-c", os.path.join(CSRC, f), "-o", o]
+              hip_flags + ["-c", os.path.join(CSRC, f), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lm", "-lpthread"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lm", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    build_example(verbose)
-    return LIB
 
 
 EXAMPLE = os.path.join(HERE, "pmr446_file")
@@ -100,5 +116,8 @@ def build_example(verbose=False):
 if __name__ == "__main__":
     if "--kernel-hash" in sys.argv:
         print(kernel_sources_sha256())
+    elif "--variant" in sys.argv:                       # build.py --variant NAME "-DFOO -DBAR=1"
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2] if len(sys.argv) > i + 2 else ""))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

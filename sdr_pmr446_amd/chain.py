@@ -101,12 +101,13 @@ def load(build_if_missing=True):
     # Two HIP runtimes can end up in one process: this library links the system libamdhip64.so.7, a PyTorch
     # wheel bundles its own (different SONAME).  They coexist as long as PyTorch's is initialised FIRST, so when
     # torch is installed let it initialise before libpmr446_hip.so pulls in the system runtime.
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
+    if not os.environ.get("PMR_NO_TORCH"):           # (lean tools that never touch torch skip its multi-second import)
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
     path = _build.LIB
     if build_if_missing:
         path = _build.build()

@@ -1751,12 +1751,18 @@ static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_i
     if (!single) HIPCHK(hipStreamWaitEvent(q->stream, q->ev_fe[par], 0), "wait front end");
     if (q->pend_tf) {
         q->pend_tf = 0;
+#ifdef EXP_NO_TAIL      /* timing experiment (tools/ab_libs.py): what would the chain gain without this launch?  WRONG results */
+        if (q->cal_now) { }
+        else
+#endif
         if (q->cal_now) LAUNCH(K_FE_TILEFIX, pmr_launch_fe_carry_tail(q->stream, &q->pend_t2, &q->pend_f2, NULL));
         else LAUNCH(K_FE_TILEFIX, pmr_launch_fe_tilefix(q->stream, &q->pend_t2, &q->pend_f2, q->pend_tf_Q, NULL));
     }
     if (q->pend_l2) {
         q->pend_l2 = 0;
+#ifndef EXP_NO_CARRY5   /* timing experiment: the two-level plan without its carry launch.  WRONG results */
         LAUNCH(K_FE_TILES, pmr_launch_fe_carry(q->stream, &q->pend_t2, &q->pend_f2));
+#endif
         if (q->pend_ntiles2) LAUNCH(K_FE_L2, pmr_launch_frontend_l2(q->stream, &q->pend_p2, q->pend_ntiles2, q->fe2_fast));
     }
     if (q->dbg_on && ny)

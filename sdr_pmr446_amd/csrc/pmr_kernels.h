@@ -301,6 +301,9 @@ int pmr_debug_poison_lds(pmr_stream_t s);
  * sample, whose conj(0) r product has a negative-zero real part for re(r) > 0). */
 static __device__ __forceinline__ float pmr_arg(float im, float re)
 {
+#ifdef EXP_ARG_CHEAP        /* timing experiment: what do the discriminator's ~24 instructions per channel and frame cost the chain?  WRONG results */
+    return im * re;
+#endif
     const float ax = __builtin_fabsf(re), ay = __builtin_fabsf(im);
     const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
     float q = mn * __builtin_amdgcn_rcpf(mx);
