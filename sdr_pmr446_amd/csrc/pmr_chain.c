@@ -1763,7 +1763,9 @@ static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_i
 #ifndef EXP_NO_CARRY5   /* timing experiment: the two-level plan without its carry launch.  WRONG results */
         LAUNCH(K_FE_TILES, pmr_launch_fe_carry(q->stream, &q->pend_t2, &q->pend_f2));
 #endif
+#ifndef EXP_SKIP_L2
         if (q->pend_ntiles2) LAUNCH(K_FE_L2, pmr_launch_frontend_l2(q->stream, &q->pend_p2, q->pend_ntiles2, q->fe2_fast));
+#endif
     }
     if (q->dbg_on && ny)
         if ((rc = ring_to_linear(q, q->d_dbg_xr, q->d_xr, q->xr_mask, xr_abs0, ny, sizeof(cfl)))) return rc;
@@ -1798,9 +1800,11 @@ static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_i
             HIPCHK(hipMemcpyAsync(q->d_reset_flags, q->h_reset_flags, M, hipMemcpyHostToDevice, q->stream), "reset flags");
             c.reset_flags = q->d_reset_flags;
         }
+#ifndef EXP_SKIP_CHAN   /* timing experiments (tools/ab_libs.py): the chain without its channelizer / audio FIR launch.  WRONG results */
         if (q->chan_small) LAUNCH(K_CHANNELIZE_SMALL, pmr_launch_channelize_small(q->stream, &c, &ntiles));
         else if (q->chan_wide) LAUNCH(K_CHANNELIZE, pmr_launch_channelize_wide(q->stream, &c, q->d_chan_x, &ntiles));
         else LAUNCH(K_CHANNELIZE, pmr_launch_channelize(q->stream, &c, &ntiles));
+#endif
         if (q->reset_pending) { q->reset_pending = 0; memset(q->h_reset_flags, 0, M); }
         if (q->dbg_on) {
             /* discriminator rows of this block, time-major, linearised */
@@ -1816,7 +1820,9 @@ static int process_block_device_body(pmr_chain q, const void *d_iq, unsigned n_i
                 LAUNCH(K_RSSI, pmr_launch_rssi_finish(q->stream, q->d_rssi_part, ntiles, M, ns, (float *)d_rssi_db));
         }
 
+#ifndef EXP_SKIP_FIR
         if (phase != 1 && (rc = audio_part(q, frame0, ns, d_pcm, d_audio, pcm_stride))) return rc;
+#endif
     }
     if (phase == 1) { q->pend_audio = 1; q->pend_audio_frame0 = frame0; q->pend_audio_ns = ns; }
     q->frames_done += ns;

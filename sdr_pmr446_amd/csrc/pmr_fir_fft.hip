@@ -80,12 +80,18 @@ static __device__ __forceinline__ cf2 cmulk(cf2 a, cf2 w)
     return __builtin_elementwise_fma(cf2{a.y, a.y}, cf2{-w.y, w.x}, cf2{a.x, a.x} * w);
 }
 
-static __device__ __forceinline__ int16_t ff_pcm16(float y)
+// PCM hand-off of a channel PAIR: trunc(x * 32767) toward zero, saturated, NaN -> 0 (src/dsd_in.c:174 + the build's saturation), the
+// way the hardware does it by itself: v_cvt_i32_f32 truncates, saturates to the int32 range and turns NaN into 0; v_cvt_pk_i16_i32
+// saturates both to int16 and packs them -- 4 instructions per pair where the float clamp (mul, NaN test + select, max, min, cvt) took
+// 12 (a sixth of the kernel's vector instructions).  Same integers: clamping before or after the truncation commutes.
+typedef short ff_s2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ ff_s2 ff_pcm16x2(cf2 y)
 {
-    float s = y * 32767.0f;                                        // trunc(x * 32767), saturated (src/dsd_in.c:174); NaN -> 0
-    s = s == s ? s : 0.f;
-    s = __builtin_fminf(__builtin_fmaxf(s, -32768.0f), 32767.0f);
-    return (int16_t)(int)s;
+    const cf2 s = y * mk2(32767.0f, 32767.0f);
+    int ia, ib;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(ia) : "v"(s.x));
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(ib) : "v"(s.y));
+    return __builtin_bit_cast(ff_s2, __builtin_amdgcn_cvt_pk_i16(ia, ib));
 }
 
 // 4-point DFT in place: (a, b, c, d) = x[0..3] -> X[0..3]; forward kernel e^(-j 2 pi nk / 4), INV: e^(+j ...)
@@ -212,15 +218,36 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
     // (the 15 + 15 twiddles of a thread are re-read where they are used -- global table through L1 for A / A', LDS for B / B' --
     //  instead of living in 60 registers across the whole kernel: the register count decides whether a wave of this kernel still
     //  fits on a SIMD beside four front-end tiles)
+    // Rows of the transform: INTERIOR blocks (every row lies inside the call and the block does not wrap around the ring: all but the
+    // call's last block or two) read row n0 N0 + t at a UNIFORM base (scalar registers) + one per-lane byte offset -- sixteen load
+    // instructions and nothing else; the edge blocks test every row (rows beyond the call's last frame read as zero).  Round 4 ran the
+    // edge form everywhere: ~15 vector / scalar instructions and two branches per row, a fifth of the kernel.
+    const unsigned idx0 = (r0lo + (unsigned)rel0) & mask32;        // ring row of transform index 0 (wave-uniform)
+    const bool interior = rel0 + N <= ns_i && (unsigned long long)idx0 + (unsigned)N <= (unsigned long long)mask32 + 1ull;
     cf2 v[16];
+    if (interior) {
+        const char *rowa = reinterpret_cast<const char *>(P.in) + ((size_t)idx0 * P.M + ca) * sizeof(float);
+        const size_t pitch = (size_t)N0 * P.M * sizeof(float);     // bytes between rows n0 and n0 + 1 of a lane
+        const unsigned voff = t * P.M * (unsigned)sizeof(float);
+        if (adjacent) {
 #pragma unroll
-    for (int n0 = 0; n0 < 16; n0++) {
-        const int rel = rel0 + n0 * N0 + (int)t;
-        v[n0] = mk2(0.f, 0.f);
-        if (rel < ns_i) {
-            const float *src = P.in + (size_t)(((r0lo + (unsigned)rel) & mask32) * P.M);
-            if (adjacent) v[n0] = *reinterpret_cast<const cf2 *>(src + ca);
-            else v[n0] = mk2(src[ca], src[cb]);
+            for (int n0 = 0; n0 < 16; n0++) v[n0] = *reinterpret_cast<const cf2 *>(rowa + n0 * pitch + voff);
+        } else {
+            const long long dba = ((long long)cb - (long long)ca) * (long long)sizeof(float);
+#pragma unroll
+            for (int n0 = 0; n0 < 16; n0++)
+                v[n0] = mk2(*reinterpret_cast<const float *>(rowa + n0 * pitch + voff), *reinterpret_cast<const float *>(rowa + dba + n0 * pitch + voff));
+        }
+    } else {
+#pragma unroll
+        for (int n0 = 0; n0 < 16; n0++) {
+            const int rel = rel0 + n0 * N0 + (int)t;
+            v[n0] = mk2(0.f, 0.f);
+            if (rel < ns_i) {
+                const float *src = P.in + (size_t)(((r0lo + (unsigned)rel) & mask32) * P.M);
+                if (adjacent) v[n0] = *reinterpret_cast<const cf2 *>(src + ca);
+                else v[n0] = mk2(src[ca], src[cb]);
+            }
         }
     }
 
@@ -280,6 +307,14 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
     ff_phase_c<R2, DUAL, true>(zs, zs2, zs, P.H, t);
     inverse_BA();
     // ---- outputs: transform index n = n0 N0 + t is frame rel0 + n (relative to row0); indices >= ntaps - 1 are valid ----
+    // Row n0 of a lane is stored by ALL lanes, by none, or (one row per block) by the lanes behind the filter's start-up: decided on
+    // the scalar unit per row -- interior blocks carry no per-lane tests except in that one row.
+    const int nvalid0 = (int)P.ntaps - 1;                          // first valid transform index
+    const auto row_mode = [&](int n0) -> int {                     // 0 skip, 1 every lane, 2 per-lane test
+        if (n0 * N0 + (N0 - 1) < nvalid0) return 0;
+        if (!interior) return 2;
+        return n0 * N0 >= nvalid0 ? 1 : 2;
+    };
     {
         // one base pointer per row and thread; the 16 stores of a row are base + n0 N0 (compile-time offsets)
         const long relt = (long)rel0 + (long)t;
@@ -287,10 +322,12 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
         float *aa = P.audio ? P.audio + (size_t)ca * P.stride + relt : nullptr, *ab = P.audio ? P.audio + (size_t)cb * P.stride + relt : nullptr;
 #pragma unroll
         for (int n0 = 0; n0 < 16; n0++) {
+            const int mode = row_mode(n0);
+            if (mode == 0) continue;
             const int n = n0 * N0 + (int)t, rel = rel0 + n;
-            if (n >= (int)P.ntaps - 1 && rel < ns_i) {
+            if (mode == 1 || (n >= nvalid0 && rel < ns_i)) {
                 const cf2 y = v[R16P(n0)];
-                if (pa) { pa[n0 * N0] = ff_pcm16(y.x); if (has_b) pb[n0 * N0] = ff_pcm16(y.y); }
+                if (pa) { const ff_s2 q16 = ff_pcm16x2(y); pa[n0 * N0] = q16.x; if (has_b) pb[n0 * N0] = q16.y; }
                 if (aa) { aa[n0 * N0] = y.x; if (has_b) ab[n0 * N0] = y.y; }
             }
         }
@@ -301,8 +338,10 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
         inverse_BA();
 #pragma unroll
         for (int n0 = 0; n0 < 16; n0++) {
+            const int mode = row_mode(n0);
+            if (mode == 0) continue;
             const int n = n0 * N0 + (int)t, rel = rel0 + n;
-            if (n >= (int)P.ntaps - 1 && rel < ns_i) {
+            if (mode == 1 || (n >= nvalid0 && rel < ns_i)) {
                 const cf2 y = v[R16P(n0)];
                 float *dst = P.out2_tm + (size_t)(((r0lo + (unsigned)rel) & mask32) * P.M);
                 if (adjacent) *reinterpret_cast<cf2 *>(dst + ca) = y;
