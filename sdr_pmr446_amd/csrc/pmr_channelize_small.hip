@@ -201,7 +201,7 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
     const bool outA = tid > 0 && mine && tA < (long)ns;
     if (outA) {
         const cf *pvrow = Xs + (size_t)(tid - 1) * FS;
-        float *o = q.fm + ((unsigned long long)(q.frame0 + tA) & q.fm_mask) * M;
+        float *o = q.fm + ((unsigned long long)(q.frame0 + tA) & q.fm_mask & PMR_EXP_ROW_AND) * M;
 #pragma unroll
         for (int k = 0; k < M; k += 4) {
             const float4 p0 = *reinterpret_cast<const float4 *>(pvrow + k), p1 = *reinterpret_cast<const float4 *>(pvrow + k + 2);

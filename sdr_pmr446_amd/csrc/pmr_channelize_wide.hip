@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_fft_disc(pmr_chan_params q, const cf *_
             const cf pv = Y[f * M + k], cu = Y[(f + 1) * M + k];
             const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
             const unsigned t = row0 + f;                         // frame relative to frame0
-            q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = pmr_arg(im, re) * q.fm_ref;
+            q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask & PMR_EXP_ROW_AND) * M + k] = pmr_arg(im, re) * q.fm_ref;
             if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
         }
     }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, PF_MINB) void k_channelize_fused256(pmr_chan_p
             if (f < nnew) {
                 const float re = fmaf(pv.x, cu.x, pv.y * cu.y), im = fmaf(pv.x, cu.y, -(pv.y * cu.x));
                 const unsigned t = R0 + f;
-                q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask) * M + k] = pmr_arg(im, re) * q.fm_ref;
+                q.fm[((unsigned long long)(q.frame0 + t) & q.fm_mask & PMR_EXP_ROW_AND) * M + k] = pmr_arg(im, re) * q.fm_ref;
                 if (chan_out) chan_out[(size_t)k * q.chan_stride + t] = cu;
             }
             pv = cu;

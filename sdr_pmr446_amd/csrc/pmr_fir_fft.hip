@@ -317,7 +317,7 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
     };
     {
         // one base pointer per row and thread; the 16 stores of a row are base + n0 N0 (compile-time offsets)
-        const long relt = (long)rel0 + (long)t;
+        const long relt = ((long)rel0 + (long)t) & PMR_EXP_PCM_AND;
         int16_t *pa = P.pcm ? P.pcm + (size_t)ca * P.stride + relt : nullptr, *pb = P.pcm ? P.pcm + (size_t)cb * P.stride + relt : nullptr;
         float *aa = P.audio ? P.audio + (size_t)ca * P.stride + relt : nullptr, *ab = P.audio ? P.audio + (size_t)cb * P.stride + relt : nullptr;
 #pragma unroll

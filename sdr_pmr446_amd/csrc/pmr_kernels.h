@@ -286,6 +286,15 @@ int pmr_debug_poison_lds(pmr_stream_t s);
 #endif
 
 #if defined(__HIPCC__)
+/* timing experiment (tools/ab_libs.py, -DEXP_BE_WIN): the back end's global STORES land in small windows (discriminator rows & 63, PCM
+ * positions & 1023): what do the back end's write streams cost the chain?  WRONG results */
+#ifdef EXP_BE_WIN
+#define PMR_EXP_ROW_AND 63ull
+#define PMR_EXP_PCM_AND 1023l
+#else
+#define PMR_EXP_ROW_AND (~0ull)
+#define PMR_EXP_PCM_AND (~0l)
+#endif
 /* every kernel launch of the library goes through here (poison mode above; otherwise exactly hipLaunchKernelGGL) */
 #define PMR_KLAUNCH(kern, grid, block, lds, st, ...)                                                                               \
     do {                                                                                                                           \
