@@ -1356,9 +1356,11 @@ static int ctcss_run(pmr_chain q, int64_t frame0, unsigned ns, int fir_done /*th
         HIPCHK(hipStreamWaitEvent(q->stream, q->ev_ct[q->ct_last_par], 0), "wait detector");
     }
     /* (k_ct_final writes every open channel's carry for the next call, zeros when the call ends on a block boundary) */
+#ifndef EXP_SKIP_CT     /* timing experiment: the low-pass branch is produced, the detector's kernels never run.  WRONG results */
     LAUNCH_ON(sct, K_CT_GOERTZEL, pmr_launch_ct_detector(sct, q->d_ctlp, q->fm_mask, frame0, ns, M, N, a1, q->d_ct_lampow, q->d_ct_dcstate,
                                                  q->d_ct_agg, q->d_ct_W, q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[cur],
                                                  q->d_ct_carry[nxt], q->d_ct_events, q->d_ct_restart, nblk, ncomplete, sel, q->n_enabled));
+#endif
     q->ct_masked_last = q->mask_on;
     if (q->mask_on) memcpy(q->ct_open_last, q->h_open, M);
     if (async) {
