@@ -48,6 +48,9 @@ _ORDER = [
     ("test_gpu_carry.py", 12),
     ("test_gpu_pipelined.py", 13),
     ("test_gpu_synth.py", 14),
+    ("test_gpu_streams.py", 14),                                # the streams the other ranks of bench.py --gpus N run (cfg4)
+    ("test_seek.py", 16),                                       # counters beyond 2^32
+    ("test_gpu_device.py", 16),
     ("test_gpu_hostpath.py::test_integer_ingest", 50),           # f4
     ("test_gpu_hostpath.py::test_sync_integer", 50),
     ("test_gpu_hostpath.py::test_two_step", 20),                # f1: the call split where the squelch sits

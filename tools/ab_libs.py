@@ -22,7 +22,10 @@ def leg(args):
     fs, M = WORK[args.leg]
     lb, rot = args.log2_block, 4
     block = 1 << lb
-    ch = chain.PmrChain(fs_in=fs, num_channels=M, max_block=block)
+    ch = chain.PmrChain(fs_in=fs, num_channels=M, max_block=block, resamp_As=args.resamp_as)
+    if args.show_plan:
+        sys.stderr.write("%s resamp_As %.1f: front-end plan %d (0 staged, 1 generic tile kernel, 2 specialised one level, 3 two levels specialised, "
+                         "4 two levels generic), stages m = %s\n" % (args.leg, args.resamp_as, ch.info(8), [ch.info(1, i) for i in range(ch.info(0))]))
     if args.ctcss:
         ch.ctcss_enable()
     if args.one_open:
@@ -56,6 +59,9 @@ def main():
     ap.add_argument("--env", default="")
     ap.add_argument("--ctcss", action="store_true")
     ap.add_argument("--one-open", action="store_true")
+    ap.add_argument("--resamp-as", type=float, default=60.0, help="msresamp stop-band (60 = the reference, :426); another value designs "
+                    "another cascade: what the plans that miss the specialised kernels cost (SURVEY A.3 risk)")
+    ap.add_argument("--show-plan", action="store_true")
     ap.add_argument("--leg", default=None)
     args = ap.parse_args()
     if args.leg:
@@ -76,13 +82,16 @@ def main():
                 else:
                     env.pop("PMR_LIBRARY", None)
                 cmd = [sys.executable, os.path.abspath(__file__), "--leg", w, "--regions", str(args.regions), "--steps", str(args.steps),
-                       "--log2-block", str(args.log2_block)] + (["--ctcss"] if args.ctcss else []) + (["--one-open"] if args.one_open else [])
+                       "--log2-block", str(args.log2_block), "--resamp-as", str(args.resamp_as)] + (["--ctcss"] if args.ctcss else []) + \
+                      (["--one-open"] if args.one_open else []) + (["--show-plan"] if args.show_plan else [])
                 r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
                 try:
                     v = float(r.stdout.split()[0])
                 except Exception:
                     v = float("nan")
                     sys.stderr.write("leg %s/%s failed: %s\n" % (name, w, (r.stderr or r.stdout)[-300:]))
+                if args.show_plan and rep == 0:
+                    sys.stderr.write(r.stderr)
                 res.setdefault((name, w), []).append(v)
     print("%-14s" % "build" + "".join("%26s" % w for w in works))
     for name, _ in libs:
