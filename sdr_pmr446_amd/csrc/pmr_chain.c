@@ -86,7 +86,7 @@ struct pmr_chain_s {
     float *d_hp_pad, *d_lp_pad, *d_de_pad;
     unsigned hp_len, lp_len, de_len;
     /* overlap-save FFT form of the audio FIR (pmr_fir_fft.hip): device tables per transform size (0: 1024, 1: 4096 points) */
-    int fft_ok; pmr_fir_fft_tab fft_tab[2]; float *d_fft_H[2], *d_fft_H2[2], *d_fft_TA[2], *d_fft_TB[2];
+    int fft_ok; pmr_fir_fft_tab fft_tab[3]; float *d_fft_H[3], *d_fft_H2[3], *d_fft_TA[3], *d_fft_TB[3];   /* per transform size (0: 1024, 1: 4096, 2: 2048 points) */
     pmr_dc_consts dcc;
 
     /* carried state / work buffers on the device */
@@ -250,7 +250,7 @@ static int fir_fft_init(pmr_chain q, const float *g, unsigned n)
     q->fft_ok = 0;
     if (q->sw.fir_direct || q->cfg.deemph_fir || q->cfg.lowpass || !pmr_fir_fft_supported(q->M, n))
         return PMR_OK;
-    for (int w = 0; w < 2; w++) {
+    for (int w = 0; w < 3; w++) {
         const unsigned N = pmr_fir_fft_size(w);
         int rc = fir_fft_upload_spectrum(q, &q->d_fft_H[w], N, g, n);
         if (rc) return rc;
@@ -275,10 +275,26 @@ static int fir_fft_init(pmr_chain q, const float *g, unsigned n)
  * compiled in and selected by PMR_FIR=fft4096 only (a run-time switch, read at create: tests/test_gpu_fir_fft.py runs both sizes;
  * round 4's compile-time threshold lived in this C file, where the tools' -D flags for hipcc never reached it).
  * Returns -1 (direct), 0 (1024 points) or 1 (4096 points). */
-static int fir_fft_pick(const struct pmr_chain_s *q, unsigned ns, unsigned nchan)
+static int fir_fft_pick(const struct pmr_chain_s *q, unsigned ns, unsigned nchan, int dual)
 {
     if (!q->fft_ok || (unsigned long long)ns * nchan < (1ull << 17)) return -1;
-    const int which = q->sw.fir_fft4096 ? 1 : 0;
+    /* Transform size: 2048 points (two-wave workgroups, 18.4 KB of LDS: still fits beside four front-end tiles) where that takes at
+     * least 15 % fewer transform points than 1024 (82 % instead of 63 % of a block is output): every 2^22+-sample block of cfg2 / cfg3;
+     * 1024 points where the call's frame count leaves a 2048-point block half empty (cfg5: 838 frames = two 1024-point blocks or ONE
+     * 2048-point block).  Six interleaved repetitions on one box (profiles/r05_ab_log.txt r5i): cfg2 452.4 vs 444.1 GS/s (+1.9 %, 6 of 6),
+     * cfg3 456.3 vs 453.9 (+0.5 %); cfg5 with 2048 points forced: -1.5 %.  PMR_FIR=fft1024 / fft2048 / fft4096 force a size. */
+    int which = 0;
+    {
+        const unsigned long long T = q->hp_len - 1u;
+        const unsigned long long n0 = ((unsigned long long)ns + (1024ull - T) - 1ull) / (1024ull - T) * 1024ull;
+        const unsigned long long n2 = ((unsigned long long)ns + (2048ull - T) - 1ull) / (2048ull - T) * 2048ull;
+        /* (DUAL -- the CTCSS low-pass branch as second product -- doubles the workgroup's LDS: 36.8 KB at 2048 points no longer fits
+         *  beside four front-end tiles; measured r5i) */
+        if (n2 * 100ull <= n0 * 85ull && !dual) which = 2;
+    }
+    if (q->sw.fir_fft1024) which = 0;
+    if (q->sw.fir_fft2048) which = 2;
+    if (q->sw.fir_fft4096) which = 1;
     /* the kernel indexes the discriminator ring and its grid with 32-bit arithmetic (pmr_launch_fir_fft re-checks the same limits):
      * a plan beyond them takes the direct form HERE, before anything is launched -- a launch-time refusal would come in the middle
      * of a block and fault the handle on every large block */
@@ -752,6 +768,8 @@ static void read_switches(pmr_switches *w)
     memset(w, 0, sizeof(*w));
     w->fir_direct = env_is("PMR_FIR", "direct");
     w->fir_fft4096 = env_is("PMR_FIR", "fft4096");
+    w->fir_fft2048 = env_is("PMR_FIR", "fft2048");
+    w->fir_fft1024 = env_is("PMR_FIR", "fft1024");
     w->no_overlap = env_is("PMR_OVERLAP", "0");
     w->carry_inplace = env_is("PMR_CARRY", "inplace");
     w->no_zerocopy = env_is("PMR_ZEROCOPY", "0");
@@ -880,7 +898,8 @@ int pmr_chain_destroy(pmr_chain q)
                      q->d_fe_V[1], q->d_fe_V[2], q->d_fe_G12, q->d_fe_GAK, q->d_fe_ring1, q->d_fe_tile_j, q->d_fe_rho_pow, q->d_ctlp, q->d_ct_taps, q->d_ct_taps_ext, q->d_ct_lampow, q->d_ct_agg, q->d_ct_W, q->d_ct_dcstate,
                      q->d_ct_U, q->d_ct_coef, q->d_ct_part, q->d_ct_carry[0], q->d_ct_carry[1], q->d_ct_events, q->d_ct_restart,
                      q->d_spec_win, q->d_spec_tw, q->d_spec_part, q->d_spec_psd, q->d_fe_G1,
-                     q->d_fft_H[0], q->d_fft_H[1], q->d_fft_H2[0], q->d_fft_H2[1], q->d_fft_TA[0], q->d_fft_TA[1], q->d_fft_TB[0], q->d_fft_TB[1] };
+                     q->d_fft_H[0], q->d_fft_H[1], q->d_fft_H2[0], q->d_fft_H2[1], q->d_fft_TA[0], q->d_fft_TA[1], q->d_fft_TB[0], q->d_fft_TB[1],
+                     q->d_fft_H[2], q->d_fft_H2[2], q->d_fft_TA[2], q->d_fft_TB[2] };
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) if (bufs[i]) hipFree(bufs[i]);
     for (unsigned i = 0; i < PIPE_DEPTH; i++) {
         pmr_slot *sl = &q->slot[i];
@@ -1480,7 +1499,7 @@ int pmr_chain_ctcss_enable(pmr_chain q, int on)
             else {
                 memcpy(te, tc, n * sizeof(float));
                 rc = upload_padded_taps(q, &q->d_ct_taps_ext, te, q->hp_len);
-                for (int w = 0; w < 2 && !rc && q->fft_ok; w++) {      /* the low-pass branch as the FFT form's second product */
+                for (int w = 0; w < 3 && !rc && q->fft_ok; w++) {      /* the low-pass branch as the FFT form's second product */
                     rc = fir_fft_upload_spectrum(q, &q->d_fft_H2[w], pmr_fir_fft_size(w), te, q->hp_len);
                     q->fft_tab[w].H2 = q->d_fft_H2[w];
                 }
@@ -1576,7 +1595,7 @@ static int audio_part(pmr_chain q, int64_t frame0, unsigned ns, void *d_pcm, voi
     {
         /* large blocks: overlap-save FFT form (pmr_fir_fft.hip); with the detector on its low-pass branch is the second product */
         const int dual = q->ct_on && q->fft_ok && q->fft_tab[0].H2 != NULL;
-        const int which = (d_pcm || d_audio) && (!q->ct_on || dual) ? fir_fft_pick(q, ns, q->mask_on ? q->n_enabled : M) : -1;
+        const int which = (d_pcm || d_audio) && (!q->ct_on || dual) ? fir_fft_pick(q, ns, q->mask_on ? q->n_enabled : M, dual) : -1;
         if (which >= 0) {
             LAUNCH(K_FIR_HP, pmr_launch_fir_fft(q->stream, which, &q->fft_tab[which], q->d_fm, q->fm_mask, frame0, ns, M, q->hp_len,
                                                 (int16_t *)d_pcm, (float *)d_audio, pcm_stride, dual ? q->d_ctlp : NULL,

@@ -130,6 +130,24 @@ static __device__ __forceinline__ void r16(cf2 (&v)[16])
     for (int c = 0; c < 4; c++) r4<INV>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   // over b: v[4 c + d] = X[c + 4 d]
 }
 
+// 8-point DFT in place, natural order in AND out: evens / odds by two 4-point DFTs, odd half times W8^k (conjugated for the inverse)
+template <bool INV>
+static __device__ __forceinline__ void r8(cf2 (&v)[8])
+{
+    constexpr float RH = 0.70710678118654752f;
+    const float sg = INV ? 1.f : -1.f;
+    cf2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    r4<INV>(e0, e1, e2, e3);
+    r4<INV>(o0, o1, o2, o3);
+    o1 = cmulk(o1, mk2(RH, sg * RH));
+    o2 = INV ? jtimes(o2) : -jtimes(o2);                             // W8^2 = -j (forward)
+    o3 = cmulk(o3, mk2(-RH, sg * RH));
+    v[0] = e0 + o0; v[4] = e0 - o0;
+    v[1] = e1 + o1; v[5] = e1 - o1;
+    v[2] = e2 + o2; v[6] = e2 - o2;
+    v[3] = e3 + o3; v[7] = e3 - o3;
+}
+
 struct ff_params {
     const float *in; unsigned long long row_mask; long long row0; unsigned ns, M;
     const cf2 *H, *H2;                 // [N] spectra of the taps / N, POSITION order (pmr_fir_fft_tables)
@@ -164,6 +182,26 @@ static __device__ __forceinline__ void ff_phase_c(cf2 *zs, cf2 *zs2, const cf2 *
         r16<true>(w);
 #pragma unroll
         for (int n2 = 0; n2 < 16; n2++) zs[FF_IDX(16 * t + n2)] = w[R16P(n2)];
+    } else if constexpr (R2 == 8) {                                // N = 2048: two runs of 8 per thread (combo c = t + 128 j)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const unsigned c = t + 128u * j;
+            cf2 u[8];
+#pragma unroll
+            for (int n2 = 0; n2 < 8; n2++) u[n2] = src[FF_IDX(8 * c + n2)];
+            if constexpr (PARK) {
+                r8<false>(u);
+                if constexpr (DUAL) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; k2++) zs2[FF_IDX(8 * c + k2)] = u[k2];
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) u[k2] = cmul(u[k2], Hp[8 * c + k2]);
+            r8<true>(u);
+#pragma unroll
+            for (int n2 = 0; n2 < 8; n2++) zs[FF_IDX(8 * c + n2)] = u[n2];
+        }
     } else {
         static_assert(R2 == 4, "radix of the last phase");
 #pragma unroll
@@ -353,7 +391,7 @@ __global__ __launch_bounds__(16 * R2) void k_fir_fft(const ff_params P)
 
 // ---- host side: the tables of one transform size, in double ----
 // H[p] (position order): p = k0 N0 + k1 R2 + k2  <->  bin k = k0 + 16 k1 + 256 k2;  H[p] = (1/N) sum_d h[d] e^(-j 2 pi k d / N)
-extern "C" unsigned pmr_fir_fft_size(int which) { return which ? 4096u : 1024u; }
+extern "C" unsigned pmr_fir_fft_size(int which) { return which == 1 ? 4096u : which == 2 ? 2048u : 1024u; }
 
 extern "C" void pmr_fir_fft_spectrum(unsigned N, const float *h, unsigned ntaps, float *H_out /*[2 N]*/)
 {
@@ -390,7 +428,7 @@ extern "C" int pmr_fir_fft_supported(unsigned M, unsigned ntaps)
     return M >= 1 && ntaps >= 2 && ntaps <= 512;                   // >= half of the smallest transform stays output
 }
 
-// which: 0 = N 1024, 1 = N 4096.  tab: the device tables of that size.
+// which: 0 = N 1024, 1 = N 4096, 2 = N 2048.  tab: the device tables of that size.
 extern "C" int pmr_launch_fir_fft(pmr_stream_t s, int which, const pmr_fir_fft_tab *tab, const float *in, uint64_t row_mask, int64_t row0,
                                   unsigned ns, unsigned M, unsigned ntaps, int16_t *pcm, float *audio, unsigned stride,
                                   float *out2_tm, const unsigned *chan_list, unsigned n_chan)
@@ -399,7 +437,7 @@ extern "C" int pmr_launch_fir_fft(pmr_stream_t s, int which, const pmr_fir_fft_t
     const unsigned nc = chan_list ? n_chan : M;
     if (!nc) return 0;
     if (!tab || !tab->H || !tab->TA || !tab->TB || (out2_tm && !tab->H2)) return (int)hipErrorInvalidValue;
-    const unsigned N = which ? 4096u : 1024u, L = N - (ntaps - 1);
+    const unsigned N = pmr_fir_fft_size(which), L = N - (ntaps - 1);
     ff_params P;
     P.in = in; P.row_mask = (unsigned long long)row_mask; P.row0 = (long long)row0; P.ns = ns; P.M = M;
     P.H = (const cf2 *)tab->H; P.H2 = (const cf2 *)tab->H2; P.TA = (const cf2 *)tab->TA; P.TB = (const cf2 *)tab->TB;
@@ -413,13 +451,16 @@ extern "C" int pmr_launch_fir_fft(pmr_stream_t s, int which, const pmr_fir_fft_t
     const dim3 grid((unsigned)units);
     const size_t buf = (size_t)(N + N / 16) * sizeof(cf2), tbb = (size_t)(N / 256) * 16 * sizeof(cf2);
     hipStream_t st = (hipStream_t)s;
-    if (which) {
+    if (which == 1) {
         if (out2_tm) {
             static pmr_attr_flags once;
             if (pmr_attr_needed(once))
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_fft<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             PMR_KLAUNCH((k_fir_fft<16, true>), grid, dim3(256), 2 * buf + tbb, st, P);
         } else PMR_KLAUNCH((k_fir_fft<16, false>), grid, dim3(256), buf + tbb, st, P);
+    } else if (which == 2) {
+        if (out2_tm) PMR_KLAUNCH((k_fir_fft<8, true>), grid, dim3(128), 2 * buf + tbb, st, P);
+        else PMR_KLAUNCH((k_fir_fft<8, false>), grid, dim3(128), buf + tbb, st, P);
     } else {
         if (out2_tm) PMR_KLAUNCH((k_fir_fft<4, true>), grid, dim3(64), 2 * buf + tbb, st, P);
         else PMR_KLAUNCH((k_fir_fft<4, false>), grid, dim3(64), buf + tbb, st, P);

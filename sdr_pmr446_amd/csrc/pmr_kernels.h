@@ -18,6 +18,8 @@ typedef void *pmr_stream_t;     /* hipStream_t */
  * All zero = the product. */
 typedef struct {
     int fir_direct;         /* PMR_FIR=direct: the direct (MFMA) form of the audio FIR for every block (default: FFT form for large blocks) */
+    int fir_fft1024, fir_fft2048;   /* PMR_FIR=fft1024 / fft2048: force the 1024- / 2048-point kernels (the plan picks between the two by the call's
+                               frame count, fir_fft_pick) -- A/B and tests */
     int fir_fft4096;        /* PMR_FIR=fft4096: the FFT form's 4096-point kernels (256 threads, 35 / 71 KB of LDS) wherever the FFT form runs
                                -- the variant that lost its A/B in the chain (r04_ab_log.txt) but is compiled in: tests run it */
     int no_overlap;         /* PMR_OVERLAP=0: single-stream calls (also pmr_chain_set_overlap)                */

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _chain(form, **kw):
-    """form: None = the product's choice (1024-point FFT form on large blocks), "direct", "fft4096" (PMR_FIR, read once at create)."""
+    """form: None = the product's choice (FFT form on large blocks), "direct", "fft1024", "fft2048", "fft4096" (PMR_FIR, read once at create)."""
     from sdr_pmr446_amd import chain
     old = os.environ.get("PMR_FIR")
     if form:
@@ -64,9 +64,17 @@ CASES = [
     (CFG2, [1 << 21, (1 << 20) + 12345, 786433], None, None, "fft4096"),
     (CFG2, [(1 << 22) + 999], None, [5, 12, 13], "fft4096"),
     (CFG3, [1 << 24], None, None, "fft4096"),
+    # the 2048-point kernels (PMR_FIR=fft2048: 128 threads, 18 KB of LDS)
+    (CFG2, [1 << 21, (1 << 20) + 12345, 786433], None, None, "fft2048"),
+    (CFG2, [(1 << 22) + 999], None, [5, 12, 13], "fft2048"),
+    (CFG3, [1 << 24], None, None, "fft2048"),
+    (CFG5, [1 << 24, 1 << 24], None, None, "fft2048"),
+    # ... and the 1024-point kernels forced where the plan now picks 2048 points
+    (CFG2, [1 << 21, (1 << 20) + 12345, 786433], None, None, "fft1024"),
+    (CFG3, [1 << 24], None, None, "fft1024"),
 ]
 IDS = ["cfg2-ragged", "cfg2-three-open", "cfg2-one-open", "cfg3-two-calls", "cfg3-one-call", "cfg5",
-       "cfg2-ragged-4096pt", "cfg2-three-open-4096pt", "cfg3-4096pt"]
+       "cfg2-ragged-4096pt", "cfg2-three-open-4096pt", "cfg3-4096pt", "cfg2-ragged-2048pt", "cfg2-three-open-2048pt", "cfg3-2048pt", "cfg5-2048pt", "cfg2-ragged-1024pt", "cfg3-1024pt"]
 
 
 @pytest.mark.parametrize("cfg,splits,ks,open_ch,form", CASES, ids=IDS)
@@ -100,8 +108,9 @@ def test_fft_form_equals_direct_form_and_oracle(cfg, splits, ks, open_ch, form):
         assert np.abs(fft["pcm"][chans].astype(np.int32) - po[chans].astype(np.int32)).max() <= 1
 
 
-@pytest.mark.parametrize("open_ch,form", [(None, None), ([2, 5, 11], None), (None, "fft4096"), ([2, 5, 11], "fft4096")],
-                         ids=["all", "three-open", "all-4096pt", "three-open-4096pt"])
+@pytest.mark.parametrize("open_ch,form", [(None, None), ([2, 5, 11], None), (None, "fft4096"), ([2, 5, 11], "fft4096"), (None, "fft2048"),
+                                          ([2, 5, 11], "fft2048"), (None, "fft1024")],
+                         ids=["all", "three-open", "all-4096pt", "three-open-4096pt", "all-2048pt", "three-open-2048pt", "all-1024pt"])
 def test_fft_form_with_the_ctcss_branch_as_second_product(open_ch, form):
     """Detector on: the low-pass branch delay188(x) - hp(x) (:884-889) leaves the same forward transform as a second product.
     Branch samples against the direct DUAL pass and the oracle; the detector's events on top of it against the oracle's."""

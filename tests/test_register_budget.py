@@ -20,6 +20,7 @@ BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, w
     ("pmr_fe_fast.hip", r"k_fe_fastILi1E", 64, "level 1 of the two-level front end"),
     ("pmr_fe_fast.hip", r"k_fe_level2", 80, "level 2 runs beside four level-1 tiles"),
     ("pmr_fir_fft.hip", r"k_fir_fftILi4ELb0E", 128, "FFT form of the audio FIR (1024 points): one-wave workgroups, four per SIMD, beside four front-end tiles"),
+    ("pmr_fir_fft.hip", r"k_fir_fftILi8ELb0E", 128, "FFT form of the audio FIR (2048 points): two-wave workgroups beside four front-end tiles"),
     ("pmr_fir_mfma4.hip", r"k_fir_mfma4ILb0ELb0ELb0E", 64, "128-frame audio FIR: four workgroups per CU"),
     ("pmr_channelize_small.hip", r"k_channelize_winILi16ELi26ELb1ELi16E", 88, "16-channel bank: a wave fits beside four front-end tiles with room to spare"),
     ("pmr_channelize_wide.hip", r"k_channelize_fused256ILb1E", 128, "256-channel bank: four waves per SIMD"),

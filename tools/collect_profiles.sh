@@ -11,7 +11,7 @@ rm -rf $O; mkdir -p $O
 python3 $R/sdr_pmr446_amd/build.py --kernel-hash > $O/kernel_sources.sha256
 cd /tmp && export TMPDIR=/tmp
 [ -n "$SKIP_BENCH" ] || python3 $R/bench.py 2>/dev/null | grep '^{' > $O/bench.json
-B="--also none --regions 2 --steps 50 --warmup 2 --no-cpu-baseline --no-kernel-events --parity-blocks 0 --no-one-open"
+B="--also none --regions 2 --steps 50 --warmup 2 --no-cpu-baseline --no-host-io --no-kernel-events --parity-blocks 0 --no-one-open"
 for W in ${WORKLOADS:-cfg5 cfg3 cfg2}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 $R/bench.py --workload $W $B > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$W -- python3 $R/bench.py --workload $W $B > /dev/null 2>&1
@@ -25,7 +25,7 @@ done
 unset PMR_OVERLAP
 # two ranks on this one GPU (gloo for the barrier / max): the N > 1 code path of bench.py for the record -- NOT a scaling figure
 [ -n "$SKIP_BENCH" ] || python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 2 \
-    --dist-backend gloo --no-cpu-baseline --regions 5 2>/dev/null | grep '^{' > $O/bench_2rank_1gpu.json
+    --dist-backend gloo --no-cpu-baseline --no-host-io --regions 5 2>/dev/null | grep '^{' > $O/bench_2rank_1gpu.json
 # keep the merged-back payload small: only this library's kernels
 for f in $(find $O -name '*_kernel_trace.csv' -o -name '*_counter_collection.csv'); do
   (head -1 $f; grep -E 'k_frontend|k_fe_|k_channelize|k_pfb|k_fft|k_fir|k_rssi|k_ct_|k_dsd|k_iq|k_poison' $f) > $f.trim; mv $f.trim $f

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): bash tools/ctcss_bench.sh [workload] : chain with the CTCSS detector on -- all channels / one open channel, isolated kernel times
-python3 bench.py --workload ${1:-cfg2} --also none --no-cpu-baseline --regions 7 --parity-blocks 0 --ctcss 2>&1 | python3 -c "
+python3 bench.py --workload ${1:-cfg2} --also none --no-cpu-baseline --no-host-io --regions 7 --parity-blocks 0 --ctcss 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

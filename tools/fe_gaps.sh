@@ -3,7 +3,7 @@
 # the pipelined loop, from a rocprofv3 kernel trace -- what a kernel boundary on the front-end stream costs per step
 R=${GRAFT_REPO_ROOT:-$(pwd)}; W=${1:-cfg5}; O=/tmp/feg_$$; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --workload $W --also none --regions 2 --steps 100 --warmup 3 --no-cpu-baseline --no-kernel-events --parity-blocks 0 --no-one-open > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O -- python3 $R/bench.py --workload $W --also none --regions 2 --steps 100 --warmup 3 --no-cpu-baseline --no-host-io --no-kernel-events --parity-blocks 0 --no-one-open > $O/bench.log 2>&1
 python3 - $O $W <<'PY'
 import csv, glob, sys
 path = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]

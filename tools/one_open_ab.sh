@@ -3,7 +3,7 @@
 W=$1; shift
 for E in "$@"; do
   echo "== $E"
-  env $E python3 bench.py --workload $W --also none --no-cpu-baseline --regions 7 --parity-blocks 0 $BENCH_ARGS 2>&1 | python3 -c "
+  env $E python3 bench.py --workload $W --also none --no-cpu-baseline --no-host-io --regions 7 --parity-blocks 0 $BENCH_ARGS 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

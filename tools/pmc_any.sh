@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; W=$1; K=$2; shift 2; O=$R/gpurun_out/pmcany; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export PMR_OVERLAP=0
-B="--workload $W --also none --regions 1 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --parity-blocks 0"
+B="--workload $W --also none --regions 1 --steps 3 --warmup 1 --no-cpu-baseline --no-host-io --no-kernel-events --parity-blocks 0"
 i=0
 for C in "$@"; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/p$i -- python3 $R/bench.py $B > /dev/null 2>&1

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; W=${1:-cfg2}; shift; O=$R/gpurun_out/pmci; rm -rf 
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp
 export PMR_OVERLAP=0
-B="--workload $W --also none --regions 1 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events --parity-blocks 0"
+B="--workload $W --also none --regions 1 --steps 3 --warmup 1 --no-cpu-baseline --no-host-io --no-kernel-events --parity-blocks 0"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $O/a -- python3 $R/bench.py $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_FLAT --output-format csv -d $O/b -- python3 $R/bench.py $B > /dev/null 2>&1
 python3 - <<'PY'

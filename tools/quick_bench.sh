@@ -1,5 +1,5 @@
 # usage: gpurun -- 'bash tools/quick_bench.sh [workload]'
-python3 bench.py --workload ${1:-cfg2} --also none --no-cpu-baseline --regions 5 --parity-blocks 0 2>&1 | python3 -c "
+python3 bench.py --workload ${1:-cfg2} --also none --no-cpu-baseline --no-host-io --regions 5 --parity-blocks 0 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

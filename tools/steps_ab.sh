@@ -3,7 +3,7 @@
 W=${1:-cfg5}
 for K in ${STEPS:-20 100 400}; do for EV in "" "--no-kernel-events"; do
   echo "== steps $K $EV"
-  python3 bench.py --workload $W --also none --no-cpu-baseline --regions 9 --steps $K --parity-blocks 0 $EV 2>&1 | python3 -c "
+  python3 bench.py --workload $W --also none --no-cpu-baseline --no-host-io --regions 9 --steps $K --parity-blocks 0 $EV 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

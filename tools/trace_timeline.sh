@@ -2,7 +2,7 @@
 # usage (GPU box): bash tools/trace_timeline.sh <workload> -> gpurun_out/tl_<workload>.txt : kernel timeline of steady-state steps + per-kernel stats
 R=${GRAFT_REPO_ROOT:-$(pwd)}; W=${1:-cfg5}; O=$R/gpurun_out/tl_$W; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --workload $W --also none --regions 2 --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-events --parity-blocks 0 > $O/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --workload $W --also none --regions 2 --steps 40 --warmup 3 --no-cpu-baseline --no-host-io --no-kernel-events --parity-blocks 0 > $O/bench.log 2>&1
 python3 $R/tools/timeline.py $O > $R/gpurun_out/tl_$W.txt 2>&1
 python3 - $O >> $R/gpurun_out/tl_$W.txt <<'PY'
 import csv, glob, sys

@@ -10,7 +10,7 @@ for F in "$@"; do
   if ! PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" PMR_CC_FLAGS="$CCF" python3 sdr_pmr446_amd/build.py --force > /tmp/variant_build.log 2>&1; then
     echo "BUILD FAILED for flags: $F"; grep -m3 -E "error" /tmp/variant_build.log; continue
   fi
-  python3 bench.py --workload $W --also none --no-cpu-baseline --regions 5 --parity-blocks 0 2>&1 | python3 -c "
+  python3 bench.py --workload $W --also none --no-cpu-baseline --no-host-io --regions 5 --parity-blocks 0 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
