@@ -418,7 +418,11 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
             const long long jn = b0 + i;
             float4 w = v[k];
             if (jn + 1 >= (long long)p.n_in) { w.z = 0.f; w.w = 0.f; }    // the pair's second sample lies beyond the block
+#ifdef EXP_L2_NOFIX      /* timing experiment: level 2 without its carry arithmetic / table loads.  WRONG results */
+            if (false) {
+#else
             if (V1 && jn + 1 >= 0 && jn < (long long)p.fix_limit) {       // the pair touches the range level 2 corrects
+#endif
                 unsigned c1, r;
                 locate((unsigned)(jn < 0 ? 0 : jn), c1, r);
                 if (jn >= 0) {
@@ -433,6 +437,9 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
         }
     }
     __syncthreads();
+#ifdef EXP_L2_STOP1      /* timing experiment: level 2 = loads + staging only */
+    if (p.n_in != 0xffffffffu) return;
+#endif
     hb_stage_ip<4, 5>(R0, tid, NT, p.taps_k, 1.0f);                        // 1024 outputs, L(8) -> L(4), in place
     hb_stage_ip<2, 10>(R0, tid, NT, p.taps_k + 10, p.zeta);                //  512 outputs, L(4) -> L(2), in place
     fe_arb_store<NT, 1>(p, ap, qa, R0, bk0, bk1, tid);
