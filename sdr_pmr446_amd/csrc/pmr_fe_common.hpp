@@ -192,7 +192,11 @@ static __device__ __forceinline__ fe_arb_plan fe_arb_prepare(const pmr_fe_params
     fe_arb_plan a;
     const fe_jrange r = fe_tile_outputs(p, qa);
     a.ja = r.ja; a.jb = r.jb;
+#ifdef FE_NO_PAIRS      /* experiment: one output per thread even in tiles with more outputs than threads (the rest in the slow leftover loop) */
+    a.pairs = false;
+#else
     a.pairs = a.jb - a.ja > (unsigned long long)NT;
+#endif
     a.jh = a.pairs ? a.ja + ((p.out_pos0 + a.ja) & 1ull) : a.ja;
     a.j0 = a.pairs ? a.jh + 2ull * tid : a.ja + tid;
     a.npts = a.pairs ? (a.j0 + 1 < a.jb ? 2 : (a.j0 < a.jb ? 1 : 0)) : (a.j0 < a.jb ? 1 : 0);
