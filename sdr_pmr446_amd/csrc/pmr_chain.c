@@ -289,8 +289,9 @@ static int fir_fft_pick(const struct pmr_chain_s *q, unsigned ns, unsigned nchan
         const unsigned long long n0 = ((unsigned long long)ns + (1024ull - T) - 1ull) / (1024ull - T) * 1024ull;
         const unsigned long long n2 = ((unsigned long long)ns + (2048ull - T) - 1ull) / (2048ull - T) * 2048ull;
         /* (DUAL -- the CTCSS low-pass branch as second product -- doubles the workgroup's LDS: 36.8 KB at 2048 points no longer fits
-         *  beside four front-end tiles; measured r5i) */
-        if (n2 * 100ull <= n0 * 85ull && !dual) which = 2;
+         *  beside four front-end tiles: with many open channels -2.3 % at cfg2, with ONE open channel -- a handful of workgroups, the
+         *  reference's mode -- +1.6 %; measured r5i) */
+        if (n2 * 100ull <= n0 * 85ull && (!dual || nchan <= 2)) which = 2;
     }
     if (q->sw.fir_fft1024) which = 0;
     if (q->sw.fir_fft2048) which = 2;
