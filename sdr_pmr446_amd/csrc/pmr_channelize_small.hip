@@ -147,6 +147,9 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
         }
     }
     __syncthreads();
+#if defined(CW_STOP) && CW_STOP == 0      /* timing experiments (tools/ab_libs.py): the kernel up to a pass boundary.  WRONG results */
+    if (q.ns != 0xffffffffu) return;
+#endif
 
     // ---- pass 1: polyphase bank, X[f][brev(c)] ----
     {
@@ -177,6 +180,9 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
     }
     __syncthreads();
 
+#if defined(CW_STOP) && CW_STOP == 1
+    if (q.ns != 0xffffffffu) return;
+#endif
     // ---- pass 2: thread = local frame tid; FFT in registers ----
     const bool mine = NFT == CW_NT || tid < NFT;          // the first NFT threads own a frame
     cf Y[M];
@@ -197,6 +203,9 @@ __global__ __launch_bounds__(CW_NT, (CW_NT <= 256 ? 4 : CW_NT <= 512 ? 2 : 1)) v
             *reinterpret_cast<float4 *>(ex + c) = make_float4(Y[c].x, Y[c].y, Y[c + 1].x, Y[c + 1].y);
     }
     __syncthreads();
+#if defined(CW_STOP) && CW_STOP == 2
+    if (q.ns != 0xffffffffu) return;
+#endif
     const long tA = t0 - 1 + tid;                         // frame of this thread, relative to q.frame0
     const bool outA = tid > 0 && mine && tA < (long)ns;
     if (outA) {
