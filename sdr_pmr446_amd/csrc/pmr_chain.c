@@ -984,7 +984,7 @@ int pmr_chain_seek(pmr_chain q, uint64_t n_raw)
     q->n_raw = n_raw;
     q->arb_phase = (uint32_t)((unsigned __int128)ny * q->d.arb_step - span);
     q->xr_abs = ny;
-    q->frames_done = ny / q->M;
+    q->frames_done = q->M ? ny / q->M : 0;
     return PMR_OK;
 }
 

@@ -247,7 +247,7 @@ static __device__ __forceinline__ void ct_store_x(const ct_xregs &x, float *xs, 
     }
 }
 
-template <bool GATHER>
+// (every channel open: slot = channel cg + s of ONE block; an open-channel list runs k_ct_goertzel_pairs below)
 __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ lp, unsigned long long row_mask,
                                                      long long row0, unsigned ns, unsigned M, unsigned N,
                                                      const float *__restrict__ U /*[38][N+1], U[j][m+1] = U_m*/,
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
     __shared__ float s_lam[16];                                    // lambda^n, n <= 13 (a table read inside the serial carry loop below
     if (tid < 16) s_lam[tid] = lampow[tid];                        //  must not be a global load per step)
     const unsigned slot = cg + (tid & 15u);
-    const unsigned kch = slot < n_chan ? (GATHER ? chan_list[slot] : slot) : 0u;       // channel of this thread's slot (staging, carry)
+    const unsigned kch = slot < n_chan ? slot : 0u;                // channel of this thread's slot (staging, carry)
     // ---- U window of the full segment, once: weight of block position p is us[j][e_pos - p] (-> u0) and us[j][e_pos - p - 1] (-> u1);
     //      and the first block's samples: every load of the thread is in flight before the first is used ----
     ct_xregs xq;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
                 uv[jj][mm] = (j < PMR_CT_TONES && m <= wlen) ? U[(size_t)j * (N + 1) + (N - e_pos) + m] : 0.f;
             }
         }
-        ct_load_x<GATHER>(xq, lp, row_mask, M, sg, cg, n_chan, kch, tid, W, blk0 * PMR_CT_SEG + seg);
+        ct_load_x<false>(xq, lp, row_mask, M, sg, cg, n_chan, kch, tid, W, blk0 * PMR_CT_SEG + seg);
 #pragma unroll
         for (int jj = 0; jj < NJ; jj++) {
             const unsigned j = wave + (CG_T / 64) * jj;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
             }
         }
     }
-    ct_store_x<GATHER>(xq, xs, tid);
+    ct_store_x<false>(xq, xs, tid);
     float wv = xq.w;
     __syncthreads();
 
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
         const bool more = bi + 1 < nbw;
         if (more) {                                                // the next block's samples and state travel while this one is processed
             sg = ct_segment(b0 + blk + 1, seg, N, SL, row0, ns);
-            ct_load_x<GATHER>(xq, lp, row_mask, M, sg, cg, n_chan, kch, tid, W, gseg + PMR_CT_SEG);
+            ct_load_x<false>(xq, lp, row_mask, M, sg, cg, n_chan, kch, tid, W, gseg + PMR_CT_SEG);
         }
         // ---- dc blocker of ctcss_execute (:606), pass 3, on the staged samples in place: thread (slot, slice of CT_SUBG frames)
         // strings the zero-state aggregates of the slices before its own onto the segment's carried state W, then runs the exact
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
                 for (int qq = 0; qq < 4; qq++) {
                     const unsigned sl = cg + 4 * kk + qq;
                     if (sl < n_chan) {
-                        const unsigned k = GATHER ? chan_list[sl] : sl;
+                        const unsigned k = sl;
                         part[((size_t)gseg * M + k) * PMR_CT_TONES * 2 + c] = acc[qq];
                     }
                 }
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(CG_T) void k_ct_goertzel(const float *__restrict__ 
         }
         if (more) {
             __syncthreads();                                       // every reader of the staged segment is done
-            ct_store_x<GATHER>(xq, xs, tid);
+            ct_store_x<false>(xq, xs, tid);
             wv = xq.w;
             __syncthreads();
         }
@@ -640,7 +640,7 @@ extern "C" int pmr_launch_ct_detector(pmr_stream_t s, const float *lp, uint64_t 
         unsigned nb = (unsigned)(((unsigned long long)nblk * PMR_CT_SEG * ny + CG_SLOTS - 1) / CG_SLOTS);
         if (nb < 1) nb = 1;
         const dim3 grid(((nblk + nb - 1) / nb) * PMR_CT_SEG, ny);
-        PMR_KLAUNCH(k_ct_goertzel<false>, grid, dim3(CG_T), lds, st, lp, rm, (long long)row0, ns, M, N, U, part, b0, nblk, nb, chan_list, nc,
+        PMR_KLAUNCH(k_ct_goertzel, grid, dim3(CG_T), lds, st, lp, rm, (long long)row0, ns, M, N, U, part, b0, nblk, nb, chan_list, nc,
                            W, a1, lampow);
     }
 #endif

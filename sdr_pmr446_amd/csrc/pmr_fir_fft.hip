@@ -16,7 +16,9 @@
 // Formulation (one workgroup = one PAIR of channels x one block of N frames):
 //  * the taps are real, so TWO channels share one complex transform: z = x_a + j x_b, y = h * z = (h * x_a) + j (h * x_b) -- no
 //    untangling pass, H is the plain N-point spectrum of the taps;
-//  * N = 16 . 16 . R2 (R2 = 16: N = 4096, 256 threads; R2 = 4: N = 1024, 64 threads), 16 points per thread, three register
+//  * N = 16 . 16 . R2 (R2 = 4: N = 1024, 64 threads; R2 = 8: N = 2048, 128 threads, round 5; R2 = 16: N = 4096, 256 threads -- the host
+//    picks 2048 points where that needs >= 15 % fewer transform points than 1024 and the pass is not DUAL with many channels,
+//    pmr_chain.c fir_fft_pick; 4096 points only by PMR_FIR=fft4096), 16 points per thread, three register
 //    phases with two LDS exchanges per direction:
 //        forward  (decimation in frequency):  A: radix-16 over n0 (stride N/16), x W_N^(r k0)    B: radix-16 over n1, x W_(N/16)^(n2 k1)
 //                                             C: radix-R2 over n2 -> X[k0 + 16 k1 + 256 k2] at position k0 N/16 + k1 R2 + k2
@@ -26,7 +28,7 @@
 //  * twiddles: exact tables computed in double by the host.  A thread keeps its 15 phase-A factors W_N^(t k0) in registers (they
 //    serve A and, conjugated, A'); the 16 x R2 phase-B factors sit in LDS;
 //  * LDS: position p at p + (p >> 4) (one float2 of padding per 16): every access pattern of the three phases is conflict-free;
-//    34.8 KB per workgroup at N = 4096 (8.7 KB at N = 1024);
+//    34.8 KB per workgroup at N = 4096, 17.4 KB at N = 2048, 8.7 KB at N = 1024 (+ the phase-B twiddles);
 //  * loads: lane t of a wave reads the two channels' samples of row (block start + n0 N/16 + t) -- 8 bytes per row; the 8 / 128
 //    pair-workgroups that share a row's cache lines are made neighbours on ONE XCD (pmr_xcd_contiguous) so the rows come from HBM
 //    once; rows beyond the call's last frame read as zero (whatever the ring holds there never enters the transform);
