@@ -743,7 +743,10 @@ static int chain_init(pmr_chain q)
      * Chain +3.3 / +2.4 / +1.6 % on three boxes (459.7 vs 445.5, 444.8 vs 434.8, 458.2 vs 451.0 GS/s; 5 KB of padding, which still
      * lets four tiles in, measures the same); alone the kernel is 1.5 % slower.  The same padding COSTS cfg2 2.6 % and cfg5 2.3 %.
      * profiles/r04_ab_log.txt r4r. */
-    q->fe_lds_pad = (q->fe_on && !q->fe_two && q->chan_wide && M == 256) ? 6656u : 0u;
+#ifndef FE_LDS_PAD_256
+#define FE_LDS_PAD_256 6656u      /* (sweep hook: tools/ab_libs.py builds) */
+#endif
+    q->fe_lds_pad = (q->fe_on && !q->fe_two && q->chan_wide && M == 256) ? FE_LDS_PAD_256 : 0u;
     q->tf_on_backend = 0;
     q->cal_ok = 0;
     if (q->fe_on && !q->fe_two && q->d_fe_G12 && !q->sw.carry_inplace) {
