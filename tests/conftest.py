@@ -61,6 +61,7 @@ _ORDER = [
     ("test_gpu_dsd.py", 40),                                    # f3
     ("test_io.py", 51),                                         # f4
     ("test_spectrum.py", 52),
+    ("test_gpu_bench_ranks.py", 55),                            # bench.py --gpus 2: the cfg4 path with every rank's parity
     ("test_gpu_poison.py", 60),
     ("test_gpu_variants.py", 80),
     ("test_gpu_soak.py", 90),
