@@ -69,7 +69,14 @@ int       pmr_chain_destroy(pmr_chain q);
 const char *pmr_chain_create_error(void);
 /* Restart the stream AT sample index n_raw: all carried state zero, counters (resampler phase, ring / NCO / frame positions, the
  * CTCSS detector's block grid) as after n_raw zero samples -- the reference's loop never ends (:788) and its counters pass 2^32
- * within seconds at the larger configurations; pmr_chain_position reports where the stream stands (any pointer may be NULL). */
+ * within seconds at the larger configurations.
+ *  - It IS a pmr_chain_reset followed by setting the counters: blocks submitted but not collected (pmr_chain_submit_block) and
+ *    blocks still in flight on the device are DROPPED, not drained -- collect first what you want to keep; a faulted handle
+ *    (PMR_EHIP after a block failed mid-way) is usable again afterwards, exactly as after pmr_chain_reset.
+ *  - n_raw >= 2^62: PMR_ERANGE, the handle is left untouched (position and state as before the call).
+ * pmr_chain_position reports where the stream stands (any pointer may be NULL): the counters are the HOST's, advanced when a block is
+ * ENQUEUED -- after un-synchronised device calls (pmr_chain_process_block_device) it is the position the queued work will reach,
+ * not what the device has completed; pmr_chain_synchronize first where that matters. */
 int       pmr_chain_seek(pmr_chain q, uint64_t n_raw);
 void      pmr_chain_position(pmr_chain q, uint64_t *n_raw, uint64_t *n_resampled, uint64_t *n_frames);
 unsigned  pmr_chain_max_frames(pmr_chain q);               /* SDR_CHANNEL_BUF_SIZE rule, :730-736        */
@@ -192,7 +199,10 @@ enum { PMR_INFO_NUM_STAGES = 0, PMR_INFO_M_STAGE = 1, PMR_INFO_ARB_STEP = 2, PMR
                                      2 specialised one-level (k_fe_fast), 3 two levels, specialised, 4 two levels, generic    */,
        PMR_INFO_CHAN_PLAN = 9     /* 0 generic k_channelize, 1 16-channel k_channelize_win, 2 fused 256-channel kernel,
                                      3 wide bank: k_pfb_wide + k_fft_disc                                                    */,
-       PMR_INFO_FIR_PLAN = 10     /* 0 k_fir_pair (VALU), 1 direct MFMA form only, 2 FFT form for large blocks + direct MFMA  */ };
+       PMR_INFO_FIR_PLAN = 10     /* 0 k_fir_pair (VALU), 1 direct MFMA form only, 2 FFT form for large blocks + direct MFMA  */,
+       PMR_INFO_EXPERIMENT_BUILD = 11 /* 1: this LIBRARY was compiled with -DPMR_EXPERIMENT, the one gate of every compile-time experiment
+                                     hook (timing-only builds with wrong results, tile-shape knobs: csrc/pmr_experiment.h).  The product
+                                     build returns 0.  The only query that needs no handle: pmr_chain_info(NULL, 11, 0)               */ };
 enum { PMR_DESIGN_HALFBAND = 0, PMR_DESIGN_ARB = 1, PMR_DESIGN_PFB = 2,
        PMR_DESIGN_DEEMPH = 3 /* {b0, b1, a1} of the de-emphasis IIR, normalised by a0 (src/sdr_pmr446.c:462-463) */ };
 unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx);

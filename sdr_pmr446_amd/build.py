@@ -11,24 +11,43 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 C_SOURCES = ["pmr_chain.c", "pmr_design.c", "pmr_squelch.c", "pmr_dsd.c", "pmr_io.c"]
 HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_fe_fast.hip", "pmr_channelize_small.hip", "pmr_channelize_wide.hip", "pmr_fir_mfma4.hip", "pmr_fir_fft.hip", "pmr_ctcss.hip", "pmr_synth.hip", "pmr_spectrum.hip",
                "pmr_dsd_kernels.hip", "pmr_poison.hip"]
-EXTRA_HIP_FLAGS = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
-EXTRA_C_FLAGS = os.environ.get("PMR_CC_FLAGS", "").split()          # experiment builds only (tools/variant_bench.sh)
-HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_internal.h", "pmr_fe_common.hpp", "pmr_carry_load.hpp", os.path.join("..", "..", "include", "pmr_chain.h"),
+# -fno-slp-vectorize: see _compile.  The PRODUCT build takes no other flags: anything else is a variant (build_variant ->
+# build_ab/NAME/, -DPMR_EXPERIMENT added unless it is a sanitizer build of unchanged sources), so the in-tree library can never be
+# an experiment build by accident (tools/variant_*.sh used to rebuild it in place with --force)
+PRODUCT_HIP_FLAGS = ["-fno-slp-vectorize"]
+PRODUCT_C_FLAGS = []
+SANITIZE_C_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-g", "-O1"]
+HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_experiment.h", "pmr_internal.h", "pmr_fe_common.hpp", "pmr_carry_load.hpp", os.path.join("..", "..", "include", "pmr_chain.h"),
            os.path.join("..", "..", "include", "pmr_dsd.h"), os.path.join("..", "..", "include", "pmr_io.h"), os.path.join("..", "..", "include", "pmr_mem.h"),
            os.path.join("..", "data", "pmr446_taps.h")]
 
 
 def kernel_sources_sha256():
-    """sha256 over the kernel sources (csrc/*.hip, *.hpp and the kernels' shared header), names and contents in sorted order: what
-    ties a committed PMC measurement (profiles/traffic.json) to the kernels it was taken with -- bench.py marks roofline.traffic
-    stale when the tree's hash differs from the entry's."""
+    """sha256 over everything that decides what a launch moves through HBM: the kernel sources (csrc/*.hip, *.hpp, the shared headers),
+    the HOST PLAN (pmr_chain.c: which kernels run, tile paddings, transform sizes, streams; pmr_design.c; the tap tables) and the
+    product's compiler flags -- names and contents in sorted order.  It ties a committed PMC measurement (profiles/traffic.json) to
+    the tree it was taken with: bench.py marks roofline.traffic stale when the tree's hash differs from the entry's.  (Round 5 hashed
+    the kernels only; a plan change left a stale number marked fresh -- ADVICE r05.)"""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".hpp")) or f == "pmr_kernels.h":
-            h.update(f.encode() + b"\0")
-            with open(os.path.join(CSRC, f), "rb") as fh:
-                h.update(fh.read())
+    names = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h", ".c"))]
+    for f in names:
+        h.update(f.encode() + b"\0")
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(HERE, "data", "pmr446_taps.h"), "rb") as fh:
+        h.update(b"pmr446_taps.h\0" + fh.read())
+    h.update(" ".join(PRODUCT_HIP_FLAGS + ["|"] + PRODUCT_C_FLAGS).encode())
+    return h.hexdigest()
+
+
+def library_sha256(path=None):
+    """sha256 of the built library file (bench.py's `library` record: which binary produced the line)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path or LIB, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
     return h.hexdigest()
 
 
@@ -43,49 +62,70 @@ def _stale():
     return False
 
 
-def build_variant(name, hip_flags="", c_flags=None, verbose=False):
+def build_variant(name, hip_flags="", c_flags=None, verbose=False, experiment=True):
     """Another BUILD of the library for same-box A/B runs (tools/ab_libs.py, PMR_LIBRARY): build_ab/<name>/libpmr446_hip.so, compiled
-    with extra -D flags (they reach hipcc AND gcc unless c_flags is given), objects beside it.  Not part of the product."""
+    with extra -D flags (they reach hipcc AND gcc unless c_flags is given), objects beside it.  Not part of the product: every such
+    build gets -DPMR_EXPERIMENT (csrc/pmr_experiment.h: the one gate of the hooks; the library then reports
+    PMR_INFO_EXPERIMENT_BUILD = 1 and bench.py refuses to print a headline from it)."""
     out = os.path.join(os.path.dirname(HERE), "build_ab", name)
     os.makedirs(out, exist_ok=True)
     if c_flags is None:
         c_flags = " ".join(t for t in hip_flags.split() if t.startswith("-D"))
+    gate = ["-DPMR_EXPERIMENT"] if experiment else []
     lib = os.path.join(out, "libpmr446_hip.so")
-    _compile(lib, out, ["-fno-slp-vectorize"] + hip_flags.split(), c_flags.split(), verbose)
+    _compile(lib, out, PRODUCT_HIP_FLAGS + gate + hip_flags.split(), PRODUCT_C_FLAGS + gate + c_flags.split(), verbose)
     return lib
 
 
+def build_sanitized(verbose=False):
+    """The product's sources with the HOST C units (planning, rings' bookkeeping, squelch, I/O, dsd host side) under
+    AddressSanitizer + UBSan: build_ab/asan/libpmr446_hip.so.  CPU tier only (tools/asan_tier.sh runs the host-logic tests on it with
+    libasan preloaded); the kernels are compiled as always -- GPU sanitizers are not available on the pool.  Not an experiment
+    build: no hook is defined, results are the product's."""
+    return build_variant("asan", "", " ".join(SANITIZE_C_FLAGS), verbose, experiment=False)
+
+
 def build(force=False, verbose=False):
-    """Compile for gfx950 (cross-compiles without a GPU).  Returns the library path."""
+    """Compile the PRODUCT for gfx950 (cross-compiles without a GPU).  Returns the library path."""
+    for v in ("PMR_HIPCC_FLAGS", "PMR_CC_FLAGS"):
+        if os.environ.get(v):
+            raise RuntimeError("%s is set: the in-tree library is the product and takes no extra flags; build a variant instead "
+                               "(python3 sdr_pmr446_amd/build.py --variant NAME \"%s\" -> build_ab/NAME/)" % (v, os.environ[v]))
     if not force and not _stale():
         return LIB
-    _compile(LIB, CSRC, EXTRA_HIP_FLAGS, EXTRA_C_FLAGS, verbose)
+    _compile(LIB, CSRC, PRODUCT_HIP_FLAGS, PRODUCT_C_FLAGS, verbose)
     build_example(verbose)
     return LIB
 
 
 def _compile(lib, objdir, hip_flags, c_flags, verbose):
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.path.join(ROCM, "bin", "hipcc")
-    objs = []
+    objs, cmds = [], []
     for f in C_SOURCES:
         o = os.path.join(objdir, f[:-2] + ".o")
-        cmd = ["gcc", "-std=gnu11", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
-               "-I" + os.path.join(ROCM, "include")] + c_flags + ["-c", os.path.join(CSRC, f), "-o", o]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        cmds.append(["gcc", "-std=gnu11", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
+                     "-I" + os.path.join(ROCM, "include")] + c_flags + ["-c", os.path.join(CSRC, f), "-o", o])
         objs.append(o)
     for f in HIP_SOURCES:
         o = os.path.join(objdir, f[:-4] + ".o")
         # -fno-slp-vectorize: keep f32 FMAs as v_fma/v_fmac; hipcc otherwise SLP-packs adjacent ones into
         # v_pk_fma_f32, which is slower than two plain FMAs on gfx950 (measured on k_fir_*; MI355X_MICROARCH.md)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-parameter"] + \
-              hip_flags + ["-c", os.path.join(CSRC, f), "-o", o]
+        cmds.append([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-parameter"] +
+                    hip_flags + ["-c", os.path.join(CSRC, f), "-o", o])
+        objs.append(o)
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(o)
+    # the units are independent: compile them side by side (a variant build on the GPU box costs box time)
+    with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 4)) as ex:
+        list(ex.map(run, cmds))
+    sanitized = any(t.startswith("-fsanitize") for t in c_flags)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lm", "-lpthread"]
+    if sanitized:            # gcc's sanitizer runtimes are preloaded by whoever loads the library (tools/asan_tier.sh)
+        cmd += ["-Wl,--allow-shlib-undefined"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -116,6 +156,8 @@ def build_example(verbose=False):
 if __name__ == "__main__":
     if "--kernel-hash" in sys.argv:
         print(kernel_sources_sha256())
+    elif "--asan" in sys.argv:                          # host C units under ASan + UBSan -> build_ab/asan/ (tools/asan_tier.sh)
+        print(build_sanitized(verbose="--verbose" in sys.argv))
     elif "--variant" in sys.argv:                       # build.py --variant NAME "-DFOO -DBAR=1"
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2] if len(sys.argv) > i + 2 else ""))

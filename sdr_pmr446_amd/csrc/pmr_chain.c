@@ -2311,6 +2311,7 @@ int pmr_chain_profile_get(pmr_chain q, unsigned i, double *total_ms, unsigned *l
 
 unsigned pmr_chain_info(pmr_chain q, int what, unsigned idx)
 {
+    if (what == PMR_INFO_EXPERIMENT_BUILD) return (unsigned)(PMR_EXPERIMENT_BUILD | pmr_kernels_experiment_build());
     if (!q) return 0;
     switch (what) {
     case PMR_INFO_NUM_STAGES: return q->d.num_stages;

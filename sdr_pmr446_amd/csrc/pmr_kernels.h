@@ -6,6 +6,7 @@
 
 #include <stdint.h>
 
+#include "pmr_experiment.h"             /* the gate of every compile-time experiment hook: first, before any hook's default */
 #include "../../include/pmr_chain.h"     /* pmr_ctcss_event */
 
 #ifdef __cplusplus
@@ -282,6 +283,8 @@ int pmr_launch_spgram(pmr_stream_t s, const void *xr, uint64_t xr_mask, uint64_t
  * write then fails on every box, not on the one box where the stale bytes happen to be a NaN. */
 int pmr_debug_poison_enabled(void);
 int pmr_debug_poison_lds(pmr_stream_t s);
+/* 1 when the KERNEL units were compiled with -DPMR_EXPERIMENT (pmr_experiment.h); pmr_chain_info ORs it with the host units' own */
+int pmr_kernels_experiment_build(void);
 
 #ifdef __cplusplus
 }

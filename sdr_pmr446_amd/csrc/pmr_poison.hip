@@ -37,6 +37,9 @@ extern "C" int pmr_debug_poison_enabled(void)
     return v;
 }
 
+// the kernel units' half of pmr_chain_info(.., PMR_INFO_EXPERIMENT_BUILD, ..): every .hip unit gets the same flags (build.py)
+extern "C" int pmr_kernels_experiment_build(void) { return PMR_EXPERIMENT_BUILD; }
+
 extern "C" int pmr_debug_poison(int on)
 {
     const int was = pmr_debug_poison_enabled();

@@ -106,22 +106,26 @@ def init_dist(backend, device=None, nccl_timeout_s=120):
 def reduce_parity(dist, rank, world, rec):
     """Every rank's oracle verdict on ITS stream and device -> one record every rank holds: {ranks, all_ok, worst_lsb, per_rank}.
     `rec`: the rank's own parity record (bench.parity_check: ok, max_abs_pcm_diff_lsb, frames_checked, channels_checked, device).
-    The exchange is one SUM all-reduce of an int64 [world][5] table over the gloo world group (rank r fills row r)."""
+    The exchange is one SUM all-reduce of an int64 [world][6] table over the gloo world group (rank r fills row r).  The last column:
+    how many PCM samples of the rank's check differ from the oracle by more than 1 LSB inside the ill-conditioned classes of
+    parity_rule.py (samples outside them at > 1 LSB make `ok` false)."""
     lsb = rec.get("max_abs_pcm_diff_lsb")
+    over = (rec.get("ill_conditioned") or {}).get("samples_over_1_lsb")
     row = [1 if rec.get("ok") else 0, int(lsb) if isinstance(lsb, int) and lsb >= 0 else -1, int(rec.get("frames_checked") or 0),
-           int(rec.get("channels_checked") or 0), int(rec.get("device", -1))]
+           int(rec.get("channels_checked") or 0), int(rec.get("device", -1)), int(over) if isinstance(over, int) else -1]
     if dist is None or world <= 1:
         rows = [row]
     else:
         import torch
-        t = torch.zeros((world, 5), dtype=torch.int64)
+        t = torch.zeros((world, 6), dtype=torch.int64)
         t[rank] = torch.tensor(row, dtype=torch.int64)
         rows = dist.sum_rows_cpu(t).tolist()
     bad = [r for r in rows if r[0] != 1]
     return {"ranks": len(rows), "all_ok": not bad,
             "worst_lsb": None if any(r[1] < 0 for r in rows) else max(r[1] for r in rows),
             "per_rank": [{"rank": i, "device": r[4], "ok": bool(r[0]), "max_abs_pcm_diff_lsb": r[1] if r[1] >= 0 else None,
-                          "frames_checked": r[2], "channels_checked": r[3]} for i, r in enumerate(rows)]}
+                          "frames_checked": r[2], "channels_checked": r[3],
+                          **({"ill_conditioned_samples_over_1_lsb": r[5]} if r[5] >= 0 else {})} for i, r in enumerate(rows)]}
 
 
 def bind_to_gpu_numa(local_rank, world_local):

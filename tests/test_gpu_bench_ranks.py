@@ -28,3 +28,39 @@ def test_two_ranks_check_their_own_streams_and_report_in_one_line():
     p = d["parity_checked"]
     assert p["ranks"] == 2 and p["all_ok"] and p["worst_lsb"] <= 1
     assert [e["rank"] for e in p["per_rank"]] == [0, 1] and all(e["ok"] and e["frames_checked"] > 1000 and e["channels_checked"] == 224 for e in p["per_rank"])
+
+
+def _run_bench(extra, timeout=1200):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PMR_DEBUG_POISON")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dist-backend", "gloo", "--workload", "cfg3", "--also", "none",
+                           "--no-cpu-baseline", "--no-one-open", "--no-kernel-events"] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_eight_ranks_first_contact_rehearsal():
+    """The shape of the driver's 8-GPU run (cfg4: eight 61.44 MS/s streams, BASELINE.json configs[3]) on ONE device: eight processes,
+    eight handles on device 0, eight streams (stream id = rank), eight parity records reduced into ONE JSON line, exit code 0 --
+    everything of the N = 8 path but the other seven device ordinals and RCCL (which cannot exist on a 1-GPU box).  2^22-sample blocks."""
+    r = _run_bench(["--gpus", "8", "--log2-block", "22", "--steps", "4", "--warmup", "1", "--regions", "1"])
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and [l for l in r.stdout.splitlines() if l.strip() and not l.startswith("{")] == [], r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and "cfg4" in d["config"]["workload"] and d["value"] > 1e3
+    assert d["dist"]["backend_used"] == "gloo" and d["dist"]["devices_visible"] >= 1
+    assert d["library"]["experiment_build"] is False and not d["library"]["selected_by_PMR_LIBRARY"] and len(d["library"]["sha256"]) == 64
+    p = d["parity_checked"]
+    assert p["ranks"] == 8 and p["all_ok"] and p["worst_lsb"] <= 1
+    assert [e["rank"] for e in p["per_rank"]] == list(range(8))
+    assert all(e["ok"] and e["device"] == 0 and e["frames_checked"] > 200 and e["channels_checked"] == 224 for e in p["per_rank"])
+
+
+def test_a_failing_rank_fails_the_job_after_rank_0s_line():
+    """One rank's check made to fail (--test-fail-rank: that rank falsifies the PCM it hands to its own oracle check): rank 0's line still
+    comes out, says which rank failed, and the job's exit code is non-zero -- what an 8-GPU run with one bad device would look like."""
+    r = _run_bench(["--gpus", "2", "--log2-block", "22", "--steps", "4", "--warmup", "1", "--regions", "1", "--test-fail-rank", "1"])
+    assert r.returncode != 0, r.stdout[-300:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    p = json.loads(lines[0])["parity_checked"]
+    assert p["ranks"] == 2 and not p["all_ok"] and [e["ok"] for e in p["per_rank"]] == [True, False]
+    assert "PARITY FAILED" in r.stderr

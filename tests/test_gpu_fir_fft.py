@@ -108,14 +108,20 @@ def test_fft_form_equals_direct_form_and_oracle(cfg, splits, ks, open_ch, form):
         assert np.abs(fft["pcm"][chans].astype(np.int32) - po[chans].astype(np.int32)).max() <= 1
 
 
-@pytest.mark.parametrize("open_ch,form", [(None, None), ([2, 5, 11], None), (None, "fft4096"), ([2, 5, 11], "fft4096"), (None, "fft2048"),
-                                          ([2, 5, 11], "fft2048"), (None, "fft1024")],
-                         ids=["all", "three-open", "all-4096pt", "three-open-4096pt", "all-2048pt", "three-open-2048pt", "all-1024pt"])
-def test_fft_form_with_the_ctcss_branch_as_second_product(open_ch, form):
+@pytest.mark.parametrize("open_ch,form,cfg", [(None, None, CFG2), ([2, 5, 11], None, CFG2), (None, "fft4096", CFG2), ([2, 5, 11], "fft4096", CFG2),
+                                              (None, "fft2048", CFG2), ([2, 5, 11], "fft2048", CFG2), (None, "fft1024", CFG2),
+                                              ("one", None, CFG2), ("one", None, CFG5)],
+                         ids=["all", "three-open", "all-4096pt", "three-open-4096pt", "all-2048pt", "three-open-2048pt", "all-1024pt",
+                              "one-open-default-plan", "one-open-default-plan-cfg5"])
+def test_fft_form_with_the_ctcss_branch_as_second_product(open_ch, form, cfg):
     """Detector on: the low-pass branch delay188(x) - hp(x) (:884-889) leaves the same forward transform as a second product.
-    Branch samples against the direct DUAL pass and the oracle; the detector's events on top of it against the oracle's."""
-    fs, M = CFG2
-    splits = [(1 << 21) + 4321, 1 << 21]
+    Branch samples against the direct DUAL pass and the oracle; the detector's events on top of it against the oracle's.
+    "one-open-default-plan": the reference's own mode (:893: ONE squelch-opened channel + the detector) on the plan fir_fft_pick selects
+    by itself for it (the 2048-point DUAL kernel for <= 2 open channels) -- ADVICE r05: that default had no parity test."""
+    fs, M = cfg
+    splits = [(1 << 21) + 4321, 1 << 21] if cfg == CFG2 else [(1 << 25) + 4321, 1 << 25]
+    if open_ch == "one":
+        open_ch = [[k for k in active_channels(M, None, fs) if synth.channel_kind(k) == "fm"][0]]
     x = _synth(sum(splits), fs, M, dev_hz=1500.0, ctcss_dev_hz=700.0)
     res = []
     for f in (form, "direct"):
@@ -135,7 +141,7 @@ def test_fft_form_with_the_ctcss_branch_as_second_product(open_ch, form):
     assert np.abs(fft["ctcss_lp"][chans] - ro["ctcss_lp"][chans]).max() <= 1e-5 * max(scale, 1.0)
     assert np.abs(fft["pcm"][chans].astype(np.int32) - ro["pcm"][chans].astype(np.int32)).max() <= 1
     fm_ch = [k for k in chans if synth.channel_kind(k) == "fm"]
-    assert fft["ctcss"].shape == ro["ctcss"].shape and ro["ctcss"].shape[1] >= 8
+    assert fft["ctcss"].shape == ro["ctcss"].shape and (ro["ctcss"].shape[1] >= 8 or cfg != CFG2)
     for k in fm_ch:
         assert np.array_equal(fft["ctcss"]["index"][k], ro["ctcss"]["index"][k])
         assert np.array_equal(fft["ctcss"]["detected"][k], ro["ctcss"]["detected"][k])

@@ -1,27 +1,28 @@
 """Every rank of `bench.py --gpus N` runs ITS OWN synthetic stream (stream_id = rank: another noise realisation) -- cfg4 is
-eight of them (BASELINE.json configs[3]; the reference's loop per stream, src/sdr_pmr446.c:788-908).  The parity tests elsewhere run
-stream 0; this file runs the streams the other ranks get, through the un-synchronised device entry, against the oracle.
+eight of them (BASELINE.json configs[3]; the reference's loop per stream, src/sdr_pmr446.c:788-908).  This file runs ALL EIGHT stream ids
+on each of cfg2 / cfg3 / cfg5 (cfg3 x 8 = every GPU of cfg4) through the un-synchronised device entry against the oracle.
 
-Bar: +-1 LSB on every signal channel for every frame after the START-UP, and for the start-up frames (the first 26 + 383 after a reset:
-the polyphase windows still hold pre-stream zeros, a channel's output ramps up from ~1e-4 of its scale and arg() amplifies the two
-implementations' f32 rounding; the audio FIR spreads that over its 383 taps) <= 8 LSB with >= 99.99 % within 1 -- the rule
-bench.py's parity_check applies on every rank.  Found by round 5's first two-rank run: stream 1 at cfg5 has ONE such sample (3 LSB, frame 200
-of channel 410; profiles/r05_stream_parity.txt), eleven other streams none."""
+Bar: sdr_pmr446_amd/parity_rule.py, the rule bench.py's parity_check applies on every rank -- +-1 LSB on every sample of every signal
+channel, except PCM samples the audio FIR connects to an ILL-CONDITIONED discriminator sample (inputs below 1 % of the channel's steady
+rms in the oracle's channelizer output: the first frames after the reset, while the polyphase windows fill): <= 4 LSB at the FIR's centre
+lags, <= 2 LSB at its other lags.  Round 5 used a blanket window (the first 409 frames of every channel, <= 8 LSB); its one known case
+(stream 1 at cfg5: 3 LSB at channel 410, frame 200 = ill frame 10 + lag 190, profiles/r05_stream_parity.txt) sits in the centre class.
+The number of samples that USE the relaxation (> 1 LSB) is asserted to stay in single digits per stream."""
 import numpy as np
 import pytest
 
 import oracle
 from parity_util import CFG2, CFG3, CFG5, active_channels
+from sdr_pmr446_amd import parity_rule
 
 pytestmark = pytest.mark.gpu
 
-STARTUP = 26 + 383
+CASES = [(name, cfg, sid, lb, nblk) for name, cfg, lb, nblk in (("cfg5", CFG5, 25, 2), ("cfg3", CFG3, 23, 2), ("cfg2", CFG2, 20, 3))
+         for sid in range(8)]
 
 
-@pytest.mark.parametrize("cfg,sid,lb,nblk", [(CFG5, 1, 25, 2), (CFG5, 2, 25, 2), (CFG5, 7, 25, 2), (CFG3, 1, 23, 2), (CFG3, 6, 23, 2),
-                                             (CFG2, 1, 20, 3), (CFG2, 5, 20, 3)],
-                         ids=["cfg5-stream1", "cfg5-stream2", "cfg5-stream7", "cfg3-stream1", "cfg3-stream6", "cfg2-stream1", "cfg2-stream5"])
-def test_other_ranks_streams_match_the_oracle(cfg, sid, lb, nblk):
+@pytest.mark.parametrize("name,cfg,sid,lb,nblk", CASES, ids=["%s-stream%d" % (c[0], c[2]) for c in CASES])
+def test_every_ranks_stream_matches_the_oracle(name, cfg, sid, lb, nblk):
     from sdr_pmr446_amd import chain
     fs, M = cfg
     block = 1 << lb
@@ -37,12 +38,16 @@ def test_other_ranks_streams_match_the_oracle(cfg, sid, lb, nblk):
     for b in bufs:
         b.free()
     o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=1 << 22)
-    ref = np.concatenate([o.process_block(x[p:p + (1 << 22)], want=("pcm",))["pcm"] for p in range(0, nblk * block, 1 << 22)],
-                         axis=1).astype(np.int32)
+    outs = [o.process_block(x[p:p + (1 << 22)], want=("pcm", "chan")) for p in range(0, nblk * block, 1 << 22)]
     o.close()
+    ref = np.concatenate([r["pcm"] for r in outs], axis=1).astype(np.int32)
+    chan = np.concatenate([r["chan"] for r in outs], axis=1)
     act = active_channels(M, None, fs)
-    assert got.shape == ref.shape and got.shape[1] > STARTUP + 200
-    d = np.abs(got[act] - ref[act])
-    assert d[:, STARTUP:].max() <= 1, int(d[:, STARTUP:].max())
-    assert d[:, :STARTUP].max() <= 8 and (d[:, :STARTUP] <= 1).mean() >= 0.9999, (int(d[:, :STARTUP].max()), float((d[:, :STARTUP] <= 1).mean()))
+    assert got.shape == ref.shape and got.shape[1] > parity_rule.PFB_FRAMES + parity_rule.FIR_TAPS + 200
+    v = parity_rule.check(got[act], ref[act], chan[act])
+    ill = v["ill_conditioned"]
+    assert v["ok"], v
+    # the ill-conditioned class is the start-up and nothing else, and hardly any sample needs the relaxation
+    assert 0 <= ill["last_frame"] < parity_rule.PFB_FRAMES, ill
+    assert ill["samples_over_1_lsb"] <= 8, ill
     assert np.abs(ref[act]).max() > 1000

@@ -229,3 +229,29 @@ def test_streaming_past_two_to_the_32_at_cfg5_equals_a_handle_seeked_there():
     d = np.abs(out[0][act] - out[1][act])
     assert out[0].shape[1] > 700 and np.abs(out[0][act]).max() > 1000
     assert d.max() <= 1, (int(d.max()), float((d > 1).mean()))
+
+
+@pytest.mark.gpu
+def test_seek_range_limit_and_position_semantics():
+    """include/pmr_chain.h: n_raw >= 2^62 is PMR_ERANGE and leaves the handle where it was; pmr_chain_position counts ENQUEUED blocks
+    (neither was stated nor tested)."""
+    from sdr_pmr446_amd import chain
+    fs, M = CFG2
+    n = 1 << 18
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n)
+    g.seek(12345)
+    assert g.position()[0] == 12345
+    assert g._L.pmr_chain_seek(g.h, 1 << 62) == 2                      # PMR_ERANGE
+    assert b"seek position" in g._L.pmr_chain_last_error(g.h)
+    assert g.position()[0] == 12345                                   # untouched
+    assert g._L.pmr_chain_seek(g.h, (1 << 62) - 1) == 0 and g.position()[0] == (1 << 62) - 1
+    g.seek(0)
+    iq = chain.synth_iq_device(n, fs, M)
+    S = g.max_frames
+    pcm = chain.DeviceBuffer(M * S * 2)
+    ns = g.process_block_device(iq.ptr, n, d_pcm=pcm.ptr, stride=S)   # not synchronised: the position is the planned one, already
+    raw, res, frames = g.position()
+    assert raw == n and frames == ns and res >= frames * M
+    g.synchronize()
+    assert g.position() == (raw, res, frames)
+    g.close(); iq.free(); pcm.free()

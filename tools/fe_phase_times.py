@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a front-end tile's time goes (diagnostic).  Needs a library built with -DFE_STAMP:
-    PMR_HIPCC_FLAGS="-fno-slp-vectorize -DFE_STAMP" python3 sdr_pmr446_amd/build.py --force
-    python3 tools/fe_phase_times.py cfg3
+    python3 sdr_pmr446_amd/build.py --variant stamp "-DFE_STAMP"          (-> build_ab/stamp/, an experiment build)
+    PMR_LIBRARY=build_ab/stamp/libpmr446_hip.so python3 tools/fe_phase_times.py cfg3
 k_fe_fast then writes s_memtime (shader-clock cycles) at its phase boundaries for every tile; the last block's stamps are read back:
 start -> tile landed (DMA) -> dc scan + first stage -> cascade -> resampler / stores, in cycles and as shares of a tile's lifetime.  Blocks run one at a time with the
 handle's overlap off, so the front end is alone on the chip while it runs (the back end follows it)."""

@@ -7,4 +7,3 @@ for W in ${@:-cfg5 cfg2}; do
   bash tools/variant_kstats.sh $W "-DPMR_BASELINE" "-DFE_STOP=1" "-DFE_STOP=3" "-DFE_OUT_SKIP" "-DFE_OUT_AND=511ull" "-DFE_OUT_NT" "-DFE_OUT_SC" "-DPMR_BASELINE" 2>&1 |
     grep -E "^==|k_fe_fast|BUILD"
 done
-python3 sdr_pmr446_amd/build.py --force > /dev/null 2>&1      # leave the product build behind

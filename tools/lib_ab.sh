@@ -5,7 +5,7 @@ ALT=$1; shift
 for W in ${@:-cfg5 cfg2 cfg3}; do
   for rep in 1 2; do for L in "" "$ALT"; do
     echo "== $W ${L:-in-tree}"
-    PMR_LIBRARY=$L python3 bench.py --workload $W --also none --no-cpu-baseline --no-host-io --regions 9 --parity-blocks 0 2>&1 | python3 -c "
+    PMR_LIBRARY=$L python3 bench.py --allow-experiment --workload $W --also none --no-cpu-baseline --no-host-io --regions 9 --parity-blocks 0 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,17 +1,15 @@
 #!/bin/bash
-# usage (GPU box): bash tools/variant_bench.sh <workload> "<extra hipcc flags>" ... : rebuild the library with each flag set and bench
+# usage (GPU box): bash tools/variant_bench.sh <workload> "<extra hipcc flags>" ... : build a variant of the library (build_ab/_variant/) with each flag set and bench
 W=$1; shift
 for F in "$@"; do
   echo "== flags: $F"
-  # (a build that fails must not fall through to the previous flag set's library: round 4 lost four "baselines" to a -DX=1 that
-  #  collided with a variable named X.  Use -DPMR_BASELINE for "no change".)
-  # the -D flags reach BOTH compilers (hipcc for the kernels, gcc for the host C: a macro that lives in pmr_chain.c was silently
-  # ignored in round 4 -- ADVICE r04); other flags are hipcc's only
-  CCF=$(for t in $F; do case $t in -D*) echo -n "$t ";; esac; done)
-  if ! PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" PMR_CC_FLAGS="$CCF" python3 sdr_pmr446_amd/build.py --force > /tmp/variant_build.log 2>&1; then
+  # the build goes to build_ab/_variant/ (never the in-tree product library) with -DPMR_EXPERIMENT added by build.py; the -D flags
+  # reach BOTH compilers (hipcc for the kernels, gcc for the host C)
+  if ! python3 sdr_pmr446_amd/build.py --variant _variant "$F" > /tmp/variant_build.log 2>&1; then
     echo "BUILD FAILED for flags: $F"; grep -m3 -E "error" /tmp/variant_build.log; continue
   fi
-  python3 bench.py --workload $W --also none --no-cpu-baseline --no-host-io --regions 5 --parity-blocks 0 2>&1 | python3 -c "
+  export PMR_LIBRARY=$PWD/build_ab/_variant/libpmr446_hip.so
+  python3 bench.py --allow-experiment --workload $W --also none --no-cpu-baseline --no-host-io --regions 5 --parity-blocks 0 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -4,13 +4,13 @@
 W=$1; shift
 for F in "$@"; do
   echo "== flags: $F"
-  # the -D flags reach BOTH compilers (hipcc for the kernels, gcc for the host C: a macro that lives in pmr_chain.c was silently
-  # ignored in round 4 -- ADVICE r04); other flags are hipcc's only
-  CCF=$(for t in $F; do case $t in -D*) echo -n "$t ";; esac; done)
-  if ! PMR_HIPCC_FLAGS="-fno-slp-vectorize $F" PMR_CC_FLAGS="$CCF" python3 sdr_pmr446_amd/build.py --force > /tmp/variant_build.log 2>&1; then
+  # the build goes to build_ab/_variant/ (never the in-tree product library) with -DPMR_EXPERIMENT added by build.py; the -D flags
+  # reach BOTH compilers (hipcc for the kernels, gcc for the host C)
+  if ! python3 sdr_pmr446_amd/build.py --variant _variant "$F" > /tmp/variant_build.log 2>&1; then
     echo "BUILD FAILED for flags: $F"; grep -m3 -E "error" /tmp/variant_build.log; continue
   fi
-  python3 bench.py --workload $W --also none --no-cpu-baseline --no-host-io --regions 5 --parity-blocks 0 2>&1 | python3 -c "
+  export PMR_LIBRARY=$PWD/build_ab/_variant/libpmr446_hip.so
+  python3 bench.py --allow-experiment --workload $W --also none --no-cpu-baseline --no-host-io --regions 5 --parity-blocks 0 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
