@@ -1250,13 +1250,7 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     p.dc_a1 = d->dc_a1; p.zeta = 1.0f; p.lam_wave = q->fe_lam_wave;
     memcpy(p.lam_pow16, q->fe_lam_pow16, sizeof(p.lam_pow16));
     fe_fill_taps(q, &p, 0, s1);
-    {
-        /* with level 2 deferred to the back-end stream, level 1 is the front-end stream's last launch of this call */
-        pmr_launch_events ev; prof_pending pe;
-        fe_launch_events(q, K_FE, q->l2_on_backend && ntiles1 != 0, &ev, &pe);
-        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles1, 256, 16, &ev));
-        prof_push(q, &pe);
-    }
+    /* (level 1 is launched below, once the parameters of the block's carry pass and level 2 are made: host arithmetic only) */
 
     /* ---- carries of level 1 + in-place fix of the ring tail: the last `keep` new samples are what the NEXT call's level 2
      * re-reads as history; level 2 of THIS call skips them (fix_limit) and corrects everything before them at load ---- */
@@ -1287,6 +1281,29 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
     p2.dc_a1 = d->dc_a1; p2.zeta = d->zeta; p2.lam_wave = q->fe_lam_wave;
     memcpy(p2.lam_pow16, q->fe_lam_pow16, sizeof(p2.lam_pow16));
     fe_fill_taps(q, &p2, s1, h2);
+#ifdef EXP_L2_INLINE     /* timing experiment (pmr_fe_fast.hip): level-2 tiles run inside the level-1 launch; the separate launch keeps the
+                          * tiles a real implementation could not place there (the first LAG level-1 tiles of every XCD range).  WRONG results */
+    {
+        extern void pmr_exp_set_l2_params(const pmr_fe_params *);
+        pmr_exp_set_l2_params(&p2);
+    }
+#endif
+    {
+        /* with level 2 deferred to the back-end stream, level 1 is the front-end stream's last launch of this call */
+        pmr_launch_events ev; prof_pending pe;
+        fe_launch_events(q, K_FE, q->l2_on_backend && ntiles1 != 0, &ev, &pe);
+        LAUNCH_FE(K_FE, pmr_launch_frontend(q->sfe, &p, ntiles1, 256, 16, &ev));
+        prof_push(q, &pe);
+    }
+#ifdef EXP_L2_INLINE
+    unsigned ntiles2_sep = ntiles2;
+    {
+        const unsigned per = ntiles1 / 8, lag = EXP_L2_INLINE;
+        const unsigned long inl = per > lag ? (unsigned long)(per - lag) * 8ul * (unsigned)q->fe_TQ / (unsigned)q->fe2_T_own : 0;
+        ntiles2_sep = inl < ntiles2 ? ntiles2 - (unsigned)inl : 0;
+    }
+#define ntiles2 ntiles2_sep
+#endif
     if (q->l2_on_backend) {
         /* Level 2 touches 1/2^s1 of the data in a few thousand tiles -- too few to fill the chip -- so it runs best under the
          * next block's level 1 instead of between two level-1 launches on the same stream. */
@@ -1295,6 +1312,9 @@ static int frontend_two_level(pmr_chain q, const void *d_iq, unsigned n_in, unsi
         LAUNCH_FE(K_FE_TILES, pmr_launch_fe_carry(q->sfe, &t, &f));
         if (ntiles2) LAUNCH_FE(K_FE_L2, pmr_launch_frontend_l2(q->sfe, &p2, ntiles2, q->fe2_fast));
     }
+#ifdef EXP_L2_INLINE
+#undef ntiles2
+#endif
     q->fe_sel = nxt;
     q->arb_phase = new_phase;
     *ny_out = ny;

@@ -68,8 +68,22 @@ static __device__ __forceinline__ cf fe_raw(const void *x, long b, int fmt)
     return cfm(((float)(w & 0xffu) - 127.5f) * (1.0f / 127.5f), ((float)(w >> 8) - 127.5f) * (1.0f / 127.5f));
 }
 
+static __device__ __forceinline__ void fe_level2_tile(const pmr_fe_params &p, const int c, char *smem, const int tid);
+
+#ifdef EXP_L2_INLINE
+/* TIMING EXPERIMENT (profiles/r06_ab_log.txt r6a; WRONG results): what could "level 2 inside the level-1 launch" buy?  The level-1 tile
+ * that sits EXP_L2_INLINE tiles behind the last contributor of a level-2 tile runs that tile's body after its own ring stores -- no
+ * counters, no acquire, the dc carries of the contributors read from whatever the carry buffer holds: everything a real
+ * implementation must ADD is left out, so the build bounds its gain from above.  -DEXP_L2_INLINE_ATOMIC adds the cheapest
+ * conceivable hand-shake: every tile drains its stores and makes ONE agent-scope atomic add (no return value) on the worker's
+ * counter, the worker reads that counter once. */
+#define FE_P2_PARAM , pmr_fe_params p2, unsigned long long *l2cnt
+#else
+#define FE_P2_PARAM
+#endif
+
 template <int MODE, int N3, int TAIL>
-__global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
+__global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 {
     static_assert(N3 >= 1 || (MODE == FE_FULL && TAIL == 1), "a cascade without six-tap stages is (m = 5, m = 10)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -362,6 +376,40 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
             nh[i] = sb < 0 ? hist[(long)i + p.n_in] : fe_raw(p.x, sb, p.in_fmt);
         }
     }
+#ifdef EXP_L2_INLINE
+    if constexpr (MODE == FE_L1 && N3 == 4) {
+        const int per = (int)(gridDim.x >> 3);
+        const int lc = per ? c % per : c;                                 // position inside the XCD's contiguous range
+#ifdef EXP_L2_INLINE_ATOMIC
+        {
+            // this tile's arrival: stores drained, then ONE agent-scope add on the counter of the level-2 tile its samples end in
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const long je = ((long)c + 1) * p.TQ - 1;
+            long c2a = (je + p2.Hh + p2.pend) / p2.T_own;
+            if (tid == 0) __hip_atomic_fetch_add(l2cnt + (c2a & 4095), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
+        if (lc >= EXP_L2_INLINE && c < (int)gridDim.x) {
+            // level-2 tile c2 whose LAST input sample lies in the ring range tile c - LAG produced
+            const long cl = (long)c - EXP_L2_INLINE;
+            const long lo = cl * p.TQ, hi = lo + p.TQ;                     // new-sample indices tile cl stored
+            long c2 = (lo - 2047 + p2.Hh + p2.pend + p2.T_own - 1) / p2.T_own;
+            if (c2 < 0) c2 = 0;
+            const long jl = c2 * p2.T_own - p2.Hh - p2.pend + 2047;
+            if (jl >= lo && jl < hi && c2 <= p2.c_end) {
+#ifdef EXP_L2_INLINE_ATOMIC
+                if (tid == 0) {
+                    const unsigned long long seen = __hip_atomic_load(l2cnt + (c2 & 4095), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen == 0xffffffffffffffffull) l2cnt[4095] = 1;    // (keeps the load alive; never true)
+                }
+#endif
+                __syncthreads();                                           // every wave is done with the level-1 tile's LDS
+                fe_level2_tile(p2, (int)c2, smem, tid);
+            }
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -370,14 +418,12 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p)
 // already fixed the last few in place: index >= fix_limit); it is subtracted here while loading.  A tile starts at a multiple
 // of 4 in absolute ring index, so samples are loaded as 16-byte pairs.  1/16 of the raw rate flows through here (cfg5).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
+// one level-2 tile (c = its index): the body of k_fe_level2; 256 threads, (FE_PAD + 2304) cf of LDS from `smem`
+static __device__ __forceinline__ void fe_level2_tile(const pmr_fe_params &p, const int c, char *smem, const int tid)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256;                                // 2048 ring samples per tile
     cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;       // input (layout L(8)), then z1 (L(4)), then z2 (L(2)), all in place
     cf *R0 = buf;
-    const int tid = threadIdx.x;
-    const int c = (int)pmr_xcd_contiguous(blockIdx.x, gridDim.x);
     const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // index of tile sample 0 among this call's new ring samples
 
     const unsigned long long qa = (unsigned long long)c * p.TQ;
@@ -445,7 +491,26 @@ __global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
     fe_arb_store<NT, 1>(p, ap, qa, R0, bk0, bk1, tid);
 }
 
+__global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    fe_level2_tile(p, (int)pmr_xcd_contiguous(blockIdx.x, gridDim.x), smem, (int)threadIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------
+#ifdef EXP_L2_INLINE
+static pmr_fe_params g_exp_p2;                      /* level-2 parameters of the block whose level 1 is launched next (one thread: timing only) */
+static unsigned long long *g_exp_cnt;
+extern "C" void pmr_exp_set_l2_params(const pmr_fe_params *p2)
+{
+    g_exp_p2 = *p2;
+    if (!g_exp_cnt) { (void)hipMalloc((void **)&g_exp_cnt, 4096 * sizeof(unsigned long long)); (void)hipMemset(g_exp_cnt, 0, 4096 * 8); }
+}
+#define FE_P2_ARG , g_exp_p2, g_exp_cnt
+#else
+#define FE_P2_ARG
+#endif
+
 template <int MODE, int N3, int TAIL>
 static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
@@ -454,7 +519,7 @@ static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, 
 #endif
     const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS + (MODE == FE_FULL ? p->lds_pad : 0u);
     auto kern = k_fe_fast<MODE, N3, TAIL>;
-    PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p);
+    PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p FE_P2_ARG);
     return (int)hipGetLastError();
 }
 
