@@ -137,7 +137,7 @@ struct pmr_chain_s {
     int fe_two;                      /* 1: two launches of k_frontend (modes 1 and 2)                 */
     int fe_s1;                       /* stages in level 1 (all 6-tap)                                  */
     int fe2_T_own, fe2_Hh, fe2_HhQ, fe2_TQ;   /* level-2 tile geometry, in level-1 output samples      */
-    int fe2_N0, fe2_fast;            /* level-2 tile size; specialised k_fe_level2 (m = 5, 10) selected   */
+    int fe2_N0, fe2_fast;            /* level-2 tile size; specialised k_fe_level2<MA, MB> selected       */
     float fe1_K;                     /* alpha * prod G_e (e < s1): dc-carry gain at the level-1 output */
     float *d_fe_G1;                  /* [..] fe1_K * mu^e: level 1's carry gain per tile-local index (level 2's load-time fix) */
     cfl *d_fe_ring1; uint64_t ring1_mask;
@@ -461,6 +461,10 @@ static int fe_init(pmr_chain q)
         S = 0;
         for (unsigned e = 0; e < s1; e++) S += (unsigned long)(4 * q->fe_m[e] - 2) << e;
         H = S;
+#ifdef EXP_L1_EXTRA_HALO   /* experiment (results stay CORRECT: a larger halo only): what would the halo of a level 1 that also ran the first
+                            * long stage cost?  (4 m - 2) 2^s1 = 288 more raw samples per tile at m = 5, s1 = 4 -- profiles/r06_ab_log.txt r6b */
+        H += EXP_L1_EXTRA_HALO;
+#endif
         L = D1 > 16 ? D1 : 16;
     }
     int nt = 0;
@@ -491,8 +495,8 @@ static int fe_init(pmr_chain q)
         unsigned long S2 = 0;
         for (unsigned e = s1; e < h; e++) S2 += (unsigned long)(4 * q->fe_m[e] - 2) << (e - s1);
         const unsigned long H2 = S2 + 13ul * D2, L2 = D2 > 16 ? D2 : 16;
-        /* level-2 tile: 2048 ring samples for the specialised kernel (m = 5, 10: k_fe_level2), 4096 for the generic one */
-        q->fe2_fast = (h - s1 == 2 && q->fe_m[s1] == 5 && q->fe_m[s1 + 1] == 10);
+        /* level-2 tile: 2048 ring samples for the specialised kernel (k_fe_level2<MA, MB>), 4096 for the generic one */
+        q->fe2_fast = h - s1 == 2 && pmr_fe_fast_covers(2, q->fe_m + s1, 2);      /* (MA, MB) is one of the pairs k_fe_level2 is built for */
         const unsigned long N2 = q->fe2_fast ? 2048 : 4096;
         if (H2 + L2 > N2) return PMR_OK;
         const unsigned long t2 = (N2 - H2) / L2 * L2;

@@ -58,7 +58,8 @@ typedef float fe_f4 __attribute__((ext_vector_type(4)));
 #define FE_STORE4(ptr, val) (*reinterpret_cast<float4 *>(ptr) = (val))
 #endif
 
-#define FE_PAD 64      /* elements in front of the tile buffer; >= (4*10-2) * (1 + 1/2) */
+#define FE_PAD 80      /* zeroed elements in front of the tile buffer: a stage's window left of sample 0, (4 m - 2) (1 + 1/G) elements in layout
+                          L(G); largest: m = 12 read in layout L(2) = 69 (the kernels static_assert their own) */
 
 static constexpr int fdiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 template <int G> static constexpr int loff(int e) { return e + fdiv(e, G); }   // layout offset of a constant index

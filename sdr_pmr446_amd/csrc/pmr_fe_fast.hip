@@ -1,11 +1,13 @@
 // pmr_fe_fast.hip -- the SPECIALISED front-end kernels for gfx950: dc-block -> half-band cascade -> arbitrary resampler
 // (reference src/sdr_pmr446.c:795-796: iirfilt_crcf_execute_block + msresamp_crcf_execute) for the cascades liquid's
-// As = 60 dB design produces: N3 six-tap stages (m = 3), then the m = 5 and m = 10 stages, then the 256 x 14 polyphase bank.
+// msresamp2 design produces at stop-bands of 50 ... 72 dB: N3 six-tap stages (m = 3), then two longer stages (MA, MB) = (5, 10) at the
+// reference's As = 60 dB (:426) -- (4, 8), (5, 9), (5, 11), (6, 11), (6, 12) for the designs around it (SURVEY A.3 is confidence [M]
+// on what liquid really picks: every pair gets the same kernels) --, then the 256 x 14 polyphase bank.
 //
-//   k_fe_fast<FE_FULL, N3, 1>   whole front end in one pass over the raw block (cfg2: N3 = 1, cfg3: N3 = 2; N3 = 0: the reference's
-//                               own 1.024 MS/s plan, whose cascade is just m = 5, m = 10)
-//   k_fe_fast<FE_L1,  N3, 0>    level 1 of a deep cascade (cfg5 / dsd_in: N3 = 4): dc-block + N3 six-tap stages -> decimated ring
-//   k_fe_level2                 level 2: ring in (level 1's dc carry applied at load) -> m = 5 -> m = 10 -> resampler
+//   k_fe_fast<FE_FULL, N3, MA, MB>  whole front end in one pass over the raw block (cfg2: N3 = 1, cfg3: N3 = 2; N3 = 0: the reference's
+//                                   own 1.024 MS/s plan, whose cascade is just the two long stages)
+//   k_fe_fast<FE_L1,  N3, 0, 0>     level 1 of a deep cascade (cfg5 / dsd_in: N3 = 4): dc-block + N3 six-tap stages -> decimated ring
+//   k_fe_level2<MA, MB>             level 2: ring in (level 1's dc carry applied at load) -> stage MA -> stage MB -> resampler
 //
 // Same arithmetic and the same order of operations as the run-time-parameterised k_frontend (pmr_frontend.hip); what is
 // specialised is WHEN things are fetched and how much instruction overhead surrounds the ~13 packed MACs per sample:
@@ -68,6 +70,7 @@ static __device__ __forceinline__ cf fe_raw(const void *x, long b, int fmt)
     return cfm(((float)(w & 0xffu) - 127.5f) * (1.0f / 127.5f), ((float)(w >> 8) - 127.5f) * (1.0f / 127.5f));
 }
 
+template <int MA, int MB>
 static __device__ __forceinline__ void fe_level2_tile(const pmr_fe_params &p, const int c, char *smem, const int tid);
 
 #ifdef EXP_L2_INLINE
@@ -82,10 +85,13 @@ static __device__ __forceinline__ void fe_level2_tile(const pmr_fe_params &p, co
 #define FE_P2_PARAM
 #endif
 
-template <int MODE, int N3, int TAIL>
+template <int MODE, int N3, int MA, int MB>
 __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 {
-    static_assert(N3 >= 1 || (MODE == FE_FULL && TAIL == 1), "a cascade without six-tap stages is (m = 5, m = 10)");
+    constexpr int TAIL = MA > 0 ? 1 : 0;
+    static_assert((MA > 0) == (MB > 0), "the two long stages come as a pair");
+    static_assert(N3 >= 1 || (MODE == FE_FULL && TAIL == 1), "a cascade without six-tap stages is the two long stages");
+    static_assert((4 * MB - 2) * 3 / 2 <= FE_PAD && (4 * MA - 2) * 3 / 2 <= FE_PAD, "zero pad in front of the tile: a stage's window left of sample 0");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256, SPT = 16, N0 = NT * SPT;
     constexpr int H = N3 + 2 * TAIL;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 #define FE_STAGE(E, MM, TOFF) do { constexpr int NOUT = (N0 / 2) >> (E); constexpr int PP = NOUT >= NT ? NOUT / NT : 1;          \
         hb_stage_pp<PP, MM>(((E) & 1) ? R0 : R1, ((E) & 1) ? R1 : R0, tid, NOUT / PP, p.taps_k + (TOFF),                         \
                             (E) == H - 1 ? p.zeta : 1.0f); } while (0)
-    // six-tap stages 1 .. N3-1 (taps at 6 e), then the m = 5 and m = 10 stages
+    // six-tap stages 1 .. N3-1 (taps at 6 e), then the two long stages (m = MA, MB: 5 and 10 in the reference's design)
     if constexpr (N3 >= 2) FE_STAGE(1, 3, 6);
     if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
     // level 1 with four six-tap stages (cfg5, dsd_in): the last stage has one output per thread -- it stays in a register and goes
@@ -315,15 +321,15 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 #ifdef FE_LAST_LDS        /* A/B hook: the last stage through LDS like the others */
     constexpr bool LAST_IN_REG = false;
 #else
-    constexpr bool LAST_IN_REG = MODE == FE_L1 && N3 == 4;
+    constexpr bool LAST_IN_REG = MODE == FE_L1 && N3 == 4 && !TAIL;
 #endif
     cf ylast = cfm(0.f, 0.f);
     if constexpr (LAST_IN_REG) ylast = hb_stage_out1<3>(R0, tid, p.taps_k + 18, p.zeta);
     else if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
     if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
-    if constexpr (TAIL && N3 == 0) hb_stage_ip<8, 5>(buf, tid, NT, p.taps_k, 1.0f);            // 2048 outputs, L(16) -> L(8), in place
-    else if constexpr (TAIL) FE_STAGE(N3, 5, 6 * N3);
-    if constexpr (TAIL) FE_STAGE(N3 + 1, 10, 6 * N3 + 10);
+    if constexpr (TAIL && N3 == 0) hb_stage_ip<8, MA>(buf, tid, NT, p.taps_k, 1.0f);           // 2048 outputs, L(16) -> L(8), in place
+    else if constexpr (TAIL) FE_STAGE(N3, MA, 6 * N3);
+    if constexpr (TAIL) FE_STAGE(N3 + 1, MB, 6 * N3 + 2 * MA);
 #undef FE_STAGE
     constexpr int NLAST = (N0 / 2) >> (H - 1);
     constexpr int PLAST = H == 1 ? 8 : (NLAST >= NT ? NLAST / NT : 1);
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
                 }
 #endif
                 __syncthreads();                                           // every wave is done with the level-1 tile's LDS
-                fe_level2_tile(p2, (int)c2, smem, tid);
+                fe_level2_tile<5, 10>(p2, (int)c2, smem, tid);
             }
         }
     }
@@ -413,12 +419,13 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Level 2 of the two-level front end: 2048 samples of the decimated ring per tile -> m = 5 stage -> m = 10 stage -> resampler.
+// Level 2 of the two-level front end: 2048 samples of the decimated ring per tile -> stage MA -> stage MB -> resampler.
 // The ring samples produced by THIS call still miss level 1's dc carry, V_c1 * K1 * mu^i' (k_fe_carry computed the V_c1 and
 // already fixed the last few in place: index >= fix_limit); it is subtracted here while loading.  A tile starts at a multiple
 // of 4 in absolute ring index, so samples are loaded as 16-byte pairs.  1/16 of the raw rate flows through here (cfg5).
 // ---------------------------------------------------------------------------------------------
 // one level-2 tile (c = its index): the body of k_fe_level2; 256 threads, (FE_PAD + 2304) cf of LDS from `smem`
+template <int MA, int MB>
 static __device__ __forceinline__ void fe_level2_tile(const pmr_fe_params &p, const int c, char *smem, const int tid)
 {
     constexpr int NT = 256;                                // 2048 ring samples per tile
@@ -486,15 +493,17 @@ static __device__ __forceinline__ void fe_level2_tile(const pmr_fe_params &p, co
 #ifdef EXP_L2_STOP1      /* timing experiment: level 2 = loads + staging only */
     if (p.n_in != 0xffffffffu) return;
 #endif
-    hb_stage_ip<4, 5>(R0, tid, NT, p.taps_k, 1.0f);                        // 1024 outputs, L(8) -> L(4), in place
-    hb_stage_ip<2, 10>(R0, tid, NT, p.taps_k + 10, p.zeta);                //  512 outputs, L(4) -> L(2), in place
+    hb_stage_ip<4, MA>(R0, tid, NT, p.taps_k, 1.0f);                       // 1024 outputs, L(8) -> L(4), in place
+    hb_stage_ip<2, MB>(R0, tid, NT, p.taps_k + 2 * MA, p.zeta);            //  512 outputs, L(4) -> L(2), in place
     fe_arb_store<NT, 1>(p, ap, qa, R0, bk0, bk1, tid);
 }
 
-__global__ __launch_bounds__(256, 6) void k_fe_level2(pmr_fe_params p)
+template <int MA, int MB>
+__global__ __launch_bounds__(256, MB <= 10 ? 6 : 5) void k_fe_level2(pmr_fe_params p)      // (80 VGPRs; the longer pairs would spill: 96)
 {
+    static_assert((4 * MB - 2) * 5 / 4 <= FE_PAD, "zero pad in front of the tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    fe_level2_tile(p, (int)pmr_xcd_contiguous(blockIdx.x, gridDim.x), smem, (int)threadIdx.x);
+    fe_level2_tile<MA, MB>(p, (int)pmr_xcd_contiguous(blockIdx.x, gridDim.x), smem, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -511,55 +520,76 @@ extern "C" void pmr_exp_set_l2_params(const pmr_fe_params *p2)
 #define FE_P2_ARG
 #endif
 
-template <int MODE, int N3, int TAIL>
+template <int MODE, int N3, int MA, int MB>
 static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
 #ifndef FE_EXTRA_LDS
 #define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup on top of pmr_fe_params.lds_pad */
 #endif
     const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS + (MODE == FE_FULL ? p->lds_pad : 0u);
-    auto kern = k_fe_fast<MODE, N3, TAIL>;
+    auto kern = k_fe_fast<MODE, N3, MA, MB>;
     PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p FE_P2_ARG);
     return (int)hipGetLastError();
 }
 
-/* the specialised kernels cover: N3 six-tap stages, then optionally (m = 5, m = 10); 256 x 16 tiles */
-static int fast_pattern_m(const int *m, int h, int *n3, int *tail)
+/* The (MA, MB) pairs the kernels are instantiated for: what liquid's msresamp2 design yields for the two stages next to the output
+ * at stop-bands of 50 ... 72 dB (pmr_design.c; As = 60 -- the reference, :426 -- gives (5, 10)).  tools/ab_libs.py --resamp-as,
+ * tests/test_gpu_parity.py (As parameter). */
+#define FE_TAIL_PAIRS(X) X(4, 8) X(5, 9) X(5, 10) X(5, 11) X(6, 11) X(6, 12)
+static int tail_pair_ok(int ma, int mb)
+{
+#define X(A, B) if (ma == A && mb == B) return 1;
+    FE_TAIL_PAIRS(X)
+#undef X
+    return 0;
+}
+
+/* the specialised kernels cover: N3 six-tap stages, then optionally one of the pairs above; 256 x 16 tiles */
+static int fast_pattern_m(const int *m, int h, int *n3, int *ma, int *mb)
 {
     int k = 0;
     while (k < h && m[k] == 3) k++;
-    *n3 = k;
-    if (k == h) { *tail = 0; return k >= 1; }
-    if (k + 2 == h && m[k] == 5 && m[k + 1] == 10) { *tail = 1; return 1; }
+    *n3 = k; *ma = 0; *mb = 0;
+    if (k == h) return k >= 1;
+    if (k + 2 == h && tail_pair_ok(m[k], m[k + 1])) { *ma = m[k]; *mb = m[k + 1]; return 1; }
     return 0;
 }
-static int fast_pattern(const pmr_fe_params *p, int *n3, int *tail) { return fast_pattern_m(p->m, p->h, n3, tail); }
 
 extern "C" int pmr_fe_fast_covers(int mode, const int *m, int h)
 {
-    int n3 = 0, tail = 0;
-    if (!fast_pattern_m(m, h, &n3, &tail)) return 0;
-    if (mode == FE_FULL) return tail && n3 <= 3;
-    if (mode == FE_L1) return !tail && n3 >= 2 && n3 <= 5;
+    int n3 = 0, ma = 0, mb = 0;
+    if (!fast_pattern_m(m, h, &n3, &ma, &mb)) return 0;
+    if (mode == FE_FULL) return ma && n3 <= 3;
+    if (mode == FE_L1) return !ma && n3 >= 2 && n3 <= 5;
+    if (mode == 2) return ma && n3 == 0;             /* level 2: the pair alone */
     return 0;
+}
+
+template <int MA, int MB>
+static int launch_full(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev, int n3)
+{
+    if (n3 == 0) return launch_fast<FE_FULL, 0, MA, MB>(st, p, ntiles, ev);
+    if (n3 == 1) return launch_fast<FE_FULL, 1, MA, MB>(st, p, ntiles, ev);
+    if (n3 == 2) return launch_fast<FE_FULL, 2, MA, MB>(st, p, ntiles, ev);
+    if (n3 == 3) return launch_fast<FE_FULL, 3, MA, MB>(st, p, ntiles, ev);
+    return -1;
 }
 
 extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev)
 {
     hipStream_t st = (hipStream_t)s;
-    int n3 = 0, tail = 0;
-    if (!p->taps_valid || !fast_pattern(p, &n3, &tail)) return -1;
-    if (p->mode == FE_FULL && tail) {
-        if (n3 == 0) return launch_fast<FE_FULL, 0, 1>(st, p, ntiles, ev);
-        if (n3 == 1) return launch_fast<FE_FULL, 1, 1>(st, p, ntiles, ev);
-        if (n3 == 2) return launch_fast<FE_FULL, 2, 1>(st, p, ntiles, ev);
-        if (n3 == 3) return launch_fast<FE_FULL, 3, 1>(st, p, ntiles, ev);
+    int n3 = 0, ma = 0, mb = 0;
+    if (!p->taps_valid || !fast_pattern_m(p->m, p->h, &n3, &ma, &mb)) return -1;
+    if (p->mode == FE_FULL && ma) {
+#define X(A, B) if (ma == A && mb == B) return launch_full<A, B>(st, p, ntiles, ev, n3);
+        FE_TAIL_PAIRS(X)
+#undef X
     }
-    if (p->mode == FE_L1 && !tail) {
-        if (n3 == 2) return launch_fast<FE_L1, 2, 0>(st, p, ntiles, ev);
-        if (n3 == 3) return launch_fast<FE_L1, 3, 0>(st, p, ntiles, ev);
-        if (n3 == 4) return launch_fast<FE_L1, 4, 0>(st, p, ntiles, ev);
-        if (n3 == 5) return launch_fast<FE_L1, 5, 0>(st, p, ntiles, ev);
+    if (p->mode == FE_L1 && !ma) {
+        if (n3 == 2) return launch_fast<FE_L1, 2, 0, 0>(st, p, ntiles, ev);
+        if (n3 == 3) return launch_fast<FE_L1, 3, 0, 0>(st, p, ntiles, ev);
+        if (n3 == 4) return launch_fast<FE_L1, 4, 0, 0>(st, p, ntiles, ev);
+        if (n3 == 5) return launch_fast<FE_L1, 5, 0, 0>(st, p, ntiles, ev);
     }
     return -1;
 }
@@ -567,7 +597,10 @@ extern "C" int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsign
 extern "C" int pmr_launch_fe_level2_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles)
 {
     if (!ntiles) return 0;
-    const size_t lds = (FE_PAD + (2048 + 256)) * sizeof(cf);          /* 18.9 KB: the stages run in place */
-    PMR_KLAUNCH(k_fe_level2, dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p);
-    return (int)hipGetLastError();
+    if (p->h != 2 || !p->taps_valid) return -1;
+    const size_t lds = (FE_PAD + (2048 + 256)) * sizeof(cf);          /* 19 KB: the stages run in place */
+#define X(A, B) if (p->m[0] == A && p->m[1] == B) { PMR_KLAUNCH((k_fe_level2<A, B>), dim3(ntiles), dim3(256), lds, (hipStream_t)s, *p); return (int)hipGetLastError(); }
+    FE_TAIL_PAIRS(X)
+#undef X
+    return -1;
 }

@@ -229,7 +229,7 @@ typedef struct {
     float dc_a1, zeta, lam_wave;
     float lam_pow16[6];         /* lambda^(spt * 2^j)                                                */
     int taps_valid;             /* taps_k holds all taps of this launch (they fit)                    */
-    float taps_k[48];           /* copy of this launch's branch taps (its stages only, execution order) in the kernel
+    float taps_k[64];           /* copy of this launch's branch taps (its stages only, execution order) in the kernel
                                    argument segment: the specialised kernel reads them as scalars, no pointer chase */
 } pmr_fe_params;
 
@@ -262,7 +262,8 @@ int pmr_launch_frontend(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles,
 int pmr_launch_frontend_l2(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, int fast);
 /* specialised kernels of pmr_fe_fast.hip; return -1 when the cascade is not one they cover */
 int pmr_launch_fe_fast(pmr_stream_t s, const pmr_fe_params *p, unsigned ntiles, const pmr_launch_events *ev);
-/* does a specialised kernel exist for this cascade (mode 0: whole front end, 1: level 1; m[0..h): stages in execution order)? */
+/* does a specialised kernel exist for this cascade (mode 0: whole front end, 1: level 1, 2: level 2; m[0..h): stages in execution
+ * order)?  Six-tap stages followed by one of the (MA, MB) pairs pmr_fe_fast.hip instantiates */
 int pmr_fe_fast_covers(int mode, const int *m, int h);
 /* tile carries of a level-1 launch (V[c], next call's dc state) + in-place dc fix of the ring samples [f->j0, f->ny) */
 int pmr_launch_fe_carry(pmr_stream_t s, const pmr_fe_tiles_params *t, const pmr_fe_fix_params *f);

@@ -116,6 +116,33 @@ def test_cfg5_1024_channels():
     _compare(fs, M, x, [1 << 24, 1 << 24], synth_ch=ks)
 
 
+# liquid picks the half-band lengths at run time (msresamp_crcf_create(.., As), :425-426); SURVEY A.3 recalls (3, ..., 5, 10) for As = 60 at
+# confidence [M].  The specialised front end therefore takes EVERY pair of long stages a 50 ... 72 dB design yields -- (4, 8), (5, 9),
+# (5, 10), (5, 11), (6, 11), (6, 12) -- and each must select the specialised plan and keep parity.
+AS_PAIRS = {50.0: (4, 8), 55.0: (5, 9), 65.0: (5, 11), 68.0: (6, 11), 70.0: (6, 12)}
+
+
+@pytest.mark.parametrize("cfg,n,As", [(CFG_REF, 200000, 55.0), (CFG_REF, 200000, 70.0),
+                                      (CFG2, 1 << 19, 50.0), (CFG2, 1 << 19, 55.0), (CFG2, 1 << 19, 65.0), (CFG2, 1 << 19, 68.0), (CFG2, 1 << 19, 70.0),
+                                      (CFG3, 1 << 22, 55.0), (CFG3, 1 << 22, 65.0), (CFG3, 1 << 22, 70.0),
+                                      (CFG5, 1 << 25, 55.0), (CFG5, 1 << 25, 65.0), (CFG5, 1 << 25, 70.0)],
+                         ids=lambda v: ("%d-ch" % v[1] if isinstance(v, tuple) else str(v)))
+def test_other_stop_bands_keep_the_specialised_front_end_and_parity(cfg, n, As):
+    from sdr_pmr446_amd import chain
+    fs, M = cfg
+    g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=n, resamp_As=As)
+    h = g.info(0)
+    stages = [g.info(1, i) for i in range(h)]                         # design order: the stage next to the output first
+    plan = g.info(8)
+    g.close()
+    assert (stages[1], stages[0]) == AS_PAIRS[As] and all(m == 3 for m in stages[2:]), stages
+    assert plan == (3 if M == 1024 else 2), "As = %g no longer selects the specialised front end (plan %d)" % (As, plan)
+    ks = None if M <= 16 else list(range(0, M, 5 if M == 256 else 73))
+    x = synth.synth_iq(n, fs, M, channels=ks, dev_hz=500.0)
+    a = n // 2 + 12345
+    _compare(fs, M, x, [a, n - a], synth_ch=ks, resamp_As=As)
+
+
 @pytest.mark.parametrize("fs,M,n", [(819.2e6, 4096, 1 << 24), (409.6e6, 4096, 1 << 23), (102.4e6, 2048, 1 << 22), (6.4e6, 64, 1 << 20),
                                     (1.6e6, 4, 1 << 18)],
                          ids=["4096ch-h3", "4096ch-h2-no-six-tap-stage", "2048ch-generic-bank", "64ch", "4ch"])

@@ -23,7 +23,7 @@ CASES = [
     # id, fs_in, M, extra cfg, splits, expected (fe, chan, fir) plan
     ("staged-front-end-h12-4ch", 4 * 12500.0 * 5120.0, 4, {}, [700000, 1, 499999, 650000], (0, 0, 0)),
     ("generic-tile-kernel-As80", 2.4e6, 16, dict(resamp_As=80.0), [150000, 1, 99999, 130000], (1, 1, 2)),
-    ("generic-tile-kernel-As75-1024ch", 1.0e9, 1024, dict(resamp_As=75.0), [1 << 22, 3000000], (1, 3, 2)),
+    ("generic-tile-kernel-As75-1024ch", 1.0e9, 1024, dict(resamp_As=75.0), [1 << 22, 3000000], (1, 3, 2)),   # (6, 13) behind an m = 4 stage
     ("two-level-generic-level1-256ch-1GSps", 1.0e9, 256, {}, [1 << 22, 3000001], (4, 2, 2)),     # six six-tap stages in level 1
     ("generic-bank-16ch-m9", 2.4e6, 16, dict(pfb_m=9), [150000, 1, 99999, 130000], (2, 0, 2)),
     ("generic-bank-32ch", 4.8e6, 32, {}, [300000, 3, 199999], (2, 0, 2)),

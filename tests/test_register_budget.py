@@ -18,7 +18,8 @@ BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, w
     ("pmr_fe_fast.hip", r"k_fe_fastILi0ELi[1-9]E", 88, "one-level front end: four tiles per SIMD + one 160-register back-end wave"),
     ("pmr_fe_fast.hip", r"k_fe_fastILi0ELi0E", 96, "one-level front end of the reference's own 1.024 MS/s plan (small blocks: its back end is the 64- / 84-register small-block kernels)"),
     ("pmr_fe_fast.hip", r"k_fe_fastILi1E", 64, "level 1 of the two-level front end"),
-    ("pmr_fe_fast.hip", r"k_fe_level2", 80, "level 2 runs beside four level-1 tiles"),
+    ("pmr_fe_fast.hip", r"k_fe_level2ILi5ELi10E", 80, "level 2 (the reference's As = 60 pair) runs beside four level-1 tiles"),
+    ("pmr_fe_fast.hip", r"k_fe_level2", 96, "level 2 for the other (MA, MB) pairs: five waves per SIMD, still beside four 54-register level-1 tiles"),
     ("pmr_fir_fft.hip", r"k_fir_fftILi4ELb0E", 128, "FFT form of the audio FIR (1024 points): one-wave workgroups, four per SIMD, beside four front-end tiles"),
     ("pmr_fir_fft.hip", r"k_fir_fftILi8ELb0E", 128, "FFT form of the audio FIR (2048 points): two-wave workgroups beside four front-end tiles"),
     ("pmr_fir_mfma4.hip", r"k_fir_mfma4ILb0ELb0ELb0E", 64, "128-frame audio FIR: four workgroups per CU"),
@@ -30,7 +31,7 @@ BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, w
 def _counts(unit):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        flags = os.environ.get("PMR_HIPCC_FLAGS", "-fno-slp-vectorize").split()
+        flags = ["-fno-slp-vectorize"]                      # the product's flags (build.PRODUCT_HIP_FLAGS)
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S"] + flags +
                               [os.path.join(CSRC, unit), "-o", out], stderr=subprocess.DEVNULL)
         txt = open(out).read()
