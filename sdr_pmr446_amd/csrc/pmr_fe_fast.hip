@@ -95,6 +95,13 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256, SPT = 16, N0 = NT * SPT;
     constexpr int H = N3 + 2 * TAIL;
+    // stage 1 (execution index 1: a six-tap stage when N3 >= 2, else the first long stage) computed from registers, see phase B
+    constexpr int M1 = N3 >= 2 ? 3 : (MA > 0 ? MA : 3);
+#ifdef FE_S1_LDS            /* A/B hook: stage 1 through LDS like the later stages (rounds 2-5) */
+    constexpr bool S1_REG = false;
+#else
+    constexpr bool S1_REG = N3 >= 1 && H >= 2;
+#endif
     constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;         // z1 (2048 samples, layout L(8)) fills [0, R1_OFF) of the tile area
     // LDS: [FE_PAD zero pad | raw tile, 4096 samples = 2048 swizzled 16-byte chunks; afterwards R0 (z1, 2304 slots) and
     // R1 (z2, 1280 slots) | scan scratch] = 33.6 KB -> four tiles per CU
@@ -295,13 +302,68 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
         }
         // z1[8 tid + q] = W[2q + 5] + sum_j h1[j] W[2q + 2j]   (window offset 0 <-> sample 16 tid - 10)
         const float scale0 = H == 1 ? p.zeta : 1.0f;
-        cf *o = buf + tid * 9;                             // z1 in layout L(8), region R0 (over the raw tile)
+        cf z[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             cf a = cfm(0.f, 0.f);
 #pragma unroll
             for (int j = 0; j < 6; j++) a = cfma(p.taps_k[j], W[2 * q + 2 * j], a);
-            o[q] = cadd_scale(W[2 * q + 5], a, scale0);
+            z[q] = cadd_scale(W[2 * q + 5], a, scale0);
+        }
+        if constexpr (!S1_REG) {
+            cf *o = buf + tid * 9;                         // z1 in layout L(8), region R0 (over the raw tile)
+#pragma unroll
+            for (int q = 0; q < 8; q++) o[q] = z[q];
+        } else {
+            // STAGE 1 STRAIGHT FROM REGISTERS (round 6): thread t holds z1[8t .. 8t + 7]; its four stage-1 outputs need z1[8t - (4 M1 - 2) ..
+            // 8t + 6], i.e. elements of the LM threads to its left -- brought over by chained DPP wave_shr:1 moves (S[s][e] = element e of
+            // thread t - s) instead of a write of all of z1 to LDS and 13 - 17 window reads back per thread.  Only a wave's first LM lanes
+            // need the previous wave's last LM lanes: those go through LDS (96 complex numbers per tile; the raw tile is dead: every
+            // thread holds its samples since the scan's barrier).  Same operations in the same order as hb_stage_pp<4, M1>: bit-identical.
+            constexpr int LM = (4 * M1 - 2 + 7) / 8;
+            static_assert(LM <= 3, "stage 1 reaches at most three threads to the left");
+            cf *bz = buf;                                                       // [4 waves][3 lanes][8]
+            if (lane >= 61) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) bz[(wave * 3 + (lane - 61)) * 8 + e] = z[e];
+            }
+            __syncthreads();
+            cf S[LM + 1][8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) S[0][e] = z[e];
+#pragma unroll
+            for (int sft = 1; sft <= LM; sft++) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) S[sft][e] = dpp0c<0x138>(S[sft - 1][e]);               // wave_shr:1 (lane 0 <- 0)
+            }
+            if (wave > 0 && lane < LM) {
+#pragma unroll
+                for (int sft = 1; sft <= LM; sft++) {
+                    if (lane < sft) {
+                        const cf *src = bz + ((wave - 1) * 3 + (3 + lane - sft)) * 8;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) S[sft][e] = src[e];
+                    }
+                }
+            }
+            // z1 at index 8t + REL, REL in [-(4 M1 - 2), 7]: thread t - L's element REL + 8 L
+            const float scale1 = H == 2 ? p.zeta : 1.0f;
+            cf y[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; pp++) {
+                cf a = cfm(0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 2 * M1; j++) {
+                    const int rel = 2 * pp - (4 * M1 - 2) + 2 * j, L = (7 - rel) / 8;              // rel <= 6: L = ceil(-rel / 8)
+                    a = cfma(p.taps_k[6 + j], S[L][rel + 8 * L], a);
+                }
+                const int rd = 2 * pp + 1 - 2 * M1, Ld = (7 - rd) / 8;
+                y[pp] = cadd_scale(S[Ld][rd + 8 * Ld], a, scale1);
+            }
+            // (no barrier here: bz lies in R0's first 96 slots, the outputs go to R1; R0 is not written before the barrier that ends phase B)
+            cf *o = buf + R1_OFF + tid * 5;                                     // stage 1's outputs, layout L(4), region R1 (as hb_stage_pp<4, .> leaves them)
+#pragma unroll
+            for (int pp = 0; pp < 4; pp++) o[pp] = y[pp];
         }
     }
         }
@@ -314,7 +376,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
         hb_stage_pp<PP, MM>(((E) & 1) ? R0 : R1, ((E) & 1) ? R1 : R0, tid, NOUT / PP, p.taps_k + (TOFF),                         \
                             (E) == H - 1 ? p.zeta : 1.0f); } while (0)
     // six-tap stages 1 .. N3-1 (taps at 6 e), then the two long stages (m = MA, MB: 5 and 10 in the reference's design)
-    if constexpr (N3 >= 2) FE_STAGE(1, 3, 6);
+    if constexpr (N3 >= 2 && !S1_REG) FE_STAGE(1, 3, 6);
     if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
     // level 1 with four six-tap stages (cfg5, dsd_in): the last stage has one output per thread -- it stays in a register and goes
     // straight to the ring (below): one LDS write, one barrier and two LDS reads less at the end of the tile's life
@@ -328,7 +390,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
     else if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
     if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
     if constexpr (TAIL && N3 == 0) hb_stage_ip<8, MA>(buf, tid, NT, p.taps_k, 1.0f);           // 2048 outputs, L(16) -> L(8), in place
-    else if constexpr (TAIL) FE_STAGE(N3, MA, 6 * N3);
+    else if constexpr (TAIL && !(S1_REG && N3 == 1)) FE_STAGE(N3, MA, 6 * N3);
     if constexpr (TAIL) FE_STAGE(N3 + 1, MB, 6 * N3 + 2 * MA);
 #undef FE_STAGE
     constexpr int NLAST = (N0 / 2) >> (H - 1);

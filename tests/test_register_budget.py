@@ -1,6 +1,8 @@
-"""The kernels' VGPR counts are part of the design: four front-end tiles (4 x 88 registers per SIMD) leave 160 for a back-end
-wave, so every back-end kernel must stay <= 160 (the FFT audio FIR <= 128) and the front end <= 88 -- a build that crossed either line by five registers
-cost the cfg2 chain 8-10 % with no test failing (profiles/r03_ab_log.txt).  Cross-compiles the units for
+"""The kernels' VGPR counts are part of the design: a SIMD has 512 registers, allocated in granules of 8.  Four front-end tiles at <= 96
+(= 384) leave 128 for one back-end wave, so the front end must stay <= 96 and every back-end kernel of the hot path <= 128 -- a build that
+crossed either line by five registers cost the cfg2 chain 8-10 % with no test failing (profiles/r03_ab_log.txt).  (Rounds
+3-5 held the front end to 88 and the back end to 160; round 6's stage 1 from registers needs 89 = the same 96-register granule, and no
+back-end kernel of the chain is above 128: profiles/r06_ab_log.txt r6e.)  Cross-compiles the units for
 gfx950 (no GPU needed) and reads the counts from the code objects' metadata."""
 import os
 import re
@@ -15,7 +17,7 @@ CSRC = os.path.join(ROOT, "sdr_pmr446_amd", "csrc")
 HIPCC = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
 
 BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, why)
-    ("pmr_fe_fast.hip", r"k_fe_fastILi0ELi[1-9]E", 88, "one-level front end: four tiles per SIMD + one 160-register back-end wave"),
+    ("pmr_fe_fast.hip", r"k_fe_fastILi0ELi[1-9]E", 96, "one-level front end: four tiles per SIMD (4 x 96) + one 128-register back-end wave"),
     ("pmr_fe_fast.hip", r"k_fe_fastILi0ELi0E", 96, "one-level front end of the reference's own 1.024 MS/s plan (small blocks: its back end is the 64- / 84-register small-block kernels)"),
     ("pmr_fe_fast.hip", r"k_fe_fastILi1E", 64, "level 1 of the two-level front end"),
     ("pmr_fe_fast.hip", r"k_fe_level2ILi5ELi10E", 80, "level 2 (the reference's As = 60 pair) runs beside four level-1 tiles"),
@@ -23,6 +25,8 @@ BUDGET = [                      # (unit, regex on the mangled name, max VGPRs, w
     ("pmr_fir_fft.hip", r"k_fir_fftILi4ELb0E", 128, "FFT form of the audio FIR (1024 points): one-wave workgroups, four per SIMD, beside four front-end tiles"),
     ("pmr_fir_fft.hip", r"k_fir_fftILi8ELb0E", 128, "FFT form of the audio FIR (2048 points): two-wave workgroups beside four front-end tiles"),
     ("pmr_fir_mfma4.hip", r"k_fir_mfma4ILb0ELb0ELb0E", 64, "128-frame audio FIR: four workgroups per CU"),
+    ("pmr_channelize_wide.hip", r"k_pfb_wide", 128, "1024-channel bank: beside four level-1 tiles"),
+    ("pmr_channelize_wide.hip", r"k_fft_disc", 128, "FFT + discriminator of the wide banks"),
     ("pmr_channelize_small.hip", r"k_channelize_winILi16ELi26ELb1ELi16E", 88, "16-channel bank: a wave fits beside four front-end tiles with room to spare"),
     ("pmr_channelize_wide.hip", r"k_channelize_fused256ILb1E", 128, "256-channel bank: four waves per SIMD"),
 ]
