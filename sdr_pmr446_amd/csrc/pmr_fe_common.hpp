@@ -128,6 +128,56 @@ static __device__ __forceinline__ cf hb_stage_out1(const cf *__restrict__ src, i
     return cadd_scale(wd, a, scale);
 }
 
+// a stage whose INPUT sits in registers (round 6): thread t holds zin[e] = z[PIN t + e] and computes its PIN / 2 outputs
+//   y[p] = z[2o + 1 - 2 MM] + sum_j h1[j] z[2o - (4 MM - 2) + 2j],  o = (PIN / 2) t + p     (hb_stage_pp's arithmetic, same order: bit-identical)
+// The window reaches LM = ceil((4 MM - 2) / PIN) threads to the left: chained DPP wave_shr:1 moves bring their elements over
+// (S[s][e] = element e of thread t - s; the compiler drops the ones no tap uses) instead of a write of every sample to LDS and a
+// window of reads back.  Only a wave's first LM lanes need the previous wave's last LM lanes: those PIN LM samples per wave go
+// through `xch` ([4 waves][LM][PIN], LDS), ONE barrier.  Wave 0's first lanes read zeros there (left of the tile: halo only).
+// Consecutive register stages must use different `xch` areas (a fast wave may publish the next stage's samples while a slow one
+// still reads this stage's).
+template <int PIN, int MM>
+static __device__ __forceinline__ void hb_stage_reg(const cf (&zin)[PIN], cf (&y)[PIN / 2], cf *xch, int lane, int wave,
+                                                    const float *h1, float scale)
+{
+    constexpr int LM = (4 * MM - 2 + PIN - 1) / PIN;
+    static_assert(LM <= 8 && PIN >= 2, "hb_stage_reg: the window must stay within a few threads");
+    if (lane >= 64 - LM) {
+#pragma unroll
+        for (int e = 0; e < PIN; e++) xch[(wave * LM + (lane - (64 - LM))) * PIN + e] = zin[e];
+    }
+    __syncthreads();
+    cf S[LM + 1][PIN];
+#pragma unroll
+    for (int e = 0; e < PIN; e++) S[0][e] = zin[e];
+#pragma unroll
+    for (int sft = 1; sft <= LM; sft++) {
+#pragma unroll
+        for (int e = 0; e < PIN; e++) S[sft][e] = dpp0c<0x138>(S[sft - 1][e]);                     // wave_shr:1 (lane 0 <- 0)
+    }
+    if (wave > 0 && lane < LM) {
+#pragma unroll
+        for (int sft = 1; sft <= LM; sft++) {
+            if (lane < sft) {
+                const cf *src = xch + ((wave - 1) * LM + (LM + lane - sft)) * PIN;
+#pragma unroll
+                for (int e = 0; e < PIN; e++) S[sft][e] = src[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int pp = 0; pp < PIN / 2; pp++) {
+        cf a = cfm(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 2 * MM; j++) {
+            const int rel = 2 * pp - (4 * MM - 2) + 2 * j, L = (PIN - 1 - rel) / PIN;              // rel <= PIN - 2: L = ceil(-rel / PIN)
+            a = cfma(h1[j], S[L][rel + PIN * L], a);
+        }
+        const int rd = 2 * pp + 1 - 2 * MM, Ld = (PIN - 1 - rd) / PIN;
+        y[pp] = cadd_scale(S[Ld][rd + PIN * Ld], a, scale);
+    }
+}
+
 // the same stage IN PLACE: read window -> barrier -> write over the input -> barrier.  Two barriers instead of one, half the LDS
 // (a level-2 tile then fits beside four level-1 tiles on a CU).
 template <int P, int MM>

@@ -102,6 +102,12 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 #else
     constexpr bool S1_REG = N3 >= 1 && H >= 2;
 #endif
+#if defined(FE_LAST_LDS) || defined(FE_L1_LDS23)   /* A/B hooks: level 1's stages 2 (and 3: FE_LAST_LDS) through LDS, as in rounds 4-5 */
+    constexpr bool ALL_REG = false;
+#else
+    constexpr bool ALL_REG = S1_REG && MODE == FE_L1 && N3 == 4 && !TAIL;
+#endif
+    cf ylast = cfm(0.f, 0.f);                              // level 1's last-stage output of this thread (LAST_IN_REG / ALL_REG)
     constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;         // z1 (2048 samples, layout L(8)) fills [0, R1_OFF) of the tile area
     // LDS: [FE_PAD zero pad | raw tile, 4096 samples = 2048 swizzled 16-byte chunks; afterwards R0 (z1, 2304 slots) and
     // R1 (z2, 1280 slots) | scan scratch] = 33.6 KB -> four tiles per CU
@@ -315,58 +321,29 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 #pragma unroll
             for (int q = 0; q < 8; q++) o[q] = z[q];
         } else {
-            // STAGE 1 STRAIGHT FROM REGISTERS (round 6): thread t holds z1[8t .. 8t + 7]; its four stage-1 outputs need z1[8t - (4 M1 - 2) ..
-            // 8t + 6], i.e. elements of the LM threads to its left -- brought over by chained DPP wave_shr:1 moves (S[s][e] = element e of
-            // thread t - s) instead of a write of all of z1 to LDS and 13 - 17 window reads back per thread.  Only a wave's first LM lanes
-            // need the previous wave's last LM lanes: those go through LDS (96 complex numbers per tile; the raw tile is dead: every
-            // thread holds its samples since the scan's barrier).  Same operations in the same order as hb_stage_pp<4, M1>: bit-identical.
-            constexpr int LM = (4 * M1 - 2 + 7) / 8;
-            static_assert(LM <= 3, "stage 1 reaches at most three threads to the left");
-            cf *bz = buf;                                                       // [4 waves][3 lanes][8]
-            if (lane >= 61) {
+            // STAGE 1 STRAIGHT FROM REGISTERS (round 6, hb_stage_reg): thread t holds z1[8t .. 8t + 7]; the elements of the threads to its
+            // left that its four outputs need come by DPP, a wave's first lanes get theirs through 96 samples of LDS (the raw tile is
+            // dead: every thread holds its samples since the scan's barrier) -- instead of a write of all of z1 to LDS and 13 - 17
+            // window reads back per thread.  Same operations in the same order as hb_stage_pp<4, M1>: bit-identical (tools/pcm_hash.py).
+            cf y1[4];
+            hb_stage_reg<8, M1>(z, y1, buf, lane, wave, p.taps_k + 6, H == 2 ? p.zeta : 1.0f);
+            if constexpr (ALL_REG) {
+                // level 1 of the deep cascades (cfg5, dsd_in): the remaining two six-tap stages the same way -- no stage of this kernel
+                // goes through LDS any more, only 184 boundary samples per tile do
+                cf y2[2], y3[1];
+                hb_stage_reg<4, 3>(y1, y2, buf + 96, lane, wave, p.taps_k + 12, 1.0f);
+                hb_stage_reg<2, 3>(y2, y3, buf + 96 + 48, lane, wave, p.taps_k + 18, p.zeta);
+                ylast = y3[0];
+            } else {
+                // (no barrier in front: the exchange area lies in R0's first slots, the outputs go to R1; R0 is not written before the barrier below)
+                cf *o = buf + R1_OFF + tid * 5;                                 // stage 1's outputs, layout L(4), region R1 (as hb_stage_pp<4, .> leaves them)
 #pragma unroll
-                for (int e = 0; e < 8; e++) bz[(wave * 3 + (lane - 61)) * 8 + e] = z[e];
+                for (int pp = 0; pp < 4; pp++) o[pp] = y1[pp];
             }
-            __syncthreads();
-            cf S[LM + 1][8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) S[0][e] = z[e];
-#pragma unroll
-            for (int sft = 1; sft <= LM; sft++) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) S[sft][e] = dpp0c<0x138>(S[sft - 1][e]);               // wave_shr:1 (lane 0 <- 0)
-            }
-            if (wave > 0 && lane < LM) {
-#pragma unroll
-                for (int sft = 1; sft <= LM; sft++) {
-                    if (lane < sft) {
-                        const cf *src = bz + ((wave - 1) * 3 + (3 + lane - sft)) * 8;
-#pragma unroll
-                        for (int e = 0; e < 8; e++) S[sft][e] = src[e];
-                    }
-                }
-            }
-            // z1 at index 8t + REL, REL in [-(4 M1 - 2), 7]: thread t - L's element REL + 8 L
-            const float scale1 = H == 2 ? p.zeta : 1.0f;
-            cf y[4];
-#pragma unroll
-            for (int pp = 0; pp < 4; pp++) {
-                cf a = cfm(0.f, 0.f);
-#pragma unroll
-                for (int j = 0; j < 2 * M1; j++) {
-                    const int rel = 2 * pp - (4 * M1 - 2) + 2 * j, L = (7 - rel) / 8;              // rel <= 6: L = ceil(-rel / 8)
-                    a = cfma(p.taps_k[6 + j], S[L][rel + 8 * L], a);
-                }
-                const int rd = 2 * pp + 1 - 2 * M1, Ld = (7 - rd) / 8;
-                y[pp] = cadd_scale(S[Ld][rd + 8 * Ld], a, scale1);
-            }
-            // (no barrier here: bz lies in R0's first 96 slots, the outputs go to R1; R0 is not written before the barrier that ends phase B)
-            cf *o = buf + R1_OFF + tid * 5;                                     // stage 1's outputs, layout L(4), region R1 (as hb_stage_pp<4, .> leaves them)
-#pragma unroll
-            for (int pp = 0; pp < 4; pp++) o[pp] = y[pp];
         }
     }
         }
+    if constexpr (!ALL_REG)
     __syncthreads();
     FE_STAMP_AT(2);
 
@@ -377,16 +354,16 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
                             (E) == H - 1 ? p.zeta : 1.0f); } while (0)
     // six-tap stages 1 .. N3-1 (taps at 6 e), then the two long stages (m = MA, MB: 5 and 10 in the reference's design)
     if constexpr (N3 >= 2 && !S1_REG) FE_STAGE(1, 3, 6);
-    if constexpr (N3 >= 3) FE_STAGE(2, 3, 12);
+    if constexpr (N3 >= 3 && !ALL_REG) FE_STAGE(2, 3, 12);
     // level 1 with four six-tap stages (cfg5, dsd_in): the last stage has one output per thread -- it stays in a register and goes
     // straight to the ring (below): one LDS write, one barrier and two LDS reads less at the end of the tile's life
-#ifdef FE_LAST_LDS        /* A/B hook: the last stage through LDS like the others */
+#ifdef FE_LAST_LDS
     constexpr bool LAST_IN_REG = false;
 #else
     constexpr bool LAST_IN_REG = MODE == FE_L1 && N3 == 4 && !TAIL;
 #endif
-    cf ylast = cfm(0.f, 0.f);
-    if constexpr (LAST_IN_REG) ylast = hb_stage_out1<3>(R0, tid, p.taps_k + 18, p.zeta);
+    if constexpr (ALL_REG) { }
+    else if constexpr (LAST_IN_REG) ylast = hb_stage_out1<3>(R0, tid, p.taps_k + 18, p.zeta);
     else if constexpr (N3 >= 4) FE_STAGE(3, 3, 18);
     if constexpr (N3 >= 5) FE_STAGE(4, 3, 24);
     if constexpr (TAIL && N3 == 0) hb_stage_ip<8, MA>(buf, tid, NT, p.taps_k, 1.0f);           // 2048 outputs, L(16) -> L(8), in place
