@@ -85,6 +85,20 @@ static __device__ __forceinline__ void fe_level2_tile(const pmr_fe_params &p, co
 #define FE_P2_PARAM
 #endif
 
+// Level 1 of the deep cascades with every stage in registers (ALL_REG) needs no LDS beyond the raw tile: no stage window reaches left
+// of the tile (no zero pad), and the scan / halo scratch of wave w lives in wave w's OWN quarter of the tile, which only that wave
+// reads and which is dead once its threads hold their samples.  32 768 bytes exactly: FIVE tiles per CU (5 x 32 KB = the whole 160 KB)
+// instead of four at 33.7 KB -- a quarter more bytes in flight per CU.
+template <int MODE, int N3, int MA>
+static constexpr bool fe_tight_lds()
+{
+#if defined(FE_LAST_LDS) || defined(FE_L1_LDS23) || defined(FE_S1_LDS) || defined(FE_NO_TIGHT)
+    return false;
+#else
+    return MODE == FE_L1 && N3 == 4 && MA == 0;
+#endif
+}
+
 template <int MODE, int N3, int MA, int MB>
 __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 {
@@ -114,9 +128,14 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
     // N3 == 0 (no six-tap stage: the reference's own 1.024 MS/s plan is m = 5, 10): the dc-blocked tile goes back to LDS in
     // layout L(16) (4352 slots) and the m = 5 stage runs from there in place; the scan scratch sits behind it
     constexpr int SCR = N3 == 0 ? N0 + N0 / 16 : N0;
-    cf *buf = reinterpret_cast<cf *>(smem) + FE_PAD;
-    cf *wagg = buf + SCR;
-    cf *bnd = wagg + NT / 64;                                 // [4][10]
+    constexpr bool TIGHT = fe_tight_lds<MODE, N3, MA>();
+    cf *buf = reinterpret_cast<cf *>(smem) + (TIGHT ? 0 : FE_PAD);
+    // scan aggregate of wave w: wagg[w * WST]; halo of stage 0 across the wave boundary: bnd[w * BST + 0 .. 9].  TIGHT: inside wave w's own
+    // quarter of the tile (1024 samples per wave), otherwise behind the tile
+    constexpr int WST = TIGHT ? 1024 : 1, BST = TIGHT ? 1024 : 10;
+    cf *wagg = TIGHT ? buf : buf + SCR;
+    cf *bnd = TIGHT ? buf + 8 : wagg + NT / 64;               // [4][10]
+    cf *xch = TIGHT ? buf + 32 : buf;                         // exchange areas of the register stages (hb_stage_reg): 96 + 48 + 40 samples
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     FE_STAMP_AT(0);
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
     const long b0 = (long)c * p.T_own - p.Hh - p.pend;     // block-relative index of tile sample 0
 
     // ---- phase A: raw tile -> LDS ----
-    if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f);
+    if constexpr (!TIGHT) { if (tid < FE_PAD) buf[tid - FE_PAD] = cfm(0.f, 0.f); }
     const bool fast = p.in_fmt == 0 && b0 >= 0 && b0 + N0 <= (long)p.n_in && ((reinterpret_cast<uintptr_t>(x + b0) & 15) == 0);
     if (fast) {
         // wave-instruction i of wave w moves slots s0 .. s0 + 63, s0 = 512 w + 64 i (1 KiB).  fe_swz(s0 + lane) - s0 depends on
@@ -242,7 +261,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
         v = cfma(p.lam_pow16[3], dpp0c<0x118>(v), v);                      // row_shr:8
         v = cfma(l15, dpp0c<0x142, 0xA>(v), v);                            // row_bcast:15 -> rows 1, 3
         v = cfma(l31, dpp0c<0x143, 0xC>(v), v);                            // row_bcast:31 -> rows 2, 3
-        if (lane == 63) wagg[wave] = v;
+        if (lane == 63) wagg[wave * WST] = v;
         const cf ex = dpp0c<0x138>(v);                                     // wave_shr:1 (lane 0 <- 0)
         __syncthreads();                                                   // also: every thread holds its raw samples
         // v (local) at the end of the previous wave: Horner over the aggregates of the waves before this one.  Branch-free (the
@@ -250,7 +269,7 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
         // loop with one dependent LDS read per trip -- ~400 cycles for wave 3, which the whole tile waits for at the next barrier
         cf cw = cfm(0.f, 0.f);
         {
-            const cf a0 = wagg[0], a1 = wagg[1], a2 = wagg[2];
+            const cf a0 = wagg[0], a1 = wagg[WST], a2 = wagg[2 * WST];
             const cf c1 = cfma(p.lam_wave, cw, a0);
             cw = wave > 0 ? c1 : cw;
             const cf c2 = cfma(p.lam_wave, cw, a1);
@@ -299,12 +318,12 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
         for (int i = 0; i < 16; i++) W[10 + i] = yb[i];
         if (lane == 63) {
 #pragma unroll
-            for (int i = 0; i < 10; i++) bnd[wave * 10 + i] = yb[6 + i];
+            for (int i = 0; i < 10; i++) bnd[wave * BST + i] = yb[6 + i];
         }
         __syncthreads();
         if (lane == 0 && wave > 0) {
 #pragma unroll
-            for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * 10 + i];
+            for (int i = 0; i < 10; i++) W[i] = bnd[(wave - 1) * BST + i];
         }
         // z1[8 tid + q] = W[2q + 5] + sum_j h1[j] W[2q + 2j]   (window offset 0 <-> sample 16 tid - 10)
         const float scale0 = H == 1 ? p.zeta : 1.0f;
@@ -326,13 +345,13 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
             // dead: every thread holds its samples since the scan's barrier) -- instead of a write of all of z1 to LDS and 13 - 17
             // window reads back per thread.  Same operations in the same order as hb_stage_pp<4, M1>: bit-identical (tools/pcm_hash.py).
             cf y1[4];
-            hb_stage_reg<8, M1>(z, y1, buf, lane, wave, p.taps_k + 6, H == 2 ? p.zeta : 1.0f);
+            hb_stage_reg<8, M1>(z, y1, xch, lane, wave, p.taps_k + 6, H == 2 ? p.zeta : 1.0f);
             if constexpr (ALL_REG) {
                 // level 1 of the deep cascades (cfg5, dsd_in): the remaining two six-tap stages the same way -- no stage of this kernel
                 // goes through LDS any more, only 184 boundary samples per tile do
                 cf y2[2], y3[1];
-                hb_stage_reg<4, 3>(y1, y2, buf + 96, lane, wave, p.taps_k + 12, 1.0f);
-                hb_stage_reg<2, 3>(y2, y3, buf + 96 + 48, lane, wave, p.taps_k + 18, p.zeta);
+                hb_stage_reg<4, 3>(y1, y2, xch + 96, lane, wave, p.taps_k + 12, 1.0f);
+                hb_stage_reg<2, 3>(y2, y3, xch + 96 + 48, lane, wave, p.taps_k + 18, p.zeta);
                 ylast = y3[0];
             } else {
                 // (no barrier in front: the exchange area lies in R0's first slots, the outputs go to R1; R0 is not written before the barrier below)
@@ -565,7 +584,8 @@ static int launch_fast(hipStream_t st, const pmr_fe_params *p, unsigned ntiles, 
 #ifndef FE_EXTRA_LDS
 #define FE_EXTRA_LDS 0      /* experiment: bytes of unused LDS per workgroup on top of pmr_fe_params.lds_pad */
 #endif
-    const size_t lds = (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS + (MODE == FE_FULL ? p->lds_pad : 0u);
+    const size_t lds = fe_tight_lds<MODE, N3, MA>() ? 4096 * sizeof(cf) + FE_EXTRA_LDS
+                     : (FE_PAD + (N3 == 0 ? 4352 : 4096) + 4 + 40) * sizeof(cf) + FE_EXTRA_LDS + (MODE == FE_FULL ? p->lds_pad : 0u);
     auto kern = k_fe_fast<MODE, N3, MA, MB>;
     PMR_LAUNCH_EV(kern, dim3(ntiles), dim3(256), lds, st, ev, *p FE_P2_ARG);
     return (int)hipGetLastError();
