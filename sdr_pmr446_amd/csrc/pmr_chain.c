@@ -866,7 +866,16 @@ static pmr_chain chain_create(const pmr_chain_cfg *cfg, int frontend_only)
         pmr_chain_destroy(q);
         return NULL;
     }
-    q->fe_prio_high = q->fe_on && q->fe_two && q->fft_ok;
+    /* (round 6: also the one-level plan whose tiles are PADDED to leave the back end's workgroup its LDS -- the 256-channel plan,
+     * fe_lds_pad: the front end cannot starve a back end whose room is reserved; cfg3 +1.2 %, 3 of 3 interleaved pairs, while the
+     * unpadded 16-channel plan loses 10 % with a high-priority front end: profiles/r06_ab_log.txt r6h) */
+    q->fe_prio_high = q->fe_on && q->fft_ok && (q->fe_two || q->fe_lds_pad != 0);
+#ifdef EXP_FE_PRIO_EQUAL   /* A/B hooks: both streams at the base priority in every plan / the front-end stream high in every plan */
+    q->fe_prio_high = 0;
+#endif
+#ifdef EXP_FE_PRIO_HIGH
+    q->fe_prio_high = q->fe_on;
+#endif
     if (hipStreamCreateWithPriority(&q->stream_fe, hipStreamNonBlocking, q->fe_prio_high ? prio_hi : prio_base) != hipSuccess) {
         create_error("hipStreamCreateWithPriority failed");
         pmr_chain_destroy(q);

@@ -19,7 +19,7 @@
 #if defined(EXP_SKIP_FIR) || defined(EXP_SKIP_CHAN) || defined(EXP_SKIP_L2) || defined(EXP_SKIP_CT) || defined(EXP_NO_TAIL) ||          \
     defined(EXP_NO_CARRY5) || defined(EXP_ARG_CHEAP) || defined(EXP_BE_WIN) || defined(EXP_L2_NOFIX) || defined(EXP_L2_STOP1) ||        \
     defined(EXP_CT_NO_AGG) || defined(EXP_CT_NO_SCAN) || defined(EXP_CT_NO_GOERTZEL) || defined(EXP_CT_NO_FINAL) ||                     \
-    defined(EXP_CG_EXTRA_LDS) || defined(EXP_L2_INLINE) || defined(EXP_L2_INLINE_ATOMIC) || defined(EXP_L1_EXTRA_HALO) ||                                             \
+    defined(EXP_CG_EXTRA_LDS) || defined(EXP_L2_INLINE) || defined(EXP_L2_INLINE_ATOMIC) || defined(EXP_L1_EXTRA_HALO) || defined(EXP_FE_PRIO_EQUAL) || defined(EXP_FE_PRIO_HIGH) ||                                             \
     defined(PMR_CARRY_NOOP) || defined(CW_STOP) || defined(CW_NT) ||                                                                    \
     defined(FE_STOP) || defined(FE_STAMP) || defined(FE_OUT_AND) || defined(FE_OUT_SKIP) || defined(FE_OUT_NT) || defined(FE_OUT_SC) || \
     defined(FE_NO_PAIRS) || defined(FE_LAST_LDS) || defined(FE_S1_LDS) || defined(FE_L1_LDS23) || defined(FE_NO_TIGHT) || defined(FE_DMA_AUX) || defined(FE_EXTRA_LDS) || defined(FE_LDS_PAD_256) ||          \
