@@ -751,6 +751,9 @@ static int chain_init(pmr_chain q)
 #define FE_LDS_PAD_256 6656u      /* (sweep hook: tools/ab_libs.py builds) */
 #endif
     q->fe_lds_pad = (q->fe_on && !q->fe_two && q->chan_wide && M == 256) ? FE_LDS_PAD_256 : 0u;
+#ifdef FE_LDS_PAD_16        /* sweep hook: the same padding for the 16-channel plan (r6i) */
+    if (q->fe_on && !q->fe_two && q->chan_small) q->fe_lds_pad = FE_LDS_PAD_16;
+#endif
     q->tf_on_backend = 0;
     q->cal_ok = 0;
     if (q->fe_on && !q->fe_two && q->d_fe_G12 && !q->sw.carry_inplace) {

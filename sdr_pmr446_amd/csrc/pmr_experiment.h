@@ -22,7 +22,7 @@
     defined(EXP_CG_EXTRA_LDS) || defined(EXP_L2_INLINE) || defined(EXP_L2_INLINE_ATOMIC) || defined(EXP_L1_EXTRA_HALO) || defined(EXP_FE_PRIO_EQUAL) || defined(EXP_FE_PRIO_HIGH) ||                                             \
     defined(PMR_CARRY_NOOP) || defined(CW_STOP) || defined(CW_NT) ||                                                                    \
     defined(FE_STOP) || defined(FE_STAMP) || defined(FE_OUT_AND) || defined(FE_OUT_SKIP) || defined(FE_OUT_NT) || defined(FE_OUT_SC) || \
-    defined(FE_NO_PAIRS) || defined(FE_LAST_LDS) || defined(FE_S1_LDS) || defined(FE_L1_LDS23) || defined(FE_NO_TIGHT) || defined(FE_DMA_AUX) || defined(FE_EXTRA_LDS) || defined(FE_LDS_PAD_256) ||          \
+    defined(FE_NO_PAIRS) || defined(FE_LAST_LDS) || defined(FE_S1_LDS) || defined(FE_L1_LDS23) || defined(FE_NO_TIGHT) || defined(FE_DMA_AUX) || defined(FE_EXTRA_LDS) || defined(FE_LDS_PAD_256) || defined(FE_LDS_PAD_16) ||          \
     defined(PW_F) || defined(PW_FPW1024) || defined(PW_MINB) || defined(PW_RB) || defined(PF_G) || defined(PF_RB) || defined(PF_MINB)
 #error "experiment hook defined without -DPMR_EXPERIMENT: build with `python3 sdr_pmr446_amd/build.py --variant NAME \"-DFLAGS\"` (pmr_experiment.h)"
 #endif
