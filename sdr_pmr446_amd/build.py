@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpmr446_hip.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
-C_SOURCES = ["pmr_chain.c", "pmr_design.c", "pmr_squelch.c", "pmr_dsd.c", "pmr_io.c"]
+C_SOURCES = ["pmr_chain.c", "pmr_chain_plan.c", "pmr_chain_frontend.c", "pmr_chain_host.c", "pmr_chain_aux.c", "pmr_design.c", "pmr_squelch.c", "pmr_dsd.c", "pmr_io.c"]
 HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_fe_fast.hip", "pmr_channelize_small.hip", "pmr_channelize_wide.hip", "pmr_fir_mfma4.hip", "pmr_fir_fft.hip", "pmr_ctcss.hip", "pmr_synth.hip", "pmr_spectrum.hip",
                "pmr_dsd_kernels.hip", "pmr_poison.hip"]
 # -fno-slp-vectorize: see _compile.  The PRODUCT build takes no other flags: anything else is a variant (build_variant ->
@@ -17,7 +17,7 @@ HIP_SOURCES = ["pmr_kernels.hip", "pmr_frontend.hip", "pmr_fe_fast.hip", "pmr_ch
 PRODUCT_HIP_FLAGS = ["-fno-slp-vectorize"]
 PRODUCT_C_FLAGS = []
 SANITIZE_C_FLAGS = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-g", "-O1"]
-HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_experiment.h", "pmr_internal.h", "pmr_fe_common.hpp", "pmr_carry_load.hpp", os.path.join("..", "..", "include", "pmr_chain.h"),
+HEADERS = ["pmr_design.h", "pmr_kernels.h", "pmr_experiment.h", "pmr_internal.h", "pmr_chain_priv.h", "pmr_fe_common.hpp", "pmr_carry_load.hpp", os.path.join("..", "..", "include", "pmr_chain.h"),
            os.path.join("..", "..", "include", "pmr_dsd.h"), os.path.join("..", "..", "include", "pmr_io.h"), os.path.join("..", "..", "include", "pmr_mem.h"),
            os.path.join("..", "data", "pmr446_taps.h")]
 
