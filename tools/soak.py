@@ -46,6 +46,11 @@ while time.time() < t_end:
         continue
     fs, M = CFGS[rng.integers(len(CFGS))]
     opts = dict(lowpass=bool(rng.integers(2)) and rng.random() < 0.3, deemph_fir=rng.random() < 0.2)
+    # (round 6) another stop-band of the resampler = another pair of long half-band stages: the specialised front end is built for
+    # every pair a 50 ... 72 dB design yields, 75 takes the generic kernels (M >= 16: with fewer channels the outermost ones sit on the
+    # resampler's transition band)
+    if M >= 16 and rng.random() < 0.5:
+        opts["resamp_As"] = float(rng.choice([50.0, 55.0, 65.0, 68.0, 70.0, 75.0]))
     max_block = int(rng.choice([3000, 20000, 100000, 400000]))
     nblk = int(rng.integers(1, 6))
     splits = [int(rng.integers(0, max_block + 1)) if rng.random() < 0.8 else int(rng.integers(0, 40)) for _ in range(nblk)]
