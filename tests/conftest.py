@@ -63,6 +63,7 @@ _ORDER = [
     ("test_spectrum.py", 52),
     ("test_gpu_bench_ranks.py", 55),                            # bench.py --gpus 2: the cfg4 path with every rank's parity
     ("test_gpu_poison.py", 60),
+    ("test_gpu_build_identity.py", 75),                         # builds the round-5 kernel form on the box: bit-identical outputs
     ("test_gpu_variants.py", 80),
     ("test_gpu_soak.py", 90),
 ]
