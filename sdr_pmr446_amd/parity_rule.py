@@ -30,20 +30,26 @@ PFB_FRAMES = 26             # frames until the polyphase windows hold stream sam
 E_FLOOR = 0.02              # |E| below this many LSB counts as "explains nothing" (the +-1 bar applies)
 
 
-def audio_response(hp_taps, gain, b0, b1, a1, tail=1e-9):
-    """Impulse response of the audio path behind the discriminator (:882-898): high-pass FIR, gain, de-emphasis IIR
-    (v0 = u - a1 v1; y = b0 v0 + b1 v1), truncated where the IIR's tail falls below `tail` of the peak.  float64."""
+def audio_response(hp_taps, gain, b0, b1, a1, tail=1e-9, deemph_fir_taps=None, lp_taps=None):
+    """Impulse response of the audio path behind the discriminator (:882-902): high-pass FIR, gain, de-emphasis -- the IIR
+    (v0 = u - a1 v1; y = b0 v0 + b1 v1; truncated where its tail falls below `tail` of the peak) or, with `deemph_fir_taps`, the
+    101-tap FIR variant (:457-458) --, then the optional low-pass FIR (`lp_taps`, :453-454).  float64."""
     hp = np.asarray(hp_taps, np.float64) * float(gain)
-    extra = 1
-    while abs(a1) ** extra > tail and extra < 64:
-        extra += 1
-    u = np.concatenate([hp, np.zeros(extra)])
-    y = np.zeros_like(u)
-    v1 = 0.0
-    for i, x in enumerate(u):
-        v0 = x - a1 * v1
-        y[i] = b0 * v0 + b1 * v1
-        v1 = v0
+    if deemph_fir_taps is not None:
+        y = np.convolve(hp, np.asarray(deemph_fir_taps, np.float64))
+    else:
+        extra = 1
+        while abs(a1) ** extra > tail and extra < 64:
+            extra += 1
+        u = np.concatenate([hp, np.zeros(extra)])
+        y = np.zeros_like(u)
+        v1 = 0.0
+        for i, x in enumerate(u):
+            v0 = x - a1 * v1
+            y[i] = b0 * v0 + b1 * v1
+            v1 = v0
+    if lp_taps is not None:
+        y = np.convolve(y, np.asarray(lp_taps, np.float64))
     return y
 
 
@@ -111,3 +117,10 @@ def fixtures(root):
     de = np.load(os.path.join(root, "tests", "golden", "deemph_ref.npz"))
     b, a = de["b"].astype(np.float64), de["a"].astype(np.float64)
     return t["hp_audio_taps"].astype(np.float64), b[0] / a[0], b[1] / a[0], a[1] / a[0]
+
+
+def option_taps(root):
+    """(de-emphasis FIR taps, low-pass taps) of the reference's optional audio stages (src/sdr_pmr446.c:99-136), same fixture."""
+    import os
+    t = np.load(os.path.join(root, "tests", "golden", "pmr446_taps.npz"))
+    return t["deemph_taps"].astype(np.float64), t["lp_audio_taps"].astype(np.float64)

@@ -76,3 +76,19 @@ def test_audio_response_is_the_oracles_audio_path_and_only_the_start_up_is_ill_c
     pred = np.convolve(r["fm"][k].astype(np.float64), h)[:r["fm"].shape[1]]
     assert np.abs(pred - r["audio"][k]).max() <= 1e-5 * max(1.0, np.abs(r["audio"][k]).max())
     assert 1.5 < np.abs(h).max() < 2.2 and np.argmax(np.abs(h)) in (188, 189)
+
+
+def test_audio_response_with_the_optional_stages_is_the_oracles_audio_path():
+    """lowpass (:453-454, :900-902) and the FIR form of the de-emphasis (:457-458): the responses tools/soak.py hands the rule."""
+    fs, M, n = 2.4e6, 16, 1 << 19
+    x = synth.synth_iq(n, fs, M, stream_id=1)
+    hp, b0, b1, a1 = pr.fixtures(ROOT)
+    de_fir, lp = pr.option_taps(ROOT)
+    for opts in (dict(lowpass=True), dict(deemph_fir=True), dict(lowpass=True, deemph_fir=True)):
+        o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=n, **opts)
+        r = o.process_block(x, want=("fm", "audio"))
+        o.close()
+        h = pr.audio_response(hp, 4.0, b0, b1, a1, deemph_fir_taps=de_fir if opts.get("deemph_fir") else None, lp_taps=lp if opts.get("lowpass") else None)
+        k = synth.signal_channels(M, fs)[0]
+        pred = np.convolve(r["fm"][k].astype(np.float64), h)[:r["fm"].shape[1]]
+        assert np.abs(pred - r["audio"][k]).max() <= 2e-5 * max(1.0, np.abs(r["audio"][k]).max()), opts

@@ -5,7 +5,10 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle
-from sdr_pmr446_amd import chain, synth
+from sdr_pmr446_amd import chain, parity_rule, synth
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HP, B0, B1, A1 = parity_rule.fixtures(ROOT)
+DE_FIR, LP = parity_rule.option_taps(ROOT)
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -63,22 +66,40 @@ while time.time() < t_end:
     want = ("pcm", "rssi") if rng.random() < 0.5 else ("pcm",)
     g = chain.PmrChain(fs_in=fs, num_channels=M, max_block=max_block, **opts)
     o = oracle.OracleChain(fs_in=fs, num_channels=M, max_block=max_block, **opts)
-    pg, po, pos = [], [], 0
+    # Every case starts at a reset, so the first frames' discriminator samples can be ill-conditioned (arg() of a channel output that is
+    # numerically zero while the polyphase windows fill): the PCM is held to sdr_pmr446_amd/parity_rule.py -- +-1 LSB wherever no such
+    # sample reaches, and oracle + what the MEASURED discriminator difference at those samples explains through the audio path
+    # elsewhere (round 6: with random stop-bands one case in a few hundred has a +pi / -pi pair there, PCM hundreds of LSB apart).
+    pg, po, co, fg, fo, pos, seen = [], [], [], [], [], 0, 0
     for s in splits:
-        a = g.process_block(x[pos:pos + s], want=want)
-        b = o.process_block(x[pos:pos + s], want=want)
+        tap = ("fm",) if seen < 64 else ()                     # the chain's discriminator output through the debug tap, start-up only
+        a = g.process_block(x[pos:pos + s], want=want + tap)
+        b = o.process_block(x[pos:pos + s], want=want + ("chan",) + tap)
         assert a["n_frames"] == b["n_frames"], (fs, M, splits, a["n_frames"], b["n_frames"])
-        pg.append(a["pcm"]); po.append(b["pcm"]); pos += s
+        pg.append(a["pcm"]); po.append(b["pcm"]); co.append(b["chan"]); pos += s
+        if tap:
+            fg.append(a["fm"]); fo.append(b["fm"])
+        seen += a["n_frames"]
         if "rssi" in want and a["n_frames"] > 8:
             act = [k for k in (ks or range(M)) if synth.channel_kind(k) != "empty"]
             assert np.abs(a["rssi"][act] - b["rssi"][act]).max() < 0.05, (fs, M, "rssi")
-    pg, po = np.concatenate(pg, axis=1), np.concatenate(po, axis=1)
+    pg, po, co = np.concatenate(pg, axis=1), np.concatenate(po, axis=1), np.concatenate(co, axis=1)
+    fg, fo = np.concatenate(fg, axis=1), np.concatenate(fo, axis=1)
     act = [k for k in (ks or range(M)) if synth.channel_kind(k) != "empty"]
-    d = int(np.abs(pg[act].astype(np.int32) - po[act].astype(np.int32)).max()) if pg.shape[1] else 0
+    d, reached = 0, 0
+    if pg.shape[1]:
+        h = parity_rule.audio_response(HP, 4.0, B0, B1, A1, deemph_fir_taps=DE_FIR if opts.get("deemph_fir") else None,
+                                       lp_taps=LP if opts.get("lowpass") else None)
+        v = parity_rule.check(pg[act], po[act], co[act], fg[act], fo[act], h)
+        if "error" in v:
+            print("FAIL (rule) %r" % v["error"], flush=True); sys.exit(1)
+        d = v["max_abs_pcm_diff_lsb"] if v["ok"] else max(2, v["max_abs_pcm_diff_lsb"], int(np.ceil(v["ill_conditioned"]["max_abs_unexplained_lsb"])))
+        reached = v["ill_conditioned"]["samples_over_1_lsb"]
     worst = max(worst, d)
     n_cases += 1
     status = "ok" if d <= 1 else "FAIL"
-    print("%s fs=%g M=%d opts=%s max_block=%d splits=%s frames=%d maxdiff=%d" % (status, fs, M, opts, max_block, splits, pg.shape[1], d), flush=True)
+    print("%s fs=%g M=%d opts=%s max_block=%d splits=%s frames=%d maxdiff=%d%s" % (status, fs, M, opts, max_block, splits, pg.shape[1], d,
+          " (%d samples > 1 LSB explained by ill-conditioned start-up discriminator samples)" % reached if reached else ""), flush=True)
     g.close(); o.close()
     if d > 1:
         sys.exit(1)
