@@ -11,6 +11,7 @@ the next ~400 frames.  Round 5 applied a blanket window (the first 26 + 383 fram
 every channel's start-up) and too strict (the case above).  This rule is tied to the cause, with MEASURED quantities only:
 
   ill(k, t)   min(|r(k, t)|, |r(k, t-1)|) < COND_FRAC * rms_k     r = the ORACLE's channelizer output, rms_k its steady level
+              or conj(r(k, t-1)) r(k, t) on the branch cut of arg(): Re < 0, |Im| < CUT_FRAC |.|   (+pi and -pi are one angle, 2 apart)
   D(k, t)     fm_chain(k, t) - fm_oracle(k, t) where ill(k, t), 0 elsewhere        (both discriminator outputs, debug taps)
   E(k, t)     32767 * sum_n h[n] D(k, t - n)                  h = the audio path's impulse response (high-pass * gain -> de-emphasis)
   verdict     |pcm_chain - pcm_oracle| <= 1                   wherever E = 0   (every sample no ill-conditioned input reaches)
@@ -28,6 +29,7 @@ import numpy as np
 COND_FRAC = 0.01            # discriminator inputs below 1 % of the channel's steady-state rms are ill-conditioned
 PFB_FRAMES = 26             # frames until the polyphase windows hold stream samples only (p = 2 m, src/sdr_pmr446.c:437)
 E_FLOOR = 0.02              # |E| below this many LSB counts as "explains nothing" (the +-1 bar applies)
+CUT_FRAC = 1e-4             # |Im| below this fraction of |conj(r') r| with Re < 0: on the branch cut of arg() (f32 rounding of r: ~1e-6)
 
 
 def audio_response(hp_taps, gain, b0, b1, a1, tail=1e-9, deemph_fir_taps=None, lp_taps=None):
@@ -54,13 +56,22 @@ def audio_response(hp_taps, gain, b0, b1, a1, tail=1e-9, deemph_fir_taps=None, l
 
 
 def ill_conditioned(chan_ref):
-    """chan_ref: complex [K, T], the oracle's channelizer outputs of the compared channels from the reset on -> bool [K, T]."""
-    mag = np.abs(np.asarray(chan_ref))
+    """chan_ref: complex [K, T], the oracle's channelizer outputs of the compared channels from the reset on -> bool [K, T].
+    Two ways for arg(conj(r') r) to be ill-conditioned: an input that is (numerically) nothing, or a product on the BRANCH CUT of
+    arg() -- a phase advance of pi per frame, where the sign of a rounding-sized imaginary part decides between +pi and -pi
+    (discriminator outputs 2 apart for the same angle).  The second kind needs energy at exactly half the channel rate from the
+    channel's centre: the dc blocker's start-up transient does that to the two channels next to band centre (an even channel count
+    puts DC on their common edge)."""
+    c = np.asarray(chan_ref).astype(np.complex128)
+    mag = np.abs(c)
     K, T = mag.shape
     steady = mag[:, PFB_FRAMES:] if T > 2 * PFB_FRAMES else mag
-    rms = np.sqrt((steady.astype(np.float64) ** 2).mean(axis=1))
-    prev = np.concatenate([np.zeros((K, 1), mag.dtype), mag[:, :-1]], axis=1)        # r' of the first frame is the reset state, 0
-    return np.minimum(mag, prev) < COND_FRAC * rms[:, None]
+    rms = np.sqrt((steady ** 2).mean(axis=1))
+    prevc = np.concatenate([np.zeros((K, 1), c.dtype), c[:, :-1]], axis=1)           # r' of the first frame is the reset state, 0
+    small = np.minimum(mag, np.abs(prevc)) < COND_FRAC * rms[:, None]
+    z = np.conj(prevc) * c
+    cut = (z.real < 0) & (np.abs(z.imag) < CUT_FRAC * np.abs(z))
+    return small | cut
 
 
 def check(got, ref, chan_ref, fm_got, fm_ref, h):
@@ -76,13 +87,15 @@ def check(got, ref, chan_ref, fm_got, fm_ref, h):
     last = int(np.nonzero(ill.any(axis=0))[0].max()) if ill.any() else -1
     fm_got = np.asarray(fm_got, np.float64); fm_ref = np.asarray(fm_ref, np.float64)
     F = fm_got.shape[1]
-    if fm_got.shape != fm_ref.shape or fm_got.shape[0] != K or last >= F:
-        return {"ok": False, "error": "discriminator taps %r / %r do not cover the ill-conditioned frames (last %d)" % (fm_got.shape, fm_ref.shape, last)}
+    if fm_got.shape != fm_ref.shape or fm_got.shape[0] != K or F > T:
+        return {"ok": False, "error": "discriminator taps %r / %r do not fit %d channels x %d frames" % (fm_got.shape, fm_ref.shape, K, T)}
+    # (ill-conditioned samples beyond the taps' F frames have no measured difference: they explain nothing, the +-1 bar applies to
+    #  whatever they reach -- the start-up, where both kinds occur, is what the callers tap)
     D = np.where(ill[:, :F], fm_got - fm_ref, 0.0)
     E = np.zeros((K, T))
     h = np.asarray(h, np.float64)
-    for k in np.nonzero(np.abs(D).max(axis=1) > 0)[0]:
-        e = np.convolve(D[k, :last + 1], h)[:T]
+    for k in np.nonzero(np.abs(D).max(axis=1) > 0)[0] if F else []:
+        e = np.convolve(D[k], h)[:T]
         E[k, :len(e)] = 32767.0 * e
     d = got - ref
     reached = np.abs(E) > E_FLOOR
@@ -94,10 +107,11 @@ def check(got, ref, chan_ref, fm_got, fm_ref, h):
     return {"ok": bool(not strict_bad.any() and not expl_bad.any()),
             "max_abs_pcm_diff_lsb": w_strict, "tolerance_lsb": 1,
             "ill_conditioned": {
-                "rule": "discriminator input below %g of the channel's steady rms (oracle chan, either of the two samples) = ill-conditioned; "
+                "rule": "discriminator input below %g of the channel's steady rms (oracle chan, either of the two samples), or conj(r') r on the "
+                        "branch cut of arg() (+pi / -pi) = ill-conditioned; "
                         "PCM may differ by what the MEASURED discriminator difference at those samples explains through the audio filter "
                         "(|d - E| <= 1 + min(1, |E|) LSB), by +-1 LSB everywhere else" % COND_FRAC,
-                "discriminator_samples": int(ill.sum()), "last_frame": last,
+                "discriminator_samples": int(ill.sum()), "last_frame": last, "beyond_the_taps": int(ill[:, F:].sum()),
                 "max_abs_discriminator_diff": float(np.abs(D).max()) if D.size else 0.0,
                 "pcm_samples_reached": int(reached.sum()), "pcm_samples_strict": int((~reached).sum()),
                 "pcm_samples_reached_over_1_lsb": int(over.sum()), "max_abs_pcm_diff_lsb_reached": int(np.abs(d[reached]).max()) if reached.any() else 0,

@@ -28,6 +28,25 @@ def test_ill_conditioned_class():
     assert ill[:, :9].all() and not ill[:, 9:].any()           # frame 8 is ill through its r' = frame 7
 
 
+def test_branch_cut_class():
+    """A phase advance of exactly pi per frame (energy at half the channel rate from the channel's centre: what the dc blocker's
+    start-up transient does to the two channels next to band centre): +pi and -pi are the same angle, the discriminator outputs 2 apart."""
+    c = np.ones((2, 600), np.complex64)
+    c[0, 40:60] = (-1.0) ** np.arange(20)                       # r alternates sign: conj(r') r = -1 exactly
+    ill = pr.ill_conditioned(c)
+    assert ill[0, 41:61].all() and not ill[0, 61:].any() and not ill[0, 1:41].any() and not ill[1, 1:].any()
+    h = _h()
+    ref = np.zeros(c.shape, np.int32)
+    fm_ref = np.zeros((2, 100)); fm_got = fm_ref.copy()
+    fm_ref[0, 45], fm_got[0, 45] = 1.0, -1.0                    # the oracle says +pi, the chain -pi
+    E = np.zeros(600); E[45:45 + len(h)] = 32767 * -2.0 * h
+    got = ref.copy(); got[0] = np.trunc(E).astype(np.int32)
+    got = np.clip(got, -32767, 32767)
+    v = pr.check(got, ref, c, fm_got, fm_ref, h)
+    assert v["ok"], v
+    assert not pr.check(got, ref, np.ones_like(c), fm_got, fm_ref, h)["ok"]      # the same PCM with no sample on the cut: unexplained
+
+
 def test_verdicts():
     c, h = _chan(), _h()
     K, T = c.shape
@@ -58,7 +77,7 @@ def test_verdicts():
     assert not v["ok"] and v["max_abs_pcm_diff_lsb"] == 2
     # malformed inputs are failures, not exceptions
     assert not pr.check(got[:, :-1], ref, c, fm_got, fm_ref, h)["ok"]
-    assert not pr.check(got, ref, c, fm_got[:, :5], fm_ref[:, :5], h)["ok"]          # taps do not cover the ill frames
+    assert not pr.check(got, ref, c, fm_got[:, :2], fm_ref[:, :2], h)["ok"]          # taps that miss the ill frame 3: nothing explains the PCM
 
 
 def test_audio_response_is_the_oracles_audio_path_and_only_the_start_up_is_ill_conditioned():
