@@ -75,7 +75,7 @@ def main():
             k, v = kv.split("=", 1); base_env[k] = v
     for rep in range(args.reps):
         for w in works:
-            for name, path in libs:
+            for name, path in list(libs):
                 env = dict(base_env)
                 if path:
                     env["PMR_LIBRARY"] = os.path.join(ROOT, path) if not os.path.isabs(path) else path
@@ -84,13 +84,20 @@ def main():
                 cmd = [sys.executable, os.path.abspath(__file__), "--leg", w, "--regions", str(args.regions), "--steps", str(args.steps),
                        "--log2-block", str(args.log2_block), "--resamp-as", str(args.resamp_as)] + (["--ctcss"] if args.ctcss else []) + \
                       (["--one-open"] if args.one_open else []) + (["--show-plan"] if args.show_plan else [])
-                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+                # a leg takes ~12 s; one that does not come back (an experiment build with an impossible parameter can hang a kernel: round 6
+                # lost ten GPU-minutes to -DPW_FPW1024=1) is given up after 150 s instead of taking the whole comparison down
                 try:
+                    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
                     v = float(r.stdout.split()[0])
+                except subprocess.TimeoutExpired:
+                    v = float("nan")
+                    sys.stderr.write("leg %s/%s TIMED OUT (150 s): build dropped from the remaining repetitions\n" % (name, w))
+                    libs = [kv for kv in libs if kv[0] != name or kv is libs[0]]
+                    r = None
                 except Exception:
                     v = float("nan")
                     sys.stderr.write("leg %s/%s failed: %s\n" % (name, w, (r.stderr or r.stdout)[-300:]))
-                if args.show_plan and rep == 0:
+                if args.show_plan and rep == 0 and r is not None:
                     sys.stderr.write(r.stderr)
                 res.setdefault((name, w), []).append(v)
     print("%-14s" % "build" + "".join("%26s" % w for w in works))
