@@ -20,7 +20,12 @@
 //     branch taps arrive as scalars from the kernel-argument segment;
 //   * tile bookkeeping (which resampler outputs a tile owns) is wave-uniform INTEGER arithmetic on the scalar unit
 //     (ceil_div_step) instead of an fp64 division in every lane;
-//   * the cascade ping-pongs between two LDS regions (one barrier per stage); z1 / z2 reuse the raw tile's 32 KB.
+//   * (round 6) the stage behind the first one -- all remaining stages in level 1 of the deep cascades -- is computed straight from
+//     registers: the left neighbours' samples come by DPP, only a wave's first lanes fetch the previous wave's last ones through a
+//     few dozen samples of LDS (hb_stage_reg, pmr_fe_common.hpp); the later stages of the one-level kernels ping-pong between two
+//     LDS regions inside the dead raw tile (one barrier per stage);
+//   * (round 6) that level 1 needs exactly the raw tile's 32 768 bytes of LDS (its scratch lives in each wave's own quarter of the
+//     tile): five tiles per CU; the one-level kernels 33.7 KB (zero pad in front of the tile + scratch behind it): four.
 #include <stdlib.h>
 #include <string.h>
 
@@ -123,8 +128,8 @@ __global__ __launch_bounds__(256, 4) void k_fe_fast(pmr_fe_params p FE_P2_PARAM)
 #endif
     cf ylast = cfm(0.f, 0.f);                              // level 1's last-stage output of this thread (LAST_IN_REG / ALL_REG)
     constexpr int R1_OFF = (N0 / 2) + (N0 / 2) / 8;         // z1 (2048 samples, layout L(8)) fills [0, R1_OFF) of the tile area
-    // LDS: [FE_PAD zero pad | raw tile, 4096 samples = 2048 swizzled 16-byte chunks; afterwards R0 (z1, 2304 slots) and
-    // R1 (z2, 1280 slots) | scan scratch] = 33.6 KB -> four tiles per CU
+    // LDS: [FE_PAD zero pad | raw tile, 4096 samples = 2048 swizzled 16-byte chunks; afterwards R0 (z3 ..., 2304 slots: z1 itself stays in
+    // registers since round 6) and R1 (z2, 1280 slots) | scan scratch] = 33.7 KB -> four tiles per CU; TIGHT (below): the raw tile only
     // N3 == 0 (no six-tap stage: the reference's own 1.024 MS/s plan is m = 5, 10): the dc-blocked tile goes back to LDS in
     // layout L(16) (4352 slots) and the m = 5 stage runs from there in place; the scan scratch sits behind it
     constexpr int SCR = N3 == 0 ? N0 + N0 / 16 : N0;

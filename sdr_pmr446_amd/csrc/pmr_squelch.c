@@ -11,31 +11,33 @@ void pmr_squelch_init(pmr_squelch *s)
     s->rssi = 0.0f;
 }
 
-/* :668-700 -- only mask-enabled channels take part; result is (max - mean of the dB values).  The mask has the layout of
- * pmr_chain_set_channel_mask (bit k & 63 of word k >> 6 enables channel k: the reference's uint64_t channel_mask, :18, :293-295,
- * for any M; NULL = every channel enabled).  A mask shorter than M channels is an error: -1, no channel. */
-int pmr_find_max_rssi_channel(const float *rssi_db, unsigned M, const uint64_t *mask_words, unsigned n_words, float *max_rssi)
+/* Channel selection of the reference's scan (src/sdr_pmr446.c:668-700): among the OPEN channels, the strongest one and how far it
+ * stands above the mean of the open channels' dB values; ties go to the lowest channel, the mean is summed in channel order in
+ * float32 (the reference's arithmetic, bit for bit: tests/test_squelch.py, tests/golden/rssi_ref.npz).  The mask has the layout of
+ * pmr_chain_set_channel_mask -- bit (k & 63) of word (k >> 6) opens channel k: the reference's single uint64_t (:18, :293-295)
+ * extended to any M; NULL = every channel open -- and is walked word by word, bit by bit (closed words cost one test).
+ * Returns the channel, or -1 when no channel is open or the mask is shorter than M channels (*margin_db untouched then). */
+int pmr_find_max_rssi_channel(const float *rssi_db, unsigned M, const uint64_t *mask_words, unsigned n_words, float *margin_db)
 {
-    int max_i = -1, ch_en = 0;
-    float rssi_max = 0.0f, rssi_avg = 0.0f;
     if (mask_words && (uint64_t)n_words * 64 < M) return -1;
-    for (unsigned i = 0; i < M; i++) {
-        const int enabled = mask_words ? (int)((mask_words[i >> 6] >> (i & 63)) & 1u) : 1;
-        if (!enabled) continue;
-        ++ch_en;
-        const float rssi = rssi_db[i];
-        rssi_avg += rssi;
-        if (max_i >= 0) {
-            if (rssi > rssi_max) { rssi_max = rssi; max_i = (int)i; }
-        } else {
-            rssi_max = rssi; max_i = (int)i;
+    int best = -1;
+    unsigned n_open = 0;
+    float best_db = 0.0f, sum_db = 0.0f;
+    for (unsigned w = 0; w * 64u < M; w++) {
+        uint64_t open = mask_words ? mask_words[w] : ~(uint64_t)0;
+        const unsigned left = M - w * 64u;
+        if (left < 64u) open &= (((uint64_t)1 << left) - 1u);           /* channels beyond M do not exist */
+        while (open) {
+            const unsigned k = w * 64u + (unsigned)__builtin_ctzll(open);
+            open &= open - 1u;                                          /* lowest open channel first: channel order */
+            const float db = rssi_db[k];
+            sum_db += db;
+            n_open++;
+            if (best < 0 || db > best_db) { best = (int)k; best_db = db; }
         }
     }
-    if (max_i >= 0) {
-        rssi_avg /= (float)ch_en;
-        *max_rssi = rssi_max - rssi_avg;
-    }
-    return max_i;
+    if (best >= 0) *margin_db = best_db - sum_db / (float)n_open;
+    return best;
 }
 
 /* :828-874.  Returns 1 when the active channel changed (tuned, hopped or detuned), 0 otherwise. */
