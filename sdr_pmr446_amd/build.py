@@ -30,7 +30,10 @@ def kernel_sources_sha256():
     the kernels only; a plan change left a stale number marked fresh -- ADVICE r05.)"""
     import hashlib
     h = hashlib.sha256()
-    names = [f for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h", ".c"))]
+    # every kernel unit and shared header, and the host units that make the main chain's plan (pmr_chain*.c, pmr_design.c); NOT the
+    # host-only consumers that cannot change a launch of it (squelch logic, file I/O, the dsd_in host side)
+    names = [f for f in sorted(os.listdir(CSRC))
+             if f.endswith((".hip", ".hpp", ".h")) or (f.endswith(".c") and (f.startswith("pmr_chain") or f == "pmr_design.c"))]
     for f in names:
         h.update(f.encode() + b"\0")
         with open(os.path.join(CSRC, f), "rb") as fh:

@@ -55,3 +55,43 @@ def test_find_max_respects_mask_and_all_disabled():
     w = _words(((1 << 256) - 1) & ~(1 << 200), 256)
     assert L.pmr_find_max_rssi_channel(big.ctypes.data, 256, w.ctypes.data, 4, C.byref(mr)) == 70
     assert L.pmr_find_max_rssi_channel(big.ctypes.data, 256, w.ctypes.data, 3, C.byref(mr)) == -1
+
+
+def test_channel_selection_is_the_references_arithmetic_on_random_masks():
+    """pmr_find_max_rssi_channel walks the mask word by word (its own structure: lowest open channel first by ctz); the numbers must be the
+    reference's, bit for bit -- src/sdr_pmr446.c:668-700: float32 sum in channel order, strict '>' (ties to the lowest channel), max - mean --
+    for any M, multi-word masks, masks with closed words, ties, and no open channel at all (margin untouched)."""
+    import ctypes as C
+    import numpy as np
+    from sdr_pmr446_amd import chain
+    L = chain.load()
+    L.pmr_find_max_rssi_channel.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.POINTER(C.c_float)]
+    L.pmr_find_max_rssi_channel.restype = C.c_int
+    rng = np.random.default_rng(1)
+
+    def reference(r, M, mask):
+        best, mx, acc, n = -1, np.float32(0), np.float32(0), 0
+        for i in range(M):
+            if mask is not None and not (int(mask[i >> 6]) >> (i & 63)) & 1:
+                continue
+            n += 1
+            acc = np.float32(acc + r[i])
+            if best < 0 or r[i] > mx:
+                mx, best = r[i], i
+        return (best, np.float32(mx - np.float32(acc / np.float32(n)))) if best >= 0 else (-1, None)
+
+    for _ in range(600):
+        M = int(rng.choice([1, 4, 16, 63, 64, 65, 100, 128, 256, 1000, 1024, 4096]))
+        r = (rng.standard_normal(M) * 10 - 50).astype(np.float32)
+        if rng.random() < 0.3:
+            r[rng.integers(M)] = r.max()
+        nw = (M + 63) // 64
+        mask = None if rng.random() < 0.2 else (rng.integers(0, 2 ** 63, size=nw, dtype=np.uint64) * np.uint64(2)
+                                                 + rng.integers(0, 2, size=nw).astype(np.uint64))
+        if mask is not None and rng.random() < 0.2:
+            mask[:] = 0
+        out = C.c_float(123.0)
+        got = L.pmr_find_max_rssi_channel(r.ctypes.data, M, mask.ctypes.data if mask is not None else None, nw, C.byref(out))
+        want, margin = reference(r, M, mask)
+        assert got == want
+        assert (out.value == 123.0) if want < 0 else (np.float32(out.value) == margin)
